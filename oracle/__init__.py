@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE -- ctypes binding of the CPU restatement (oracle/tombo_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this, and only
+as the checker.  Parity status: pinned against tests/golden (generated from the live reference).
+"""
+import os
+import ctypes as C
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, '_build', 'libtombo_oracle.so')
+i64 = C.c_int64
+f64 = C.c_double
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int64)
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ('tombo_oracle.c', 'tombo_oracle.h')]
+    if (force or not os.path.exists(_LIB) or
+            os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in src)):
+        subprocess.check_call(['make', '-s', '-C', _HERE], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    return _LIB
+
+
+class Params(C.Structure):
+    _fields_ = [(n, f64) for n in ('match_evalue', 'skip_pen', 'max_half_z_score', 'z_shift',
+                                   'stay_pen')] + \
+               [(n, i64) for n in ('bandwidth', 'running_stat_width', 'min_obs_per_base',
+                                   'raw_min_obs_per_base', 'mean_obs_per_event',
+                                   'use_t_test_seg', 'band_bound_thresh', 'start_bw',
+                                   'start_save_bw', 'start_n_bases', 'do_winsorize_z')]
+
+
+class Opts(C.Structure):
+    _fields_ = [('has_outlier_thresh', i64), ('outlier_thresh', f64),
+                ('has_const_scale', i64), ('const_scale', f64),
+                ('has_scale_values', i64), ('sv_shift', f64), ('sv_scale', f64),
+                ('sv_has_lims', i64), ('sv_lower', f64), ('sv_upper', f64),
+                ('skip_seq_scaling', i64),
+                ('check_start_score', i64), ('sig_match_thresh', f64),
+                ('max_raw_cpts', i64), ('min_event_to_seq_ratio', f64),
+                ('kmer_width', i64), ('central_pos', i64),
+                ('use_rna_event_scale', i64), ('rna_scale_num_events', i64),
+                ('rna_scale_max_frac_events', f64)]
+
+
+class Debug(C.Structure):
+    _fields_ = [('valid_cpts', _pi), ('n_valid_cpts', i64), ('event_means', _pd),
+                ('seg_norm_signal', _pd), ('seg_scale_values', f64 * 4),
+                ('start_calls', f64 * 4), ('n_start_calls', i64),
+                ('band_event_starts', _pi), ('fwd_last_row', _pd), ('fwd_last_row_len', i64),
+                ('read_tb', _pi), ('dp_segs', _pi), ('dp_read_start', i64),
+                ('theil_sen', f64 * 4), ('used_static', i64), ('mask_seq_len', i64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_median.restype = f64
+        _lib.orc_np_sum.restype = f64
+    return _lib
+
+
+def _p(a, t=C.c_double):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def make_params(rp):
+    """th.resquiggleParams-like namedtuple -> Params"""
+    p = Params()
+    p.match_evalue, p.skip_pen = rp.match_evalue, rp.skip_pen
+    p.do_winsorize_z = 0 if rp.max_half_z_score is None else 1
+    p.max_half_z_score = 0.0 if rp.max_half_z_score is None else rp.max_half_z_score
+    p.z_shift, p.stay_pen = rp.z_shift, rp.stay_pen
+    for n in ('bandwidth', 'running_stat_width', 'min_obs_per_base', 'raw_min_obs_per_base',
+              'mean_obs_per_event', 'band_bound_thresh', 'start_bw', 'start_save_bw',
+              'start_n_bases'):
+        setattr(p, n, int(getattr(rp, n)))
+    p.use_t_test_seg = int(bool(rp.use_t_test_seg))
+    return p
+
+
+def make_opts(kmer_width, central_pos, outlier_thresh=None, const_scale=None, scale_values=None,
+              skip_seq_scaling=False, sig_match_thresh=None, max_raw_cpts=200,
+              min_event_to_seq_ratio=1.1):
+    o = Opts()
+    o.has_outlier_thresh = int(outlier_thresh is not None)
+    o.outlier_thresh = 0.0 if outlier_thresh is None else float(outlier_thresh)
+    o.has_const_scale = int(const_scale is not None)
+    o.const_scale = 0.0 if const_scale is None else float(const_scale)
+    o.has_scale_values = int(scale_values is not None)
+    if scale_values is not None:
+        o.sv_shift, o.sv_scale = float(scale_values.shift), float(scale_values.scale)
+        o.sv_has_lims = int(scale_values.lower_lim is not None and
+                            scale_values.upper_lim is not None)
+        if o.sv_has_lims:
+            o.sv_lower, o.sv_upper = float(scale_values.lower_lim), float(scale_values.upper_lim)
+    o.skip_seq_scaling = int(bool(skip_seq_scaling))
+    o.check_start_score = int(sig_match_thresh is not None)
+    o.sig_match_thresh = 0.0 if sig_match_thresh is None else float(sig_match_thresh)
+    o.max_raw_cpts = -1 if max_raw_cpts is None else int(max_raw_cpts)
+    o.min_event_to_seq_ratio = float(min_event_to_seq_ratio)
+    o.kmer_width, o.central_pos = int(kmer_width), int(central_pos)
+    o.use_rna_event_scale, o.rna_scale_num_events, o.rna_scale_max_frac_events = 1, 10000, 0.75
+    return o
+
+
+def resquiggle_read(raw, seq_codes, kmer_means, kmer_sds, params, opts, stall_ints=None,
+                    samp_ind=None, debug=False):
+    """Runs the CPU restatement on one read.  Returns dict(status=..., segs=..., ...)."""
+    L = lib()
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    seq_codes = np.ascontiguousarray(seq_codes, dtype=np.uint8)
+    n_raw, seq_len = raw.shape[0], seq_codes.shape[0]
+    B = seq_len - int(opts.kmer_width) + 1
+    segs = np.zeros(max(B + 1, 1), dtype=np.int64)
+    norm = np.zeros(n_raw, dtype=np.float64)
+    rs, nl, changed = i64(0), i64(0), i64(0)
+    sv = np.zeros(4)
+    score = f64(0)
+    stall = None
+    n_stall = 0
+    if stall_ints is not None:
+        stall = np.ascontiguousarray(np.array(stall_ints, dtype=np.int64).reshape(-1, 2))
+        n_stall = stall.shape[0]
+    si = None if samp_ind is None else np.ascontiguousarray(samp_ind, dtype=np.int64)
+    dbg = None
+    keep = {}
+    if debug:
+        dbg = Debug()
+        ne = max(n_raw // int(params.mean_obs_per_event), int(B * 1.1)) + 8
+        keep = dict(valid_cpts=np.zeros(ne, np.int64), event_means=np.zeros(ne),
+                    seg_norm_signal=np.zeros(n_raw), band_event_starts=np.zeros(max(B, 1), np.int64),
+                    fwd_last_row=np.zeros(max(int(params.bandwidth), 4096) + ne),
+                    read_tb=np.zeros(max(B + 1, 1), np.int64),
+                    dp_segs=np.zeros(max(B + 1, 1), np.int64))
+        for k, v in keep.items():
+            setattr(dbg, k, _p(v, C.c_int64 if v.dtype == np.int64 else C.c_double))
+    rc = L.orc_resquiggle_read(
+        _p(raw), i64(n_raw), _p(seq_codes, C.c_uint8), i64(seq_len), _p(kmer_means), _p(kmer_sds),
+        C.byref(params), C.byref(opts), _p(stall, C.c_int64), i64(n_stall),
+        _p(si, C.c_int64), i64(0 if si is None else si.shape[0]),
+        _p(segs, C.c_int64), C.byref(rs), _p(norm), C.byref(nl), _p(sv), C.byref(score),
+        C.byref(changed), None if dbg is None else C.byref(dbg))
+    out = dict(status=int(rc))
+    if rc == 0:
+        out.update(segs=segs[:B + 1], read_start_rel_to_raw=int(rs.value),
+                   norm_signal=norm[:nl.value], scale_values=sv,
+                   sig_match_score=float(score.value),
+                   norm_params_changed=bool(changed.value))
+    if debug:
+        n = int(dbg.n_valid_cpts)
+        out['dbg'] = dict(
+            valid_cpts=keep['valid_cpts'][:n], event_means=keep['event_means'][:max(n - 1, 0)],
+            seg_norm_signal=keep['seg_norm_signal'],
+            seg_scale_values=np.array(list(dbg.seg_scale_values)),
+            start_calls=np.array(list(dbg.start_calls)), n_start_calls=int(dbg.n_start_calls),
+            band_event_starts=keep['band_event_starts'],
+            fwd_last_row=keep['fwd_last_row'][:int(dbg.fwd_last_row_len)],
+            read_tb=keep['read_tb'], dp_segs=keep['dp_segs'],
+            dp_read_start=int(dbg.dp_read_start), theil_sen=np.array(list(dbg.theil_sen)),
+            used_static=bool(dbg.used_static), mask_seq_len=int(dbg.mask_seq_len))
+    return out

@@ -187,7 +187,8 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
             out['read_start_rel_to_raw'] = np.int64(res.read_start_rel_to_raw)
             fsummary('norm_signal', res.raw_signal, out, full)
             sv = res.scale_values
-            out['scale_values'] = np.array([sv.shift, sv.scale, sv.lower_lim, sv.upper_lim])
+            out['scale_values'] = np.array([np.nan if v is None else v for v in (
+                sv.shift, sv.scale, sv.lower_lim, sv.upper_lim)], dtype=np.float64)
             out['sig_match_score'] = np.float64(res.sig_match_score)
             out['norm_params_changed'] = np.bool_(res.norm_params_changed)
             meta['median_abs_boundary_err'] = float(np.median(np.abs(
@@ -209,7 +210,8 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
                     fsummary('it2_norm_signal', res2.raw_signal, out, full)
                     sv = res2.scale_values
                     out['it2_scale_values'] = np.array(
-                        [sv.shift, sv.scale, sv.lower_lim, sv.upper_lim])
+                        [np.nan if v is None else v for v in (
+                            sv.shift, sv.scale, sv.lower_lim, sv.upper_lim)], dtype=np.float64)
                     out['it2_sig_match_score'] = np.float64(res2.sig_match_score)
                     out['it2_norm_params_changed'] = np.bool_(res2.norm_params_changed)
     finally:
