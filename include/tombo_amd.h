@@ -1,0 +1,190 @@
+/* include/tombo_amd.h -- C ABI of the MI355X-native resquiggle engine (libtombo_amd.so).
+ *
+ * Drop-in boundary for the hot path of nanoporetech/tombo v1.5.1: everything below
+ * tombo.resquiggle.resquiggle_read() (tombo/resquiggle.py:1122-1214) -- i.e. the twelve
+ * Python-callable Cython kernels of tombo/_c_dynamic_programming.pyx and tombo/_c_helper.pyx
+ * plus the numpy glue between them -- runs as HIP kernels for gfx950 behind these entry points.
+ * Plain pointers and sizes only; caller owns every host buffer; no exceptions cross the ABI:
+ * every per-read failure is a status code (TBA_* below == the reference's TomboError strings,
+ * table in tombo_amd/errors.py).  All arithmetic on the path is IEEE float64 / int64 in the
+ * reference's operation order (device code is built with -ffp-contract=off).
+ *
+ * Two levels:
+ *   1. the batch engine (tba_engine_*, tba_batch_*): N reads packed as ragged SoA buffers, one
+ *      fixed kernel sequence per batch on one HIP stream; this is what resquiggle_read /
+ *      resquiggle_batch call and what bench.py times (inputs resident in HBM).
+ *   2. per-kernel entry points (tba_c_*): one call == one call of the Cython function it
+ *      cites, same argument meaning, host pointers in / host pointers out, executed by the same
+ *      device code (batch of one).  These are what a maintainer binds in place of the Cython
+ *      modules (INTEGRATION.md shows the ctypes stubs).
+ */
+#ifndef TOMBO_AMD_H
+#define TOMBO_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (per read) ------------------------------------------------------------ */
+enum {
+    TBA_OK = 0,
+    TBA_TOO_MUCH_SIGNAL = 1,        /* resquiggle.py:1160 */
+    TBA_FEWER_CPTS = 2,             /* _c_helper.pyx:118,200 */
+    TBA_READ_TOO_SHORT_START = 3,   /* resquiggle.py:704 */
+    TBA_MAP_TOO_SHORT_START = 4,    /* resquiggle.py:706 */
+    TBA_POOR_START = 5,             /* resquiggle.py:745 */
+    TBA_INVALID_START_PATH = 6,     /* tombo_stats.py:2356 */
+    TBA_OPEN_PORE = 7,              /* resquiggle.py:1009 */
+    TBA_STARTS_TOO_FAR = 8,         /* resquiggle.py:612 */
+    TBA_MASK_TOO_FEW = 9,           /* resquiggle.py:672 */
+    TBA_ADAPT_BEYOND = 10,          /* _c_dynamic_programming.pyx:354 */
+    TBA_BEYOND_BANDWIDTH = 11,      /* _c_dynamic_programming.pyx:305 */
+    TBA_DISCORDANT = 12,            /* resquiggle.py:976 */
+    TBA_NOT_ENOUGH_DEL_SIGNAL = 13, /* resquiggle.py:490 */
+    TBA_TOO_MANY_DELS = 14,         /* resquiggle.py:495 */
+    TBA_INVALID_SEG = 15,           /* resquiggle.py:530 */
+    TBA_ZERO_LEN = 16,              /* resquiggle.py:534 */
+    TBA_NEG_START = 17,             /* resquiggle.py:536 */
+    TBA_PAST_END = 18,              /* resquiggle.py:538 */
+    TBA_RESCALE_FAIL = 19,          /* tombo_stats.py:421 */
+    TBA_SEQ_SEG_MISMATCH = 20,      /* resquiggle.py:1201 */
+    TBA_NO_RAW = 21,                /* resquiggle.py:1148 */
+    TBA_INVALID_SEQ = 22,           /* tombo_stats.py:858 */
+    TBA_INTERNAL = 100,             /* the reference would raise a non-Tombo exception here */
+    TBA_UNSUPPORTED = 101           /* valid in the reference, outside this engine's limits
+                                       (band wider than TBA_MAX_BAND, scratch arena exhausted) */
+};
+/* call-level return values of the functions below (0 == success) */
+enum { TBA_E_ARG = -1, TBA_E_HIP = -2, TBA_E_NOMEM = -3, TBA_E_STATE = -4 };
+
+#define TBA_MAX_BAND 3072 /* widest DP band (cells per row) the wave-per-read kernel carries */
+
+/* th.resquiggleParams (tombo/tombo_helper.py:173-198) */
+typedef struct {
+    double match_evalue, skip_pen, max_half_z_score, z_shift, stay_pen;
+    int64_t bandwidth, running_stat_width, min_obs_per_base, raw_min_obs_per_base,
+        mean_obs_per_event, use_t_test_seg, band_bound_thresh, start_bw, start_save_bw,
+        start_n_bases;
+    int64_t do_winsorize_z; /* max_half_z_score is not None */
+} tba_params;
+
+/* remaining arguments of resquiggle_read (resquiggle.py:1122-1127) that apply to a whole batch */
+typedef struct {
+    int64_t has_outlier_thresh; double outlier_thresh;
+    int64_t has_const_scale;    double const_scale;
+    int64_t skip_seq_scaling;
+    int64_t check_start_score;  double sig_match_thresh; /* seq_samp_type given */
+    int64_t max_raw_cpts;                                 /* < 0: None */
+    double  min_event_to_seq_ratio;
+    int64_t use_rna_event_scale, rna_scale_num_events;    /* _default_parameters.py:78-80 */
+    double  rna_scale_max_frac_events;
+} tba_opts;
+
+typedef struct tba_engine tba_engine;
+
+/* ---- engine ----------------------------------------------------------------------------- */
+/* One engine per process per GPU (reads shard across GPUs by process; no collective).
+ * device: HIP ordinal.  Fails with TBA_E_HIP when no gfx950 device is usable: there is no CPU
+ * fallback in this library. */
+int  tba_engine_create(int device, tba_engine **out);
+void tba_engine_destroy(tba_engine *e);
+const char *tba_last_error(void);
+int  tba_device_count(void);
+
+/* canonical k-mer level table, lexicographic k-mer order (TomboModel, tombo_stats.py:580-919;
+ * lookup replaces get_exp_levels_from_seq :834-862) */
+int tba_set_model(tba_engine *e, const double *kmer_means, const double *kmer_sds,
+                  int64_t kmer_width, int64_t central_pos);
+
+/* ---- batch pipeline == resquiggle_read() for n_reads reads -------------------------------
+ * raw_off[n+1], seq_off[n+1]: CSR offsets into raw (float64 pA / DAC values) and seq (uint8
+ * codes 0..3 = ACGT, genome_seq including the k-mer flanks).
+ * Optional per-read inputs (NULL to omit):
+ *   sv_in[n][4] + sv_flags[n]: map_res.scale_values (shift, scale, lower, upper); flag bit0 =
+ *       scale values given, bit1 = limits given (second and later run_rsqgl_iters passes,
+ *       resquiggle.py:1498-1503);
+ *   samp_ind[n][1000]: the np.random.choice subsample of calc_kmer_fitted_shift_scale
+ *       (tombo_stats.py:411-416); required for reads with more than 1000 bases unless
+ *       skip_seq_scaling;
+ *   stall_off[n+1], stall_ints[][2]: map_res.stall_ints (RNA).
+ */
+int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_opts *o, int64_t n_reads,
+                     const double *raw, const int64_t *raw_off,
+                     const uint8_t *seq, const int64_t *seq_off,
+                     const double *sv_in, const int32_t *sv_flags,
+                     const int64_t *samp_ind,
+                     const int64_t *stall_ints, const int64_t *stall_off);
+/* runs the whole kernel sequence on the uploaded batch; returns after the stream is idle */
+int tba_batch_run(tba_engine *e);
+/* same, but only enqueues (for timing with events / overlapping); pair with tba_batch_sync */
+int tba_batch_enqueue(tba_engine *e);
+int tba_batch_sync(tba_engine *e);
+/* Outputs (any pointer may be NULL):
+ *   status[n]; segs (CSR by seg_off[i] = seq_off[i] - i*(K-1) + i, B_i+1 entries per read);
+ *   read_start_rel_to_raw[n]; norm_signal (same CSR as raw; first norm_len[i] entries valid);
+ *   scale_values[n][4]; sig_match_score[n]; norm_params_changed[n] */
+int tba_batch_download(tba_engine *e, int32_t *status, int64_t *segs,
+                       int64_t *read_start_rel_to_raw, double *norm_signal, int64_t *norm_len,
+                       double *scale_values, double *sig_match_score,
+                       int32_t *norm_params_changed);
+/* stage-wise intermediates of the last run, for parity tests (what: TBA_GET_*; CSR layouts in
+ * tombo_amd/_native.py) */
+enum {
+    TBA_GET_VALID_CPTS = 1,   /* int64, CSR by ev_off (capacity num_events per read) */
+    TBA_GET_N_CPTS = 2,       /* int64[n] */
+    TBA_GET_EVENT_MEANS = 3,  /* float64, CSR by ev_off */
+    TBA_GET_SEG_NORM = 4,     /* float64, CSR by raw_off: normalised signal before trimming */
+    TBA_GET_SEG_SV = 5,       /* float64[n][4] */
+    TBA_GET_START = 6,        /* float64[n][4]: (loc, events_per_base) of call 0 and call 1 */
+    TBA_GET_BAND_STARTS = 7,  /* int64, CSR by ref_off (B per read) */
+    TBA_GET_READ_TB = 8,      /* int64, CSR by seg_off */
+    TBA_GET_DP_SEGS = 9,      /* int64, CSR by seg_off */
+    TBA_GET_THEIL_SEN = 10,   /* float64[n][4] */
+    TBA_GET_PATH = 11,        /* int32[n][4]: path (1 adaptive, 2 static), n_static, W, n_start_calls */
+    TBA_GET_LAST_ROW = 12,    /* float64[n][TBA_MAX_BAND]: last forward-pass row */
+    TBA_GET_DP_READ_START = 13, /* int64[n] */
+    TBA_GET_KERNEL_MS = 14    /* float32[32]: per-stage GPU time of the last run (events) */
+};
+int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_bytes);
+/* bytes of algorithmic traffic / cell updates of the last uploaded batch */
+int tba_batch_stats(tba_engine *e, double *algorithmic_bytes, double *dp_cells);
+
+/* ---- per-kernel entry points (one call == one Cython call; host buffers) ----------------- */
+/* c_adaptive_banded_forward_pass, _c_dynamic_programming.pyx:314-412: fwd_pass[(n_bases+1)*bw],
+ * fwd_pass_tb[(n_bases+1)*bw] (int64 moves) and event_starts[n_bases] are updated in place
+ * from row start_seq_pos. */
+int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pass, int64_t *fwd_pass_tb,
+    int64_t n_bases, int64_t bandwidth, int64_t *event_starts, const double *event_means,
+    int64_t n_events, const double *r_ref_means, const double *r_ref_sds, double z_shift,
+    double skip_pen, double stay_pen, int64_t start_seq_pos, double mask_fill_z_score,
+    int do_winsorize_z, double max_half_z_score);
+/* c_banded_forward_pass, pyx:240-279 */
+int tba_c_banded_forward_pass(tba_engine *e, const double *shifted_z_scores, int64_t n_bases,
+    int64_t bandwidth, const int64_t *event_starts, double skip_pen, double stay_pen,
+    double *fwd_pass, int64_t *fwd_pass_tb);
+/* c_banded_traceback, pyx:281-310 */
+int tba_c_banded_traceback(tba_engine *e, const int64_t *fwd_pass_tb, int64_t n_bases,
+    int64_t bandwidth, const int64_t *event_starts, int64_t band_pos,
+    int64_t band_boundary_thresh, int64_t *seq_poss);
+/* c_base_z_scores, pyx:17-32 */
+int tba_c_base_z_scores(tba_engine *e, const double *b_sig, int64_t n, double ref_mean,
+    double ref_sd, int do_winsorize_z, double max_half_z_score, double *out);
+/* c_new_means, _c_helper.pyx:59-71 */
+int tba_c_new_means(tba_engine *e, const double *norm_signal, int64_t n_sig,
+    const int64_t *new_segs, int64_t n_segs, double *means);
+/* c_apply_outlier_thresh, _c_helper.pyx:73-87 */
+int tba_c_apply_outlier_thresh(tba_engine *e, const double *sig, int64_t n, double lower_lim,
+    double upper_lim, double *out);
+/* c_valid_cpts_w_cap, _c_helper.pyx:89-120 (+ the sort of tombo_helper.py:76-82);
+ * returns a TBA_* status (TBA_FEWER_CPTS ...) */
+int tba_c_valid_cpts_w_cap(tba_engine *e, const double *sig, int64_t n, int64_t min_base_obs,
+    int64_t running_stat_width, int64_t num_cpts, int64_t *cpts);
+/* c_valid_cpts_w_cap_t_test, _c_helper.pyx:144-202 (+ sort) */
+int tba_c_valid_cpts_w_cap_t_test(tba_engine *e, const double *sig, int64_t n,
+    int64_t min_base_obs, int64_t running_stat_width, int64_t num_cpts, int64_t *cpts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

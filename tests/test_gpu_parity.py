@@ -1,0 +1,254 @@
+"""GPU parity tests proper: the HIP batch engine (through the C ABI) against the CPU oracle on
+the same seeded inputs, stage by stage, and against the committed golden fixtures.
+
+Bar: bit-exact for every integer output (change points, band starts, traceback, segment
+boundaries, statuses); float64 outputs compared bit-exactly where the arithmetic is restated
+operation by operation, with the contractual 1e-5 tolerance on the normalised signal asserted
+separately.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from tombo_amd import resquiggle as rq
+    return rq.get_engine(0)
+
+
+def _oracle_read(model, params, raw, seq, outlier_thresh, samp_name, stall_ints=None,
+                 samp_ind=None, scale_values=None, const_scale=None, skip_seq_scaling=False):
+    import oracle
+    from tombo_amd import tombo_stats as ts
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    p = oracle.make_params(params)
+    o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=outlier_thresh,
+                         const_scale=const_scale, scale_values=scale_values,
+                         skip_seq_scaling=skip_seq_scaling,
+                         sig_match_thresh=SIG_MATCH_THRESH[samp_name])
+    return oracle.resquiggle_read(raw, ts.encode_seq(seq), model.level_means, model.level_sds,
+                                  p, o, stall_ints=stall_ints, samp_ind=samp_ind, debug=True)
+
+
+def compare_batch(eng, oracles, out, label=''):
+    """Stage-wise comparison of one engine batch with per-read oracle results.
+    Returns a list of mismatch descriptions (empty == parity)."""
+    from tombo_amd import _native as N
+    bad = []
+    n = len(oracles)
+    cpts = eng.get(N.GET_VALID_CPTS)
+    ncp = eng.get(N.GET_N_CPTS)
+    evm = eng.get(N.GET_EVENT_MEANS)
+    segnorm = eng.get(N.GET_SEG_NORM)
+    start = eng.get(N.GET_START)
+    bst = eng.get(N.GET_BAND_STARTS)
+    rtb = eng.get(N.GET_READ_TB)
+    dps = eng.get(N.GET_DP_SEGS)
+    dprs = eng.get(N.GET_DP_READ_START)
+    tsn = eng.get(N.GET_THEIL_SEN)
+    path = eng.get(N.GET_PATH)
+    lastrow = eng.get(N.GET_LAST_ROW)
+
+    def chk(i, name, a, b, exact=True):
+        a, b = np.asarray(a), np.asarray(b)
+        if a.shape != b.shape:
+            bad.append('%s read %d %s: shape %s vs %s' % (label, i, name, a.shape, b.shape))
+            return False
+        if not np.array_equal(a, b):
+            d = np.flatnonzero(a != b)
+            bad.append('%s read %d %s: %d/%d differ, first at %d: gpu=%r oracle=%r' % (
+                label, i, name, d.size, a.size, d[0], a.flat[d[0]], b.flat[d[0]]))
+            return False
+        return True
+
+    for i, o in enumerate(oracles):
+        st = int(out['status'][i])
+        if st != o['status']:
+            bad.append('%s read %d status: gpu=%d oracle=%d' % (label, i, st, o['status']))
+        d = o['dbg']
+        e0 = eng.ev_off[i]
+        if o['status'] in (1,):
+            continue
+        ok = chk(i, 'n_cpts', ncp[i], len(d['valid_cpts']))
+        if len(d['valid_cpts']):
+            ok = ok and chk(i, 'valid_cpts', cpts[e0:e0 + int(ncp[i])], d['valid_cpts'])
+            chk(i, 'seg_norm', segnorm[eng.raw_off[i]:eng.raw_off[i + 1]], d['seg_norm_signal'])
+            chk(i, 'event_means', evm[e0:e0 + max(int(ncp[i]) - 1, 0)], d['event_means'])
+        if d['n_start_calls'] >= 1 and path[i, 3] >= 1:
+            k = d['n_start_calls']
+            chk(i, 'start', start[i, 2 * (k - 1):2 * k], d['start_calls'][2 * (k - 1):2 * k])
+        if o['status'] == 0 or d['dp_segs'].any():
+            chk(i, 'used_static', int(path[i, 0] == 2), int(d['used_static']))
+            r0, r1 = eng.ref_off[i], eng.ref_off[i + 1]
+            s0, s1 = eng.seg_off[i], eng.seg_off[i + 1]
+            if not d['used_static']:
+                chk(i, 'mask_seq_len', path[i, 1], d['mask_seq_len'])
+                chk(i, 'band_starts', bst[r0:r1], d['band_event_starts'])
+                chk(i, 'last_row', lastrow[i, :len(d['fwd_last_row'])], d['fwd_last_row'])
+            chk(i, 'read_tb', rtb[s0:s1], d['read_tb'])
+            chk(i, 'dp_segs', dps[s0:s1], d['dp_segs'])
+            chk(i, 'dp_read_start', dprs[i], d['dp_read_start'])
+        if o['status'] == 0 and st == 0:
+            s0, s1 = eng.seg_off[i], eng.seg_off[i + 1]
+            chk(i, 'segs', out['segs'][s0:s1], o['segs'])
+            chk(i, 'read_start', out['read_start'][i], o['read_start_rel_to_raw'])
+            chk(i, 'theil_sen', tsn[i], d['theil_sen'])
+            nl = int(out['norm_len'][i])
+            gn = out['norm'][eng.raw_off[i]:eng.raw_off[i] + nl]
+            if chk(i, 'norm_len', nl, len(o['norm_signal'])):
+                chk(i, 'norm_signal', gn, o['norm_signal'])
+                if np.max(np.abs(gn - o['norm_signal'])) > 1e-5:
+                    bad.append('%s read %d norm_signal beyond 1e-5' % (label, i))
+            chk(i, 'scale_values', out['sv'][i][:2], o['scale_values'][:2])
+            chk(i, 'score', out['score'][i], o['sig_match_score'])
+            chk(i, 'changed', bool(out['changed'][i]), o['norm_params_changed'])
+    return bad
+
+
+def run_batch(model, params, samp_name, reads, outlier_thresh=5.0, const_scale=None,
+              skip_seq_scaling=False, scale_values=None, seed0=None):
+    """reads: list of (raw, seq, stall_ints, samp_ind).  Returns (engine, out, oracles)."""
+    from tombo_amd import _native as N, tombo_stats as ts
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    eng = _engine()
+    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+    n = len(reads)
+    p = N.make_params(params)
+    o = N.make_opts(outlier_thresh=outlier_thresh, const_scale=const_scale,
+                    skip_seq_scaling=skip_seq_scaling,
+                    sig_match_thresh=SIG_MATCH_THRESH[samp_name])
+    si = np.zeros((n, 1000), np.int64)
+    for i, r in enumerate(reads):
+        if r[3] is not None:
+            si[i] = r[3]
+    sv_in = sv_flags = None
+    if scale_values is not None:
+        sv_in = np.array([[sv.shift, sv.scale, sv.lower_lim, sv.upper_lim]
+                          for sv in scale_values], dtype=np.float64)
+        sv_flags = np.full(n, 3, np.int32)
+    stalls = [r[2] for r in reads]
+    eng.upload(p, o, [np.asarray(r[0], np.float64) for r in reads],
+               [ts.encode_seq(r[1]) for r in reads], sv_in=sv_in, sv_flags=sv_flags,
+               samp_ind=si, stall_ints=stalls if any(s is not None for s in stalls) else None)
+    eng.run()
+    out = eng.download()
+    oracles = []
+    for i, r in enumerate(reads):
+        oracles.append(_oracle_read(
+            model, params, r[0], r[1], outlier_thresh, samp_name, stall_ints=r[2],
+            samp_ind=r[3], const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
+            scale_values=None if scale_values is None else scale_values[i]))
+    return eng, out, oracles
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_golden_case_on_gpu(golden_case, name):
+    """every committed golden fixture through the HIP path (batch of one) vs the oracle, and the
+    final outputs vs the reference's recorded values"""
+    from tombo_amd import errors
+    c = golden_case(name)
+    m = c.meta
+    eng, out, oracles = run_batch(
+        c.model, c.params, m['samp'], [(c.raw, c.seq, c.stall_ints, c.samp_ind())],
+        outlier_thresh=m['outlier_thresh'], const_scale=m['const_scale'],
+        skip_seq_scaling=m['skip_seq_scaling'])
+    bad = compare_batch(eng, oracles, out, name)
+    assert not bad, '\n'.join(bad)
+    g = c.g
+    if c.error:
+        assert errors.message(out['status'][0]) == c.error
+    else:
+        assert out['status'][0] == 0
+        np.testing.assert_array_equal(out['segs'], g['segs'])
+        assert out['read_start'][0] == int(g['read_start_rel_to_raw'])
+        c.check_float('norm_signal', out['norm'][:int(out['norm_len'][0])])
+        assert out['score'][0] == float(g['sig_match_score'])
+
+
+def test_mixed_dna_batch_on_gpu():
+    """one ragged batch mixing lengths / paths (adaptive, static fallback, retry, failures)"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    reads = []
+    specs = [(600, 1, {}), (150, 2, {}), (1200, 3, {}), (300, 4, {}), (1500, 5, dict(lead=5000)),
+             (20, 6, dict(lead=60000)), (400, 7, dict(mean_dwell=400)), (2000, 8, {}),
+             (260, 9, {}), (1001, 10, {}), (999, 11, {}), (700, 12, dict(mean_dwell=4)),
+             (800, 13, dict(noise_sd=0.6)), (500, 14, dict(n_trail=3000))]
+    for nb, seed, kw in specs:
+        k = dict(synth.DNA_SYNTH)
+        k.update(kw)
+        seq, raw, _ = synth.synth_read(model, nb, 500 + seed, **k)
+        si = None
+        if nb > 1000:
+            st = np.random.get_state()
+            np.random.seed(seed)
+            si = np.random.choice(nb, 1000, replace=False)
+            np.random.set_state(st)
+        reads.append((raw, seq, None, si))
+    eng, out, oracles = run_batch(model, params, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'mixed')
+    assert not bad, '\n'.join(bad[:40])
+    assert sum(o['status'] == 0 for o in oracles) >= 8
+
+
+def test_many_seeds_w100_on_gpu():
+    """BASELINE configs[0] shape (2 kb reads, bandwidth 100, band_bound_thresh 10), 48 seeds"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=100, band_bound_thresh=10)
+    reads = []
+    for seed in range(48):
+        seq, raw, _ = synth.synth_read(model, 2000, 9000 + seed, **synth.DNA_SYNTH)
+        st = np.random.get_state()
+        np.random.seed(seed)
+        si = np.random.choice(2000, 1000, replace=False)
+        np.random.set_state(st)
+        reads.append((raw, seq, None, si))
+    eng, out, oracles = run_batch(model, params, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'w100')
+    assert not bad, '\n'.join(bad[:40])
+    assert all(o['status'] == 0 for o in oracles)
+
+
+def test_second_iteration_on_gpu(golden_case):
+    """run_rsqgl_iters (resquiggle.py:1492-1504): re-run with fitted scale values"""
+    from tombo_amd import tombo_helper as th
+    c = golden_case('dna_b2000_w300')
+    g = c.g
+    sv = g['scale_values']
+    svs = [th.scaleValues(sv[0], sv[1], sv[2], sv[3], 5.0)]
+    eng, out, oracles = run_batch(c.model, c.params, 'DNA',
+                                  [(c.raw, c.seq, None, c.samp_ind())], scale_values=svs)
+    bad = compare_batch(eng, oracles, out, 'iter2')
+    assert not bad, '\n'.join(bad)
+    np.testing.assert_array_equal(out['segs'], g['it2_segs'])
+    assert out['score'][0] == float(g['it2_sig_match_score'])
+
+
+def test_resquiggle_read_dropin_on_gpu(golden_case):
+    """the Python drop-in: same call as the reference, same result tuple"""
+    from tombo_amd import resquiggle as rq, tombo_helper as th
+    c = golden_case('dna_b2000_w300')
+    g = c.g
+    mr = th.resquiggleResults(
+        align_info=th.alignInfo('r', 'BaseCalled_template', 0, 0, 0, 0, 2000, 0),
+        genome_loc=th.genomeLocation(0, '+', 'synth'), genome_seq=c.seq, mean_q_score=10.0,
+        raw_signal=c.raw)
+    np.random.seed(c.meta['np_seed'])
+    res = rq.resquiggle_read(mr, c.model, c.params, 5.0, seq_samp_type=c.samp)
+    np.testing.assert_array_equal(res.segs, g['segs'])
+    assert res.read_start_rel_to_raw == int(g['read_start_rel_to_raw'])
+    assert res.sig_match_score == float(g['sig_match_score'])
+    assert res.norm_params_changed == bool(g['norm_params_changed'])
+    assert len(res.genome_seq) == 2000
+    c.check_float('norm_signal', res.raw_signal)
+    bad = golden_case('dna_dwell400_bandfail')
+    mr2 = mr._replace(genome_seq=bad.seq, raw_signal=bad.raw)
+    with pytest.raises(th.TomboError, match='extends beyond bandwidth'):
+        rq.resquiggle_read(mr2, bad.model, bad.params, 5.0, seq_samp_type=bad.samp)

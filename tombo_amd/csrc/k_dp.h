@@ -1,0 +1,470 @@
+// k_dp.h -- event-to-sequence banded dynamic programming: one read per wavefront.
+//
+// Restates c_banded_forward_pass / c_adaptive_banded_forward_pass / c_process_band / c_argmax /
+// c_banded_traceback (_c_dynamic_programming.pyx:186-412) and their callers
+// find_seq_start_in_events, _get_masked_start_fwd_pass, find_static_base_assignment,
+// find_adaptive_base_assignment (resquiggle.py:547-1050).
+//
+// Layout: the two live band rows sit in LDS (transposed so that both "my CPL cells" and
+// "previous row shifted by the band offset" are conflict-free); each lane owns CPL contiguous
+// band cells in registers.  Cell update (pyx:213-234): v[b] = max(stay, diag, skip) with
+// stay = (v[b-1] - stay_pen) + z[b] serial along the row.  The diag/skip candidates are
+// independent per cell; the stay chain is resolved *exactly* by a monotone fixed-point sweep:
+// every lane walks its CPL cells from a guessed incoming value (-inf first), lanes exchange
+// chunk-exit values with a wave shuffle, and the sweep repeats until no incoming value changes.
+// At the fixed point every cell was produced by the reference's own expression from the exact
+// left neighbour (induction from lane 0), so rows, moves and the argmax-driven band placement
+// are bit-identical to the sequential code.  No MFMA: this is a scalar max-plus recurrence.
+#pragma once
+#include "tba_common.h"
+#include <math.h>
+
+__host__ __device__ inline int cpl_class(i64 W)
+{
+    const int cls[] = {4, 8, 12, 16, 24, 32, 48};
+    for (int i = 0; i < 7; i++) if ((i64)cls[i] * 64 >= W) return cls[i];
+    return 0;
+}
+
+enum { DP_START_TRY = 0, DP_START_RETRY = 1, DP_MAIN = 2 };
+
+template <int CPL>
+__global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, int mode,
+    const double *event_means, const double *ref_means, const double *ref_sds,
+    i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,
+    unsigned char *moves, i64 start_moves_stride, double *last_row)
+{
+    __shared__ double rows[2][CPL * 64];
+    ReadState &r = rs[blockIdx.x];
+    if (r.status != TBA_OK) return;
+    const tba_params &P = dp->p;
+    const int lane = threadIdx.x;
+
+    i64 W, n_rows, n_static, n_ev, ev_base;
+    bool identity;
+    unsigned char *mv;
+    if (mode == DP_MAIN) {
+        if (r.path == PATH_NONE) return;
+        W = r.W;
+        if (cpl_class(W) != CPL) return;
+        n_rows = r.B;
+        n_static = r.n_static;
+        ev_base = r.ev_off + r.clip;
+        n_ev = r.n_ev - r.clip;
+        identity = false;
+        mv = moves + r.moves_off;
+    } else {
+        if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
+        W = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
+        n_rows = P.start_n_bases;
+        n_static = n_rows;
+        ev_base = r.ev_off;
+        n_ev = r.n_ev;
+        identity = true;
+        mv = moves + (i64)blockIdx.x * start_moves_stride;
+    }
+    const double *ev = event_means + ev_base;
+    const double *rmu = ref_means + r.ref_off;
+    const double *rsd = ref_sds + r.ref_off;
+    i64 *bst = band_starts + r.ref_off;
+    const i32 *lo_a = lo_arr + r.ref_off;
+    const i32 *hi_a = hi_arr + r.ref_off;
+    const double stay_pen = P.stay_pen, skip_pen = P.skip_pen, z_shift = P.z_shift;
+    const double max_half_z = P.max_half_z_score;
+    const bool winsor = P.do_winsorize_z != 0;
+    const double fill_masked = dp->fill_masked;
+    const i64 half_bw = W / 2; // integer division, pyx:327
+    const double NEG_INF = -INFINITY;
+    const i64 mv_stride = (i64)CPL * 64;
+
+    double *prev = rows[0], *cur = rows[1];
+#pragma unroll
+    for (int j = 0; j < CPL; j++) prev[j * 64 + lane] = 0.0; // row 0: zeros (pyx:253-254)
+    __syncthreads();
+
+    i64 prev_start = 0;
+    i64 am = 0; // argmax of the previous row (row 0: all zeros -> 0)
+    double v[CPL];
+    for (i64 row = 0; row < n_rows; row++) {
+        i64 cur_start;
+        i64 lo, hi;
+        double fill;
+        if (row < n_static) {
+            if (identity) { cur_start = row; lo = 0; hi = W; }
+            else { cur_start = bst[row]; lo = lo_a[row]; hi = hi_a[row]; }
+            fill = fill_masked;
+        } else {
+            // adaptive band placement, pyx:342-358
+            cur_start = prev_start + am - half_bw + 1;
+            if (cur_start < prev_start) cur_start = prev_start;
+            if (cur_start >= n_ev) {
+                if (row < n_rows - 2) {
+                    if (lane == 0) r.status = TBA_ADAPT_BEYOND;
+                    return;
+                }
+                cur_start = n_ev - 1;
+            }
+            if (lane == 0) bst[row] = cur_start;
+            lo = 0;
+            hi = cur_start + W <= n_ev ? W : n_ev - cur_start;
+            fill = MASK_FILL_Z_SCORE; // literal, pyx:385-386
+        }
+        const i64 diff = row > 0 ? cur_start - prev_start : 0;
+        const double mu = rmu[row], sd = rsd[row];
+
+        // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720)
+        double z[CPL], cv[CPL];
+        u32 cfw[(CPL + 15) / 16];
+#pragma unroll
+        for (int q = 0; q < (CPL + 15) / 16; q++) cfw[q] = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const i64 b = (i64)lane * CPL + j;
+            double zz = 0.0;
+            if (b < W) { // cells past the band: z = 0, candidate = -inf (never read back)
+                if (b >= lo && b < hi) {
+                    double pz = (ev[cur_start + b] - mu) / sd;
+                    pz = fabs(pz);
+                    if (winsor) pz = max_half_z < pz ? max_half_z : pz;
+                    zz = z_shift - pz;
+                } else {
+                    zz = fill;
+                }
+            }
+            z[j] = zz;
+        }
+        // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401.
+        // previous-row cell c = lane*CPL + t sits at LDS [(t mod CPL)*64 + lane + floor(t/CPL)];
+        // t = j + diff - 1 is wave-uniform, so the index split is scalar work.
+        const int diff_i = __builtin_amdgcn_readfirstlane((int)diff);
+        const int Wi = (int)W;
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const int b = lane * CPL + j;
+            const int t1 = j + diff_i - 1;           // >= -1
+            const int q1 = t1 >= 0 ? t1 / CPL : -1;
+            const int r1 = t1 - q1 * CPL;
+            const int t2 = t1 + 1;
+            const int q2 = t2 / CPL;
+            const int r2 = t2 - q2 * CPL;
+            const int c1 = b + diff_i - 1;           // prev cell for the diagonal move
+            double c = NEG_INF;
+            u32 f = 0;
+            if (b < Wi) {
+                if (b == 0) {
+                    if (diff_i == 0) { c = prev[0] - skip_pen; f = 1; }
+                    else { c = prev[r1 * 64 + q1] + z[j]; f = 2; }
+                } else if (c1 < Wi) {
+                    double d = prev[r1 * 64 + lane + q1] + z[j];
+                    c = d; f = 2;
+                    if (c1 + 1 < Wi) {
+                        double s = prev[r2 * 64 + lane + q2] - skip_pen;
+                        if (s > d) { c = s; f = 1; }
+                    }
+                }
+            }
+            cv[j] = c;
+            cfw[j / 16] |= f << (2 * (j % 16));
+        }
+        // stay chain: monotone fixed-point sweeps
+        double in = NEG_INF;
+        bool converged = false;
+        for (int it = 0; it < 66; it++) { // <= 64 sweeps by induction over lanes (NaN-proof bound)
+            double x = in;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                double s = (x - stay_pen) + z[j];
+                x = cv[j] > s ? cv[j] : s;
+                v[j] = x;
+            }
+            double nin = shfl_up_f64(x, 1);
+            if (lane == 0) nin = NEG_INF;
+            u64 ch = __ballot(nin != in);
+            if (ch == 0) { converged = true; break; }
+            in = nin;
+        }
+        if (!converged) { // only reachable with NaNs in the signal
+            if (lane == 0) r.status = TBA_INTERNAL;
+            return;
+        }
+        // move codes (0 stay, 1 skip, 2 diag; pyx:216-231), lane-local argmax (pyx:186-197)
+        u32 mvw[CPL / 4];
+#pragma unroll
+        for (int q = 0; q < CPL / 4; q++) mvw[q] = 0;
+        double lmax = NEG_INF;
+        i64 lidx = 0;
+        {
+            double x = in;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                const i64 b = (i64)lane * CPL + j;
+                double s = (x - stay_pen) + z[j];
+                u32 f = cv[j] > s ? ((cfw[j / 16] >> (2 * (j % 16))) & 3u) : 0u;
+                mvw[j / 4] |= f << (8 * (j % 4));
+                x = v[j];
+                if (b < W && x > lmax) { lmax = x; lidx = b; }
+            }
+        }
+        unsigned char *mrow = mv + (row + 1) * mv_stride + (i64)lane * CPL;
+#pragma unroll
+        for (int q = 0; q < CPL / 4; q++) ((u32 *)mrow)[q] = mvw[q];
+#pragma unroll
+        for (int j = 0; j < CPL; j++) cur[j * 64 + lane] = v[j];
+        // wave argmax, first index among equal maxima
+        double wm = lmax;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            double t = shfl_xor_f64(wm, o);
+            wm = t > wm ? t : wm;
+        }
+        u64 eq = __ballot(lmax == wm && (i64)lane * CPL < W);
+        int first = __ffsll((unsigned long long)eq) - 1;
+        am = shfl_i64(lidx, first);
+        prev_start = cur_start;
+        __syncthreads();
+        double *t = prev; prev = cur; cur = t;
+    }
+    // last row + traceback start (np.argmax of the last row, resquiggle.py:728,1032)
+    double *lr = last_row + (i64)blockIdx.x * TBA_MAX_BAND;
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        const i64 b = (i64)lane * CPL + j;
+        if (b < W) lr[b] = prev[j * 64 + lane];
+    }
+    if (lane == 0) r.top_pos = am;
+}
+
+// c_banded_traceback (pyx:281-310) on byte moves with padded row stride; python wrap-around
+// indexing of a negative band position kept.  Returns a TBA status.
+__device__ inline int dev_banded_traceback(const unsigned char *mv, i64 stride, i64 n_bases,
+    i64 bw, const i64 *starts, bool identity, i64 band_pos, i64 thresh, i64 *seq_poss)
+{
+#define ST_AT(r_) (identity ? (i64)(r_) : starts[(r_)])
+#define MV_AT(r_, b_) mv[(r_) * stride + ((b_) < 0 ? (b_) + bw : (b_))]
+    i64 cur_ev = band_pos + ST_AT(n_bases - 1);
+    seq_poss[n_bases] = cur_ev + 1;
+    for (i64 rr = n_bases; rr > 0; rr--) {
+        const i64 st = ST_AT(rr - 1);
+        band_pos = cur_ev - st;
+        if (band_pos >= bw || band_pos < -bw) return TBA_INTERNAL;
+        while (MV_AT(rr, band_pos) == 0) {
+            band_pos--;
+            if (band_pos < -bw) return TBA_INTERNAL;
+        }
+        if (MV_AT(rr, band_pos) == 2) band_pos--;
+        if (thresh >= 0) {
+            i64 a = band_pos, b2 = bw - band_pos - 1;
+            if ((a < b2 ? a : b2) < thresh) return TBA_BEYOND_BANDWIDTH;
+        }
+        cur_ev = st + band_pos;
+        seq_poss[rr - 1] = cur_ev + 1;
+    }
+#undef ST_AT
+#undef MV_AT
+    return TBA_OK;
+}
+
+// start discovery epilogue: traceback, score_valid_bases (tombo_stats.py:2340-2362), events per
+// base (resquiggle.py:740-752) and the retry / fallback decision (resquiggle.py:992-1006).
+// One thread per read.
+__global__ void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int mode,
+    const double *event_means, const double *ref_means, const double *ref_sds,
+    const unsigned char *moves, i64 start_moves_stride, i64 *read_tb, double *start_vals)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK) return;
+    if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
+    const tba_params &P = dp->p;
+    const i64 nb = P.start_n_bases;
+    const i64 bw = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
+    const i64 stride = (i64)cpl_class(bw) * 64;
+    i64 *tb = read_tb + r.seg_off;
+    int rc = dev_banded_traceback(moves + ri * start_moves_stride, stride, nb, bw, nullptr, true,
+                                  r.top_pos, -1, tb);
+    const double *ev = event_means + r.ev_off;
+    if (rc == TBA_OK && mode == DP_START_TRY && dp->o.check_start_score) {
+        const double *mu = ref_means + r.ref_off, *sd = ref_sds + r.ref_off;
+        double *vals = start_vals + ri * nb;
+        i64 nv = 0;
+        for (i64 i = 0; i < nb; i++) {
+            if (tb[i] == tb[i + 1]) continue;
+            double m = np_sum(ev + tb[i], tb[i + 1] - tb[i]) / (double)(tb[i + 1] - tb[i]);
+            vals[nv++] = fabs((m - mu[i]) / sd[i]);
+        }
+        if (nv == 0) rc = TBA_INVALID_START_PATH;
+        else if (np_sum(vals, nv) / (double)nv > dp->o.sig_match_thresh) rc = TBA_POOR_START;
+    }
+    if (rc == TBA_OK) {
+        r.epb = (double)(tb[nb] - tb[0]) / (double)(nb + 1);
+        r.mapped_start = tb[0];
+        r.start_state = ST_OK;
+        r.start_res[2 * mode] = (double)tb[0];
+        r.start_res[2 * mode + 1] = r.epb;
+        r.n_start_calls = mode + 1;
+    } else if (mode == DP_START_TRY && rc != TBA_INTERNAL) {
+        // except th.TomboError: retry with the save bandwidth or fall back to the static DP
+        r.start_state = r.n_ev < P.start_save_bw + nb ? ST_STATIC : ST_RETRY;
+    } else {
+        r.status = rc;
+    }
+}
+
+// the branch of find_adaptive_base_assignment before start discovery (resquiggle.py:984-989)
+__global__ void k_path0(ReadState *rs, i64 n_reads, const DevParams *dp)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK) return;
+    const tba_params &P = dp->p;
+    if (dp->kmer_width - dp->central_pos - 1 <= 0) { r.status = TBA_DISCORDANT; return; }
+    if (r.n_ev < P.start_bw + P.start_n_bases || r.B < P.start_n_bases) r.start_state = ST_STATIC;
+    else r.start_state = ST_TRY;
+}
+
+// Everything between start discovery and the forward pass: open-pore check, clip / offset,
+// static fallback decision (resquiggle.py:1008-1027), the static-band row descriptors of
+// _get_masked_start_fwd_pass (resquiggle.py:607-683) or find_static_base_assignment
+// (resquiggle.py:561-571).  One thread per read; writes band_starts / lo / hi for the static
+// rows and the moves size (in moves_off, turned into an offset by k_scan_moves).
+__global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *band_starts,
+    i32 *lo_arr, i32 *hi_arr)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    r.moves_off = 0;
+    if (r.status != TBA_OK) return;
+    const tba_params &P = dp->p;
+    i64 *bst = band_starts + r.ref_off;
+    i32 *lo_a = lo_arr + r.ref_off, *hi_a = hi_arr + r.ref_off;
+    bool use_static = r.start_state == ST_STATIC;
+    const i64 bw = P.bandwidth, half_bw = P.bandwidth / 2;
+    i64 clip = 0, offset = 0;
+    if (!use_static) {
+        if (r.start_state != ST_OK) { r.status = TBA_INTERNAL; return; }
+        if (r.epb == 0) { r.status = TBA_OPEN_PORE; return; }
+        if (r.mapped_start < half_bw) { clip = 0; offset = r.mapped_start; }
+        else { clip = r.mapped_start - half_bw; offset = half_bw; }
+        if ((i64)((double)(half_bw + 1) / r.epb) >= r.B || r.n_ev - offset - clip < bw)
+            use_static = true;
+    }
+    if (use_static) {
+        // find_static_base_assignment, resquiggle.py:561-571
+        const i64 seq_len = r.B, n_ev = r.n_ev;
+        const i64 mask_len = (seq_len < n_ev ? seq_len : n_ev) / 4;
+        const i64 Ws = n_ev - mask_len;
+        if (Ws <= 0 || seq_len - 2 * mask_len < 0) { r.status = TBA_INTERNAL; return; }
+        if (cpl_class(Ws) == 0) { r.status = TBA_UNSUPPORTED; return; }
+        const i64 nz = seq_len - 2 * mask_len;
+        for (i64 i = 0; i < seq_len; i++) {
+            i64 s = 0;
+            if (i >= nz) s = (i64)np_linspace_at(0.0, (double)mask_len, 2 * mask_len, i - nz);
+            bst[i] = s; lo_a[i] = 0; hi_a[i] = (i32)Ws;
+        }
+        r.path = PATH_STATIC; r.clip = 0; r.offset = 0; r.W = Ws; r.n_static = seq_len;
+        r.moves_off = (seq_len + 1) * (i64)cpl_class(Ws) * 64;
+        return;
+    }
+    // _get_masked_start_fwd_pass on event_means[clip:]
+    const i64 n_ev = r.n_ev - clip;
+    if (n_ev - offset < bw) { r.status = TBA_STARTS_TOO_FAR; return; }
+    if (cpl_class(bw) == 0) { r.status = TBA_UNSUPPORTED; return; }
+    const double epb = r.epb;
+    const i64 start_pos = half_bw <= offset ? 0 : offset - half_bw;
+    i64 tmp_seq_len = half_bw > MASK_BASES ? half_bw : MASK_BASES;
+    const i64 t3 = (i64)((double)(half_bw + 1) / epb);
+    if (t3 > tmp_seq_len) tmp_seq_len = t3;
+    tmp_seq_len += 1;
+    const double ls0 = (double)start_pos;
+    const double ls1 = (double)start_pos + ((double)tmp_seq_len * epb);
+    i64 first = -1;
+    for (i64 i = 0; i < tmp_seq_len; i++)
+        if ((i64)np_linspace_at(ls0, ls1, tmp_seq_len, i) >= offset) { first = i + 2; break; }
+    if (first < 0) { r.status = TBA_INTERNAL; return; }
+    i64 msl = first > MASK_BASES ? first : MASK_BASES;
+    if (msl > tmp_seq_len) msl = tmp_seq_len;
+    if (msl > r.B) { r.status = TBA_INTERNAL; return; }
+    for (i64 i = 0; i < msl; i++) bst[i] = (i64)np_linspace_at(ls0, ls1, tmp_seq_len, i);
+    const double m0 = (double)(offset + 1), m1 = (double)(bst[MASK_BASES - 1] + bw);
+    for (i64 sp = 0; sp < msl; sp++) {
+        const i64 ev_pos = bst[sp];
+        const i64 sml = offset - ev_pos > 0 ? offset - ev_pos : 0;
+        i64 eml = sp >= MASK_BASES ? 0
+                                   : bw - ((i64)np_linspace_at(m0, m1, MASK_BASES, sp) - ev_pos);
+        if (ev_pos + bw - eml > n_ev) eml = ev_pos + bw - n_ev;
+        const i64 lo = ev_pos + sml, hi = ev_pos + bw - eml;
+        i64 hi_c = hi > n_ev ? n_ev : hi;
+        if (hi < 0) { hi_c = hi + n_ev; if (hi_c < 0) hi_c = 0; }
+        const i64 lo_c = lo > n_ev ? n_ev : lo;
+        const i64 nzs = hi_c > lo_c ? hi_c - lo_c : 0;
+        const i64 eml_n = eml > 0 ? eml : 0;
+        if (sml + nzs + eml_n != bw) { r.status = TBA_MASK_TOO_FEW; return; }
+        lo_a[sp] = (i32)sml;
+        hi_a[sp] = (i32)(sml + nzs);
+    }
+    r.path = PATH_ADAPTIVE; r.clip = clip; r.offset = offset; r.W = bw; r.n_static = msl;
+    r.moves_off = (r.B + 1) * (i64)cpl_class(bw) * 64;
+}
+
+// exclusive scan of the per-read moves sizes into arena offsets (single thread; N is small)
+__global__ void k_scan_moves(ReadState *rs, i64 n_reads, i64 arena_bytes)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    i64 acc = 0;
+    for (i64 i = 0; i < n_reads; i++) {
+        ReadState &r = rs[i];
+        i64 sz = r.moves_off;
+        if (r.status != TBA_OK || sz == 0) { r.moves_off = 0; continue; }
+        if (acc + sz > arena_bytes) { r.status = TBA_UNSUPPORTED; r.moves_off = 0; r.path = PATH_NONE; continue; }
+        r.moves_off = acc;
+        acc += sz;
+    }
+}
+
+// main traceback + _trim_traceback (resquiggle.py:754-764) + get_rel_raw_coords (:858-864).
+// One thread per read.
+__global__ void k_main_tb(ReadState *rs, i64 n_reads, const DevParams *dp,
+    const unsigned char *moves, const i64 *band_starts, const i64 *valid_cpts, i64 *read_tb,
+    i64 *dp_segs)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK) return;
+    if (r.path == PATH_NONE) { r.status = TBA_INTERNAL; return; }
+    const i64 B = r.B, W = r.W;
+    i64 *tb = read_tb + r.seg_off;
+    const bool adaptive = r.path == PATH_ADAPTIVE;
+    int rc = dev_banded_traceback(moves + r.moves_off, (i64)cpl_class(W) * 64, B, W,
+                                  band_starts + r.ref_off, false, r.top_pos,
+                                  adaptive ? dp->p.band_bound_thresh : -1, tb);
+    if (rc != TBA_OK) { r.status = rc; return; }
+    const i64 n_ev = r.n_ev - r.clip;
+    if (adaptive) {
+        i64 i = 0;
+        while (tb[i] < 0) { tb[i] = 0; i++; if (i > B) { r.status = TBA_INTERNAL; return; } }
+        i64 j = 1;
+        while (tb[B + 1 - j] > n_ev) { tb[B + 1 - j] = n_ev; j++; if (j > B + 1) { r.status = TBA_INTERNAL; return; } }
+    } else {
+        for (i64 i = 0; i <= B; i++)
+            if (tb[i] < -(n_ev + 1) || tb[i] > n_ev) { r.status = TBA_INTERNAL; return; }
+    }
+    const i64 *c = valid_cpts + r.ev_off + r.clip;
+    const i64 n_c = n_ev + 1;
+    i64 *sg = dp_segs + r.seg_off;
+    i64 t0 = tb[0];
+    if (t0 < 0) t0 += n_c;
+    const i64 first = c[t0];
+    for (i64 i = 0; i <= B; i++) {
+        i64 t = tb[i];
+        if (t < 0) t += n_c;
+        sg[i] = c[t] - first;
+    }
+    r.dp_read_start = first;
+    r.read_start = first;
+    r.norm_len = sg[B];
+    if (first < 0 || r.norm_len < 0 || first + r.norm_len > r.n_raw) r.status = TBA_INTERNAL;
+}

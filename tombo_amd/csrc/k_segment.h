@@ -1,0 +1,341 @@
+// k_segment.h -- per-read normalisation and event detection (segment_signal,
+// resquiggle.py:1057-1120) as batch kernels.
+#pragma once
+#include "k_select.h"
+
+// ---------------------------------------------------------------------------------------------
+// ts.normalize_raw_signal (tombo_stats.py:482-573) for 'median', 'median_const_scale' and given
+// scale values; one workgroup per read.  mode 0: DNA order (normalise first); mode 1: RNA,
+// called after event detection with scale values already in ReadState.
+__global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevParams *dp,
+    const double *raw, double *norm, const double *sv_in, int mode)
+{
+    __shared__ SelectSmem sm;
+    ReadState &r = rs[blockIdx.x];
+    if (r.status != TBA_OK) return;
+    const int tid = threadIdx.x;
+    const i64 n = r.n_raw;
+    const double *x = raw + r.raw_off;
+    double *y = norm + r.raw_off;
+    const tba_opts &o = dp->o;
+    double shift, scale, lo = 0, hi = 0;
+    bool have_lims = false, use_sv = false;
+    if (r.sv_flags & 1) {
+        use_sv = true;
+        shift = sv_in[4 * blockIdx.x + 0];
+        scale = sv_in[4 * blockIdx.x + 1];
+        if (r.sv_flags & 2) { have_lims = true; lo = sv_in[4 * blockIdx.x + 2]; hi = sv_in[4 * blockIdx.x + 3]; }
+    } else if (mode == 1 && !o.has_const_scale && o.use_rna_event_scale) {
+        use_sv = true; // get_scale_values_from_events result, tombo_stats.py:217-233
+        shift = r.shift; scale = r.scale; have_lims = true; lo = r.lower; hi = r.upper;
+    } else {
+        shift = block_median([&](i64 i) { return f64_key(x[i]); }, n, &sm);
+        if (o.has_const_scale) scale = o.const_scale;
+        else scale = block_median([&](i64 i) { return f64_key(fabs(x[i] - shift)); }, n, &sm);
+    }
+    for (i64 i = tid; i < n; i += SEL_NT) y[i] = (x[i] - shift) / scale;
+    __syncthreads();
+    // RNA with scale_values=None and no event scaling normalises without an outlier threshold
+    bool thresh = !use_sv && o.has_outlier_thresh && !(mode == 1 && !o.has_const_scale);
+    if (thresh) {
+        double med = block_median([&](i64 i) { return f64_key(y[i]); }, n, &sm);
+        double mad = block_median([&](i64 i) { return f64_key(fabs(y[i] - med)); }, n, &sm);
+        lo = med - (mad * o.outlier_thresh);
+        hi = med + (mad * o.outlier_thresh);
+        have_lims = true;
+    }
+    if (have_lims) {
+        // c_apply_outlier_thresh, _c_helper.pyx:73-87
+        for (i64 i = tid; i < n; i += SEL_NT) {
+            double v = y[i];
+            y[i] = v > hi ? hi : (v < lo ? lo : v);
+        }
+    }
+    if (tid == 0) {
+        r.shift = shift; r.scale = scale; r.lower = lo; r.upper = hi;
+        r.has_lims = have_lims ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// np.cumsum([0, x]) with its left-to-right float64 accumulation order (the order feeds the
+// change-point ranking, so a parallel scan is not an option): one lane per read.
+// csum has n_raw + 1 entries per read at raw_off + read_index.
+__global__ __launch_bounds__(64) void k_cumsum(const ReadState *rs, i64 n_reads,
+    const double *norm, double *csum)
+{
+    i64 ri = (i64)blockIdx.x * 64 + threadIdx.x;
+    if (ri >= n_reads) return;
+    const ReadState &r = rs[ri];
+    if (r.status != TBA_OK) return;
+    const double *x = norm + r.raw_off;
+    double *c = csum + r.raw_off + ri;
+    double acc = 0.0;
+    c[0] = acc;
+    for (i64 i = 0; i < r.n_raw; i++) {
+        acc = acc + x[i];
+        c[i + 1] = acc;
+    }
+}
+
+// c_valid_cpts_w_cap scores, _c_helper.pyx:94-98: |(2*c[k+w]) - c[k] - c[k+2w]|
+__global__ __launch_bounds__(256) void k_scores_dna(const ReadState *rs, const DevParams *dp,
+    const double *csum, double *score)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const i64 w = dp->p.running_stat_width;
+    const i64 ns = r.n_raw + 1 - 2 * w;
+    const double *c = csum + r.raw_off + blockIdx.y;
+    double *s = score + r.raw_off;
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < ns; k += (i64)gridDim.x * 256)
+        s[k] = fabs(((2 * c[k + w]) - c[k]) - c[k + 2 * w]);
+}
+
+// c_valid_cpts_w_cap_t_test scores, _c_helper.pyx:152-183 (sequential sums inside each window)
+__global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const DevParams *dp,
+    const double *raw, double *score)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const i64 w = dp->p.running_stat_width;
+    const i64 ns = r.n_raw - 2 * w;
+    const double *x = raw + r.raw_off;
+    double *s = score + r.raw_off;
+    for (i64 pos = (i64)blockIdx.x * 256 + threadIdx.x; pos < ns; pos += (i64)gridDim.x * 256) {
+        double m1 = 0, m2 = 0, var1 = 0, var2 = 0, d;
+        for (i64 j = 0; j < w; j++) m1 += x[pos + j];
+        m1 /= (double)w;
+        for (i64 j = 0; j < w; j++) m2 += x[pos + w + j];
+        m2 /= (double)w;
+        for (i64 j = 0; j < w; j++) { d = x[pos + j] - m1; var1 += d * d; }
+        for (i64 j = 0; j < w; j++) { d = x[pos + w + j] - m2; var2 += d * d; }
+        double t;
+        if (var1 + var2 == 0) t = 0.0;
+        else if (m1 > m2) t = (m1 - m2) / sqrt(var1 + var2);
+        else t = (m2 - m1) / sqrt(var1 + var2);
+        s[pos] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The capped greedy of c_valid_cpts_w_cap (_c_helper.pyx:100-120): candidates in descending
+// score order, a candidate is taken unless within +-(min_base_obs-1) of a taken one, stop at
+// num_cpts.  Parallel form: resolve the uncapped greedy as a fixed point
+// over the priority DAG (a position is taken iff every higher-priority neighbour is suppressed,
+// suppressed iff some higher-priority neighbour is taken), then keep the num_cpts best taken
+// positions by exact selection.  Priority = (score, index) descending -- identical to
+// np.argsort(score)[::-1] for tie-free scores; ties fall to the higher index.
+// One workgroup per read.  state: 0 undecided, 1 taken, 2 suppressed.
+__device__ __forceinline__ bool prio_before(double sp, i64 p, double sq, i64 q)
+{
+    return sp > sq || (sp == sq && p > q);
+}
+
+__global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams *dp,
+    const double *score, unsigned char *state, i64 *valid_cpts, int ttest)
+{
+    __shared__ SelectSmem sm;
+    __shared__ i64 s_cnt[SEL_NT];
+    ReadState &r = rs[blockIdx.x];
+    if (r.status != TBA_OK) return;
+    const int tid = threadIdx.x;
+    const i64 w = dp->p.running_stat_width, m = dp->p.min_obs_per_base;
+    const i64 ns = ttest ? r.n_raw - 2 * w : r.n_raw + 1 - 2 * w;
+    const i64 num_cands = ttest ? ns : ns - 2 * w;
+    const i64 num_cpts = r.num_events;
+    const double *s = score + r.raw_off;
+    unsigned char *st = state + r.raw_off;
+    i64 *cpts = valid_cpts + r.ev_off;
+    if (ns <= 0 || num_cpts <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
+
+    for (i64 p = tid; p < ns; p += SEL_NT) st[p] = 0;
+    __syncthreads();
+    // fixed point of the greedy; every round settles at least the best undecided position
+    for (i64 round = 0; round <= ns; round++) {
+        i64 undecided = 0;
+        for (i64 p = tid; p < ns; p += SEL_NT) {
+            if (st[p] != 0) continue;
+            const double sp_ = s[p];
+            bool any_taken = false, any_undecided = false;
+            i64 q0 = p - m + 1 < 0 ? 0 : p - m + 1, q1 = p + m - 1 >= ns ? ns - 1 : p + m - 1;
+            for (i64 q = q0; q <= q1; q++) {
+                if (q == p) continue;
+                if (!prio_before(s[q], q, sp_, p)) continue;
+                unsigned char sq = st[q];
+                if (sq == 1) any_taken = true;
+                else if (sq == 0) any_undecided = true;
+            }
+            if (any_taken) st[p] = 2;
+            else if (!any_undecided) st[p] = 1;
+            else undecided++;
+        }
+        __threadfence_block();
+        i64 tot = block_sum_i64(undecided, &sm);
+        if (tot == 0) break;
+    }
+    // number taken
+    i64 mine = 0;
+    for (i64 p = tid; p < ns; p += SEL_NT) mine += st[p] == 1;
+    i64 n_taken = block_sum_i64(mine, &sm);
+    if (n_taken < num_cpts) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
+
+    // the num_cpts-th taken position in priority order: select on the score key among taken
+    // (descending rank num_cpts-1 == ascending rank n_taken-num_cpts); untaken map to key 0
+    // which sorts below every real score key (scores are >= 0 -> keys >= 0x8000...)
+    auto fk = [&](i64 p) { return st[p] == 1 ? f64_key(s[p]) : 0ull; };
+    block_select(fk, ns, (ns - n_taken) + (n_taken - num_cpts), &sm);
+    const u64 tkey = sm.prefix;
+    __syncthreads();
+    // ties on the threshold score (never with continuous input): take the highest indices
+    i64 c_gt = 0, c_eq = 0;
+    for (i64 p = tid; p < ns; p += SEL_NT)
+        if (st[p] == 1) { u64 k = f64_key(s[p]); c_gt += k > tkey; c_eq += k == tkey; }
+    c_gt = block_sum_i64(c_gt, &sm);
+    c_eq = block_sum_i64(c_eq, &sm);
+    const i64 need_eq = num_cpts - c_gt;
+    __shared__ i64 s_idx_thr;
+    if (tid == 0) {
+        i64 thr = 0;
+        if (need_eq < c_eq) {
+            i64 left = need_eq;
+            for (i64 p = ns - 1; p >= 0; p--)
+                if (st[p] == 1 && f64_key(s[p]) == tkey) { if (--left == 0) { thr = p; break; } }
+        } else {
+            for (i64 p = 0; p < ns; p++)
+                if (st[p] == 1 && f64_key(s[p]) == tkey) { thr = p; break; }
+        }
+        s_idx_thr = thr;
+    }
+    __syncthreads();
+    const i64 idx_thr = s_idx_thr;
+    // rank (0-based position in the argsort order) of the last pick; the reference raises when
+    // rank + 1 >= num_cands (cand_idx is advanced past the pick before the bound check)
+    if (num_cpts > 1) {
+        i64 before = 0;
+        for (i64 p = tid; p < ns; p += SEL_NT) {
+            u64 k = f64_key(s[p]);
+            before += (k > tkey) || (k == tkey && p > idx_thr);
+        }
+        before = block_sum_i64(before, &sm);
+        if (before + 1 >= num_cands) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
+    }
+    // ordered compaction (the .sort() of tombo_helper.py:76-82): contiguous chunk per thread
+    const i64 chunk = (ns + SEL_NT - 1) / SEL_NT;
+    const i64 b0 = (i64)tid * chunk, b1 = b0 + chunk > ns ? ns : b0 + chunk;
+    i64 cnt = 0;
+    for (i64 p = b0; p < b1; p++) {
+        if (st[p] != 1) continue;
+        u64 k = f64_key(s[p]);
+        cnt += (k > tkey) || (k == tkey && p >= idx_thr);
+    }
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        i64 acc = 0;
+        for (int t = 0; t < SEL_NT; t++) { i64 c = s_cnt[t]; s_cnt[t] = acc; acc += c; }
+    }
+    __syncthreads();
+    i64 outp = s_cnt[tid];
+    for (i64 p = b0; p < b1; p++) {
+        if (st[p] != 1) continue;
+        u64 k = f64_key(s[p]);
+        if ((k > tkey) || (k == tkey && p >= idx_thr)) cpts[outp++] = p + w;
+    }
+    if (tid == 0) { r.n_cpts = num_cpts; r.n_ev = num_cpts - 1; }
+}
+
+// ts.remove_stall_cpts (tombo_stats.py:1576-1597): a change point is dropped when it lies
+// strictly inside the first stall interval whose end is >= the change point (the reference's
+// forward walk; interval ends ascend).  One thread per read (RNA only, few intervals).
+__global__ void k_remove_stalls(ReadState *rs, i64 n_reads, const i64 *stall_ints,
+    i64 *valid_cpts)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK || r.n_stall == 0) return;
+    const i64 *st = stall_ints + 2 * r.stall_off;
+    i64 *c = valid_cpts + r.ev_off;
+    i64 cur = 0, out = 0;
+    for (i64 i = 0; i < r.n_cpts; i++) {
+        i64 v = c[i];
+        while (v > st[2 * cur + 1]) {
+            if (cur + 1 >= r.n_stall) break;
+            cur++;
+        }
+        if (!(st[2 * cur] < v && v < st[2 * cur + 1])) c[out++] = v;
+    }
+    r.n_cpts = out;
+    r.n_ev = out - 1;
+    if (out < 2) r.status = TBA_INTERNAL;
+}
+
+// c_new_means (_c_helper.pyx:59-71) over the event boundaries: sequential sum, one divide.
+// grid: (blocks, reads)
+__global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const double *sig,
+    const i64 *valid_cpts, double *event_means, int from_raw_limit)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const double *x = sig + r.raw_off;
+    const i64 *c = valid_cpts + r.ev_off;
+    double *em = event_means + r.ev_off;
+    i64 n = r.n_cpts - 1;
+    (void)from_raw_limit;
+    for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < n; e += (i64)gridDim.x * 256) {
+        double s = 0;
+        for (i64 j = c[e]; j < c[e + 1]; j++) s += x[j];
+        em[e] = s / (double)(c[e + 1] - c[e]);
+    }
+}
+
+// ts.get_scale_values_from_events (tombo_stats.py:217-233): median / MAD of the first
+// min(10000, int(0.75 * n_cpts)) - 1 raw event means; one workgroup per read (RNA).
+// event_means must hold c_new_means(raw, valid_cpts) on entry.
+__global__ __launch_bounds__(SEL_NT) void k_rna_event_scale(ReadState *rs, const DevParams *dp,
+    const double *event_means)
+{
+    __shared__ SelectSmem sm;
+    ReadState &r = rs[blockIdx.x];
+    if (r.status != TBA_OK) return;
+    if (r.sv_flags & 1) return; // scale values given: not used
+    const tba_opts &o = dp->o;
+    if (o.has_const_scale || !o.use_rna_event_scale) return;
+    i64 ne = o.rna_scale_num_events;
+    if ((double)r.n_cpts * o.rna_scale_max_frac_events < (double)ne)
+        ne = (i64)((double)r.n_cpts * o.rna_scale_max_frac_events);
+    if (ne > r.n_cpts) ne = r.n_cpts;
+    if (ne < 2 || !o.has_outlier_thresh) { if (threadIdx.x == 0) r.status = TBA_INTERNAL; return; }
+    const double *em = event_means + r.ev_off;
+    double med = block_median([&](i64 i) { return f64_key(em[i]); }, ne - 1, &sm);
+    double mad = block_median([&](i64 i) { return f64_key(fabs(em[i] - med)); }, ne - 1, &sm);
+    if (threadIdx.x == 0) {
+        r.shift = med; r.scale = mad; r.lower = -o.outlier_thresh; r.upper = o.outlier_thresh;
+        r.has_lims = 1;
+    }
+}
+
+// TomboModel.get_exp_levels_from_seq (tombo_stats.py:834-862): k-mer code -> level mean / sd.
+// grid: (blocks, reads)
+__global__ __launch_bounds__(256) void k_ref_levels(ReadState *rs, const DevParams *dp,
+    const uint8_t *seq, const double *kmer_means, const double *kmer_sds, double *ref_means,
+    double *ref_sds)
+{
+    ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const i64 K = dp->kmer_width;
+    const uint8_t *s = seq + r.seq_off;
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.B; i += (i64)gridDim.x * 256) {
+        i64 code = 0;
+        for (i64 j = 0; j < K; j++) {
+            uint8_t b = s[i + j];
+            if (b > 3) bad = true;
+            code = code * 4 + (b & 3);
+        }
+        ref_means[r.ref_off + i] = kmer_means[code];
+        ref_sds[r.ref_off + i] = kmer_sds[code];
+    }
+    if (bad) r.status = TBA_INVALID_SEQ;
+}

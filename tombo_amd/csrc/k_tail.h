@@ -1,0 +1,313 @@
+// k_tail.h -- after the event-space DP: raw-signal resolution of skipped bases, Theil-Sen
+// rescale, final score (resquiggle.py:402-540, 1176-1214; tombo_stats.py:401-450, 2327-2338).
+#pragma once
+#include "k_select.h"
+
+// ---------------------------------------------------------------------------------------------
+// rq.resolve_skipped_bases_with_raw (resquiggle.py:402-540): deletion windows, then per window
+// c_reg_z_scores (pyx:34-97, reg_start=0, reg_end=n, max_base_shift=n) -> raw_forward_pass
+// (resquiggle.py:345-380, c_base_forward_pass pyx:99-163) -> raw_traceback (:382-400,
+// c_base_traceback pyx:165-182).  One thread per read; per-read scratch arenas:
+//   win[2*(B+1)] i64, fw/z[cap] f64, ld[cap]... (cap elements each, see engine)
+struct Win { i64 s, e; };
+
+__device__ inline i64 merge_windows(Win *w, i64 n)
+{
+    i64 m = 0;
+    for (i64 i = 0; i < n; i++) {
+        if (m > 0 && w[i].s < w[m - 1].e) w[m - 1].e = w[i].e;
+        else w[m++] = w[i];
+    }
+    return m;
+}
+__device__ inline void trim_windows(Win *w, i64 n, i64 n_segs)
+{
+    if (w[0].s < 0) w[0].s = 0;
+    if (w[n - 1].e > n_segs - 1) w[n - 1].e = n_segs - 1;
+}
+__device__ inline int window_too_small(const i64 *segs, i64 n_segs, Win w, i64 m)
+{
+    if (w.e >= n_segs || w.s < -n_segs) return -1;
+    i64 n_events = w.e - w.s;
+    i64 se = segs[w.e < 0 ? w.e + n_segs : w.e], ss = segs[w.s < 0 ? w.s + n_segs : w.s];
+    return (double)(se - ss) <= (double)((n_events + 1) * m) * EXTRA_SIG_FACTOR;
+}
+
+// raw-signal DP of one window; scratch: z, fw (cap doubles each), ld (2 * max_len i64),
+// cum (max_len doubles).  Layout identical to the oracle's orc_raw_window_dp.
+__device__ inline int raw_window_dp(const double *sig, i64 L, const double *means,
+    const double *sds, i64 n, i64 m, bool winsor, double mh, double *z, double *fw, i64 *ld,
+    double *cum, i64 cap, i64 *new_segs)
+{
+    if (n < 2) return TBA_INTERNAL;
+    // admissible interval of base i: [i*m, L-(n-1-i)*m)  (pyx:56-81)
+    if (L - (n - 1) * m <= 0) return TBA_INTERNAL;
+    const i64 len = L - (n - 1) * m; // every base has the same interval length
+    if (n * len > cap) return TBA_UNSUPPORTED;
+    for (i64 i = 0; i < n; i++) {
+        const double mu = means[i], sd = sds[i];
+        const double *x = sig + i * m;
+        double *zi = z + i * len;
+        for (i64 k = 0; k < len; k++) { // c_base_z_scores, pyx:17-32
+            double v = (x[k] - mu) / sd;
+            if (v > 0) v = -v;
+            if (winsor && v < -mh) v = -mh;
+            zi[k] = v;
+        }
+    }
+    i64 *pl = ld, *bl = ld + len;
+    { // first row: np.cumsum, last_diag = m
+        double acc = 0;
+        for (i64 k = 0; k < len; k++) { acc = k == 0 ? z[k] : acc + z[k]; fw[k] = acc; pl[k] = m; }
+    }
+    for (i64 i = 1; i < n; i++) {
+        const double *pz = z + (i - 1) * len, *pf = fw + (i - 1) * len, *bz = z + i * len;
+        double *bf = fw + i * len;
+        const i64 ps = (i - 1) * m, pe = ps + len, b_s = i * m, b_e = b_s + len;
+        { double acc = 0; for (i64 k = 0; k < len; k++) { acc = k == 0 ? pz[k] : acc + pz[k]; cum[k] = acc; } }
+        if (b_s - ps - 1 < 0 || b_s - ps - 1 >= len) return TBA_INTERNAL;
+        bf[0] = bz[0] + pf[b_s - ps - 1];
+        bl[0] = 1;
+        for (i64 pos = b_s + 1; pos < pe + 1; pos++) {
+            if (pos - b_s >= len) break;
+            i64 lag = 1;
+            for (;;) {
+                i64 idx = pos - ps - lag;
+                if (idx < 0) idx += len;
+                if (idx < 0 || idx >= len) return TBA_INTERNAL;
+                if (pl[idx] + lag <= m) lag++;
+                else break;
+            }
+            i64 di = pos - ps - lag;
+            if (di < 0) di += len;
+            double diag = pf[di];
+            if (lag > 1) diag += cum[pos - ps - 1] - cum[di];
+            double stay = bf[pos - b_s - 1];
+            double best;
+            i64 dv;
+            if (diag > stay) { best = diag; dv = 1; }
+            else { best = stay; dv = bl[pos - b_s - 1] + 1; }
+            bf[pos - b_s] = bz[pos - b_s] + best;
+            bl[pos - b_s] = dv;
+        }
+        if (b_e > pe + 1) {
+            double fv = bf[pe - b_s];
+            i64 cl = bl[pe - b_s];
+            for (i64 k = 0; k < b_e - pe - 1; k++) {
+                fv += bz[k + pe - b_s + 1];
+                cl += 1;
+                bf[k + pe - b_s + 1] = fv;
+                bl[k + pe - b_s + 1] = cl;
+            }
+        }
+        i64 *t = pl; pl = bl; bl = t;
+    }
+    i64 sig_start = (n - 1) * m + len - 1;
+    for (i64 b = n - 1; b >= 1; b--) {
+        const double *cf = fw + b * len, *nf = fw + (b - 1) * len;
+        const i64 cs = b * m, ns = (b - 1) * m, ne = ns + len;
+        i64 cnt = 1, found = -1;
+        for (i64 sp = sig_start; sp >= 0; sp--) {
+            cnt += 1;
+            if (cnt <= m || sp - 1 >= ne) continue;
+            if (sp <= cs) { found = sp; break; }
+            if (nf[sp - ns - 1] > cf[sp - cs - 1]) { found = sp; break; }
+        }
+        if (found < 0) return TBA_INTERNAL;
+        new_segs[b - 1] = found;
+        sig_start = found - 1;
+    }
+    return TBA_OK;
+}
+
+__global__ void k_skip_resolve(ReadState *rs, i64 n_reads, const DevParams *dp,
+    const double *norm, const double *ref_means, const double *ref_sds, const i64 *dp_segs,
+    i64 *segs, i64 *win_scratch, double *dscratch, i64 *iscratch, i64 cap)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK) return;
+    const tba_params &P = dp->p;
+    const i64 m = P.raw_min_obs_per_base;
+    const i64 n_segs = r.B + 1;
+    const i64 *ds = dp_segs + r.seg_off;
+    i64 *out = segs + r.seg_off;
+    const double *sig = norm + r.raw_off + r.read_start; // norm_signal[read_start:...]
+    const i64 n_norm = r.norm_len;
+    const double *mu = ref_means + r.ref_off, *sd = ref_sds + r.ref_off;
+    for (i64 i = 0; i < n_segs; i++) out[i] = ds[i];
+    Win *w = (Win *)(win_scratch + 2 * r.seg_off);
+    i64 nw = 0;
+    for (i64 d = 0; d + 1 < n_segs; d++) {
+        if (ds[d + 1] - ds[d] != 0) continue;
+        if (nw > 0 && d < w[nw - 1].e + DEL_FIX_WINDOW) w[nw - 1].e = d + DEL_FIX_WINDOW + 1;
+        else { w[nw].s = d - DEL_FIX_WINDOW; w[nw].e = d + DEL_FIX_WINDOW + 1; nw++; }
+    }
+    if (nw > 0) {
+        bool expanded = false;
+        nw = merge_windows(w, nw);
+        trim_windows(w, nw, n_segs);
+        for (int it = 0; it < MAX_DEL_FIX_WINDOW - DEL_FIX_WINDOW; it++) {
+            expanded = false;
+            for (i64 i = 0; i < nw; i++) {
+                int ts = window_too_small(ds, n_segs, w[i], m);
+                if (ts < 0) { r.status = TBA_INTERNAL; return; }
+                if (ts) { expanded = true; w[i].s -= 1; w[i].e += 1; }
+            }
+            if (!expanded) break;
+            nw = merge_windows(w, nw);
+            trim_windows(w, nw, n_segs);
+        }
+        if (expanded) {
+            for (i64 i = 0; i < nw; i++) {
+                int ts = window_too_small(ds, n_segs, w[i], m);
+                if (ts < 0) { r.status = TBA_INTERNAL; return; }
+                if (ts) { r.status = TBA_NOT_ENOUGH_DEL_SIGNAL; return; }
+            }
+        }
+        if (dp->o.max_raw_cpts >= 0) {
+            i64 mx = 0;
+            for (i64 i = 0; i < nw; i++) mx = w[i].e - w[i].s > mx ? w[i].e - w[i].s : mx;
+            if (mx > dp->o.max_raw_cpts) { r.status = TBA_TOO_MANY_DELS; return; }
+        }
+        // scratch of this read: z, fw: cap doubles each; cum: cap doubles; ld: 2*cap i64
+        double *z = dscratch + ri * 3 * cap, *fw = z + cap, *cum = fw + cap;
+        i64 *ld = iscratch + ri * 2 * cap;
+        for (i64 i = 0; i < nw; i++) {
+            const i64 s = w[i].s, e = w[i].e, n = e - s;
+            if (s < 0 || e >= n_segs) { r.status = TBA_INTERNAL; return; }
+            const i64 sig_start = ds[s], sig_end = ds[e];
+            if (sig_start < 0 || sig_end > n_norm) { r.status = TBA_INTERNAL; return; }
+            // new boundaries land directly in out[s+1 .. e-1] (relative to the window start)
+            int rc = raw_window_dp(sig + sig_start, sig_end - sig_start, mu + s, sd + s, n, m,
+                                   P.do_winsorize_z != 0, P.max_half_z_score, z, fw, ld, cum,
+                                   cap, out + s + 1);
+            if (rc != TBA_OK) { r.status = rc; return; }
+            for (i64 k = 0; k < n - 1; k++) out[s + 1 + k] += sig_start;
+        }
+    }
+    for (i64 i = 0; i + 1 < n_segs; i++)
+        if (out[i + 1] - out[i] < 1) { r.status = TBA_ZERO_LEN; return; }
+    if (out[0] < 0) { r.status = TBA_NEG_START; return; }
+    if (out[n_segs - 1] > n_norm) { r.status = TBA_PAST_END; return; }
+}
+
+// c_new_means over base boundaries: means of sig[read_start + segs[i] : read_start + segs[i+1]]
+// grid: (blocks, reads)
+__global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const double *sig,
+    const i64 *segs, double *base_means)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const double *x = sig + r.raw_off + r.read_start;
+    const i64 *sg = segs + r.seg_off;
+    double *bm = base_means + r.ref_off;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.B; i += (i64)gridDim.x * 256) {
+        double s = 0;
+        for (i64 j = sg[i]; j < sg[i + 1]; j++) s += x[j];
+        bm[i] = s / (double)(sg[i + 1] - sg[i]);
+    }
+}
+
+// ts.calc_kmer_fitted_shift_scale(method='theil_sen') (tombo_stats.py:401-450) with
+// c_compute_slopes (_c_helper.pyx:362-377): median of all pairwise slopes, then median
+// intercept.  One workgroup per read; the (<= 1000) points sit in LDS, the n(n-1)/2 slopes are
+// recomputed inside every radix-select pass instead of being stored (4 MB per read otherwise).
+// Pair enumeration by circular distance: (i, (i+d) mod n); slope(i,j) == slope(j,i) bitwise.
+__global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevParams *dp,
+    const double *base_means, const double *ref_means, const i64 *samp_ind)
+{
+    __shared__ SelectSmem sm;
+    __shared__ double s_ev[MAX_TS_POINTS], s_md[MAX_TS_POINTS];
+    ReadState &r = rs[blockIdx.x];
+    if (r.status != TBA_OK) return;
+    if (dp->o.skip_seq_scaling) return;
+    const int tid = threadIdx.x;
+    const double *bm = base_means + r.ref_off, *mu = ref_means + r.ref_off;
+    i64 n = r.B;
+    if (n > MAX_TS_POINTS) {
+        if (samp_ind == nullptr) { if (tid == 0) r.status = TBA_INTERNAL; return; }
+        const i64 *si = samp_ind + (i64)blockIdx.x * MAX_TS_POINTS;
+        n = MAX_TS_POINTS;
+        bool bad = false;
+        for (i64 i = tid; i < n; i += SEL_NT) {
+            i64 k = si[i];
+            if (k < 0 || k >= r.B) { bad = true; k = 0; }
+            s_ev[i] = bm[k]; s_md[i] = mu[k];
+        }
+        if (__syncthreads_or(bad)) { if (tid == 0) r.status = TBA_INTERNAL; return; }
+    } else {
+        for (i64 i = tid; i < n; i += SEL_NT) { s_ev[i] = bm[i]; s_md[i] = mu[i]; }
+        __syncthreads();
+    }
+    const i64 ns = n * (n - 1) / 2;
+    if (ns <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
+    const i64 full = n * ((n - 1) / 2); // distances 1..(n-1)/2 cover n pairs each
+    auto slope_key = [&](i64 idx) {
+        i64 i, j;
+        if (idx < full) { i64 d = idx / n + 1; i = idx - (d - 1) * n; j = i + d; if (j >= n) j -= n; }
+        else { i = idx - full; j = i + n / 2; }
+        double ei = s_ev[i], ej = s_ev[j];
+        double sl = (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) / (ei - ej);
+        return f64_key(sl);
+    };
+    double slope = block_median(slope_key, ns, &sm);
+    double inter = block_median([&](i64 i) { return f64_key(s_md[i] - (slope * s_ev[i])); }, n, &sm);
+    if (tid == 0) {
+        if (slope == 0) { r.status = TBA_RESCALE_FAIL; return; }
+        double scale_corr = 1 / slope;
+        double shift_corr = -inter / slope;
+        r.ts[0] = r.shift + (shift_corr * r.scale);
+        r.ts[1] = r.scale * scale_corr;
+        r.ts[2] = shift_corr;
+        r.ts[3] = scale_corr;
+        r.shift = r.ts[0];
+        r.scale = r.ts[1];
+        r.changed = (fabs(shift_corr) > SHIFT_CHANGE_THRESH ||
+                     fabs(scale_corr - 1) > SCALE_CHANGE_THRESH) ? 1 : 0;
+    }
+}
+
+// norm_out[i] = (norm[read_start + i] - shift_corr) / scale_corr (resquiggle.py:1190), or a
+// plain trim copy when sequence rescaling is skipped.  grid: (blocks, reads)
+__global__ __launch_bounds__(256) void k_rescale(const ReadState *rs, const DevParams *dp,
+    const double *norm, double *norm_out)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const double *x = norm + r.raw_off + r.read_start;
+    double *y = norm_out + r.raw_off;
+    const bool skip = dp->o.skip_seq_scaling != 0;
+    const double a = r.ts[2], b = r.ts[3];
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.norm_len; i += (i64)gridDim.x * 256)
+        y[i] = skip ? x[i] : (x[i] - a) / b;
+}
+
+// c_new_means over the final signal (already trimmed: offset 0) -> |z| per base
+// grid: (blocks, reads)
+__global__ __launch_bounds__(256) void k_final_absz(const ReadState *rs, const double *norm_out,
+    const i64 *segs, const double *ref_means, const double *ref_sds, double *absz)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const double *x = norm_out + r.raw_off;
+    const i64 *sg = segs + r.seg_off;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.B; i += (i64)gridDim.x * 256) {
+        double s = 0;
+        for (i64 j = sg[i]; j < sg[i + 1]; j++) s += x[j];
+        double m = s / (double)(sg[i + 1] - sg[i]);
+        absz[r.ref_off + i] = fabs((m - ref_means[r.ref_off + i]) / ref_sds[r.ref_off + i]);
+    }
+}
+
+// ts.get_read_seg_score (tombo_stats.py:2327-2338): np.mean in numpy's summation order.
+// One thread per read.
+__global__ void k_final_score(ReadState *rs, i64 n_reads, const double *absz)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK) return;
+    r.score = np_sum(absz + r.ref_off, r.B) / (double)r.B;
+}

@@ -1,0 +1,165 @@
+// tba_common.h -- shared types + device helpers of the gfx950 resquiggle engine.
+// All float64 arithmetic here is two-operand IEEE in the reference's source order; the TU is
+// compiled with -ffp-contract=off (no FMA formation) and without fast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tombo_amd.h"
+
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef uint32_t u32;
+
+#define MASK_BASES 50             // _default_parameters.py:69
+#define MASK_FILL_Z_SCORE (-15.0) // _default_parameters.py:70
+#define DEL_FIX_WINDOW 2          // _default_parameters.py:72
+#define MAX_DEL_FIX_WINDOW 10     // _default_parameters.py:73
+#define EXTRA_SIG_FACTOR 1.1      // _default_parameters.py:67
+#define SHIFT_CHANGE_THRESH 0.1   // _default_parameters.py:169
+#define SCALE_CHANGE_THRESH 0.1   // _default_parameters.py:170
+#define MAX_TS_POINTS 1000        // _default_parameters.py:178
+
+enum { PATH_NONE = 0, PATH_ADAPTIVE = 1, PATH_STATIC = 2 };
+enum { ST_NONE = 0, ST_TRY = 1, ST_OK = 2, ST_RETRY = 3, ST_STATIC = 4 };
+
+// per-read state carried from kernel to kernel (device memory, one per read)
+struct ReadState {
+    i64 raw_off, n_raw;       // into raw / norm / score arrays (score arrays use raw_off + idx)
+    i64 seq_off, seq_len;     // into seq codes
+    i64 ref_off, B;           // into ref_means / ref_sds / band_starts / lo / hi (B per read)
+    i64 seg_off;              // into segs-like arrays (B+1 per read) = ref_off + read index
+    i64 ev_off, num_events;   // into valid_cpts / event_means (capacity num_events per read)
+    i64 stall_off, n_stall;
+    i32 status, path, start_state, sv_flags;
+    i32 n_start_calls, changed, pad0, pad1;
+    double shift, scale, lower, upper; // scale values in force after segment_signal
+    i32 has_lims, pad2;
+    i64 n_cpts, n_ev;
+    double start_res[4];      // (loc, events_per_base) of start-discovery call 0 / 1
+    i64 mapped_start; double epb;
+    i64 clip, offset, W, n_static, moves_off, top_pos;
+    i64 read_start, norm_len, dp_read_start;
+    double ts[4]; double score;
+};
+
+struct DevParams {
+    tba_params p;
+    tba_opts o;
+    i64 kmer_width, central_pos;
+    double fill_masked; // (MASK_FILL_Z_SCORE - z_shift) + z_shift, the round trip of
+                        // resquiggle.py:665-668,678
+};
+
+// order-preserving map double -> u64 (ascending); no NaNs on this path
+__device__ __forceinline__ u64 f64_key(double x)
+{
+    u64 b = (u64)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(u64 k)
+{
+    u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int d)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, d, 64);
+    hi = __shfl_up(hi, d, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ i64 shfl_i64(i64 v, int src)
+{
+    int lo = (int)(v & 0xffffffff), hi = (int)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((i64)hi << 32) | (u32)lo;
+}
+
+// numpy pairwise summation of a contiguous float64 vector (DOUBLE_pairwise_sum); n <= 8192.
+// Iterative form of the recursion n -> (n2 = n/2 - (n/2)%8, n - n2) with leaves of <= 128.
+__device__ inline double np_pairwise_leaf(const double *a, i64 n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (i64 i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    i64 i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+__device__ inline double np_pairwise_sum(const double *a, i64 n)
+{
+    if (n <= 128) return np_pairwise_leaf(a, n);
+    // explicit post-order walk; depth <= 7 for n <= 8192
+    const double *sa[16]; i64 sn[16]; double sv[16]; int sst[16];
+    int sp = 0;
+    sa[0] = a; sn[0] = n; sst[0] = 0;
+    double ret = 0;
+    while (sp >= 0) {
+        if (sn[sp] <= 128) {
+            ret = np_pairwise_leaf(sa[sp], sn[sp]);
+            sp--;
+            continue;
+        }
+        i64 n2 = sn[sp] / 2;
+        n2 -= n2 % 8;
+        if (sst[sp] == 0) {          // descend left
+            sst[sp] = 1;
+            sa[sp + 1] = sa[sp]; sn[sp + 1] = n2; sst[sp + 1] = 0;
+            sp++;
+        } else if (sst[sp] == 1) {   // left done -> descend right
+            sv[sp] = ret;
+            sst[sp] = 2;
+            sa[sp + 1] = sa[sp] + n2; sn[sp + 1] = sn[sp] - n2; sst[sp + 1] = 0;
+            sp++;
+        } else {                     // both done
+            ret = sv[sp] + ret;
+            sp--;
+        }
+    }
+    return ret;
+}
+// np.add.reduce of a contiguous float64 vector: 8192-element buffer chunks, each pairwise
+// summed, accumulated left to right onto 0.0 (pinned against numpy in tests)
+__device__ inline double np_sum(const double *a, i64 n)
+{
+    double acc = 0.0;
+    for (i64 i = 0; i < n; i += 8192) acc += np_pairwise_sum(a + i, n - i < 8192 ? n - i : 8192);
+    return acc;
+}
+
+// np.linspace(start, stop, num)[i]
+__device__ __forceinline__ double np_linspace_at(double start, double stop, i64 num, i64 i)
+{
+    i64 div = num - 1;
+    double delta = stop - start;
+    if (div <= 0) return (0.0 * delta) + start;
+    if (i == num - 1) return stop;
+    double step = delta / (double)div;
+    if (step == 0.0) return (((double)i / (double)div) * delta) + start;
+    return ((double)i * step) + start;
+}

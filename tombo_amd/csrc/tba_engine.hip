@@ -1,0 +1,478 @@
+// tba_engine.hip -- batch engine + C ABI (include/tombo_amd.h) of the gfx950 resquiggle path.
+// One engine == one GPU == one HIP stream; a batch is a fixed sequence of kernels over ragged
+// SoA buffers that stay resident in HBM between upload and download.
+#include "tba_common.h"
+#include "k_select.h"
+#include "k_segment.h"
+#include "k_dp.h"
+#include "k_tail.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+static int set_err(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return set_err(TBA_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return set_err(TBA_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+enum { N_STAGE = 16 };
+static const char *STAGE_NAMES[N_STAGE] = {
+    "normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels", "start_dp",
+    "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen", "rescale_score",
+    "rna_scale", "total"};
+
+struct tba_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[N_STAGE + 1] = {};
+    float stage_ms[32] = {};
+    bool have_model = false, have_batch = false, ran = false;
+    DevParams hp;
+    i64 n_reads = 0, S_tot = 0, seq_tot = 0, B_tot = 0, E_tot = 0, max_raw = 0, max_B = 0;
+    i64 start_moves_stride = 0, moves_arena = 0, skip_cap = 8192;
+    bool any_stall = false, have_samp = false, have_sv = false;
+    double algo_bytes = 0, dp_cells = 0;
+    std::vector<ReadState> h_rs;
+    DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
+        d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
+        d_win, d_bm, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
+        d_moves, d_dscr, d_iscr;
+    void release_all()
+    {
+        DevBuf *all[] = {&d_rs, &d_dp, &d_kmeans, &d_ksds, &d_raw, &d_norm, &d_norm_out, &d_csum,
+                         &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
+                         &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_bm, &d_absz,
+                         &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
+                         &d_moves, &d_dscr, &d_iscr};
+        for (DevBuf *b : all) b->release();
+    }
+};
+
+extern "C" const char *tba_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int tba_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int tba_engine_create(int device, tba_engine **out)
+{
+    if (!out) return set_err(TBA_E_ARG, "out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_err(TBA_E_HIP, "no HIP device visible: the resquiggle engine has no CPU fallback");
+    if (device < 0 || device >= n) return set_err(TBA_E_ARG, "bad device ordinal");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return set_err(TBA_E_HIP, std::string("device is ") + prop.gcnArchName +
+                                      ", this library carries gfx950 code only");
+    tba_engine *e = new tba_engine();
+    e->device = device;
+    HIP_TRY(hipStreamCreate(&e->stream));
+    for (int i = 0; i <= N_STAGE; i++) HIP_TRY(hipEventCreate(&e->ev[i]));
+    *out = e;
+    return 0;
+}
+
+extern "C" void tba_engine_destroy(tba_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    e->release_all();
+    for (int i = 0; i <= N_STAGE; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int tba_set_model(tba_engine *e, const double *kmer_means, const double *kmer_sds,
+                             int64_t kmer_width, int64_t central_pos)
+{
+    if (!e || !kmer_means || !kmer_sds || kmer_width < 1 || kmer_width > 12)
+        return set_err(TBA_E_ARG, "bad model arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t n = (size_t)1 << (2 * kmer_width);
+    if (e->d_kmeans.ensure(n * 8) || e->d_ksds.ensure(n * 8)) return TBA_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(e->d_kmeans.p, kmer_means, n * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_ksds.p, kmer_sds, n * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->hp.kmer_width = kmer_width;
+    e->hp.central_pos = central_pos;
+    e->have_model = true;
+    return 0;
+}
+
+extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_opts *o,
+                                int64_t n_reads, const double *raw, const int64_t *raw_off,
+                                const uint8_t *seq, const int64_t *seq_off, const double *sv_in,
+                                const int32_t *sv_flags, const int64_t *samp_ind,
+                                const int64_t *stall_ints, const int64_t *stall_off)
+{
+    if (!e || !p || !o || n_reads <= 0 || !raw || !raw_off || !seq || !seq_off)
+        return set_err(TBA_E_ARG, "bad batch arguments");
+    if (!e->have_model) return set_err(TBA_E_STATE, "tba_set_model has not been called");
+    if (p->bandwidth < 2 || p->running_stat_width < 1 || p->min_obs_per_base < 1 ||
+        p->raw_min_obs_per_base < 1 || p->mean_obs_per_event < 1 || p->start_n_bases < 1)
+        return set_err(TBA_E_ARG, "bad resquiggle parameters");
+    HIP_TRY(hipSetDevice(e->device));
+    e->have_batch = false;
+    e->ran = false;
+    e->hp.p = *p;
+    e->hp.o = *o;
+    e->hp.fill_masked = (MASK_FILL_Z_SCORE - p->z_shift) + p->z_shift;
+    const i64 K = e->hp.kmer_width;
+    const i64 n = n_reads;
+    e->n_reads = n;
+    e->h_rs.assign((size_t)n, ReadState());
+    i64 ref_acc = 0, ev_acc = 0, max_raw = 0, max_B = 0;
+    double algo_bytes = 0, cells = 0;
+    i64 moves_need = 0;
+    const int cpl_main = cpl_class(p->bandwidth);
+    for (i64 i = 0; i < n; i++) {
+        ReadState &r = e->h_rs[(size_t)i];
+        memset(&r, 0, sizeof(r));
+        r.raw_off = raw_off[i];
+        r.n_raw = raw_off[i + 1] - raw_off[i];
+        r.seq_off = seq_off[i];
+        r.seq_len = seq_off[i + 1] - seq_off[i];
+        i64 B = r.seq_len - K + 1;
+        r.ref_off = ref_acc;
+        r.seg_off = ref_acc + i;
+        r.B = B > 0 ? B : 0;
+        ref_acc += r.B;
+        r.ev_off = ev_acc;
+        r.status = TBA_OK;
+        r.sv_flags = sv_flags ? sv_flags[i] : 0;
+        if (stall_off) { r.stall_off = stall_off[i]; r.n_stall = stall_off[i + 1] - stall_off[i]; }
+        if (B <= 0 || r.n_raw <= 0) {
+            r.status = r.n_raw <= 0 ? TBA_NO_RAW : TBA_INTERNAL;
+            continue;
+        }
+        // ts.compute_num_events (tombo_stats.py:1558-1574) and the guard of resquiggle.py:1159
+        i64 num_events = std::max(r.n_raw / p->mean_obs_per_event,
+                                  (i64)((double)B * o->min_event_to_seq_ratio));
+        r.num_events = num_events; // event space is reserved for every read with B > 0
+        ev_acc += num_events;
+        if ((double)num_events / (double)p->bandwidth > (double)B) { r.status = TBA_TOO_MUCH_SIGNAL; continue; }
+        if (num_events <= 1 || r.n_raw < 4 * p->running_stat_width + 2) { r.status = TBA_INTERNAL; continue; }
+        max_raw = std::max(max_raw, r.n_raw);
+        max_B = std::max(max_B, B);
+        const i64 n_ev = num_events - 1;
+        const bool short_read = n_ev < p->start_bw + p->start_n_bases || B < p->start_n_bases;
+        int cpl = cpl_main;
+        if (short_read) cpl = std::max(cpl, cpl_class(std::min<i64>(n_ev, TBA_MAX_BAND)));
+        moves_need += (B + 1) * 64 * (i64)(cpl > 0 ? cpl : 48);
+        // algorithmic traffic: raw in + seq + norm out + segs + band starts +
+        // 2-bit moves + scalars
+        algo_bytes += 8.0 * r.n_raw + (double)r.seq_len + 8.0 * r.n_raw + 8.0 * (B + 1) + 8.0 * B +
+                      (double)((B * p->bandwidth + 3) / 4) + 64.0;
+        cells += (double)B * p->bandwidth + (short_read ? 0.0 : (double)p->start_n_bases * p->start_bw);
+    }
+    e->S_tot = raw_off[n];
+    e->seq_tot = seq_off[n];
+    e->B_tot = ref_acc;
+    e->E_tot = ev_acc;
+    e->max_raw = max_raw;
+    e->max_B = max_B;
+    e->algo_bytes = algo_bytes;
+    e->dp_cells = cells;
+    e->any_stall = stall_off != nullptr && stall_off[n] > 0;
+    e->have_samp = samp_ind != nullptr;
+    e->have_sv = sv_in != nullptr && sv_flags != nullptr;
+    const i64 start_w = std::max(p->start_bw, p->start_save_bw);
+    if (cpl_class(p->start_bw) == 0 || cpl_class(p->start_save_bw) == 0 || cpl_main == 0)
+        return set_err(TBA_E_ARG, "bandwidth / start bandwidth above TBA_MAX_BAND");
+    e->start_moves_stride = (p->start_n_bases + 1) * 64 * (i64)cpl_class(start_w);
+    e->moves_arena = moves_need + moves_need / 8 + (64ll << 20);
+
+    const size_t S = (size_t)std::max<i64>(e->S_tot, 1), Bt = (size_t)std::max<i64>(e->B_tot, 1),
+                 Et = (size_t)std::max<i64>(e->E_tot, 1), N = (size_t)n;
+    int rc = 0;
+    rc |= e->d_rs.ensure(N * sizeof(ReadState));
+    rc |= e->d_dp.ensure(sizeof(DevParams));
+    rc |= e->d_raw.ensure(S * 8);
+    rc |= e->d_norm.ensure(S * 8);
+    rc |= e->d_norm_out.ensure(S * 8);
+    rc |= e->d_csum.ensure((S + N) * 8);
+    rc |= e->d_score.ensure(S * 8);
+    rc |= e->d_state.ensure(S);
+    rc |= e->d_cpts.ensure(Et * 8);
+    rc |= e->d_evm.ensure(Et * 8);
+    rc |= e->d_seq.ensure((size_t)std::max<i64>(e->seq_tot, 1));
+    rc |= e->d_refm.ensure(Bt * 8);
+    rc |= e->d_refs.ensure(Bt * 8);
+    rc |= e->d_bst.ensure(Bt * 8);
+    rc |= e->d_lo.ensure(Bt * 4);
+    rc |= e->d_hi.ensure(Bt * 4);
+    rc |= e->d_readtb.ensure((Bt + N) * 8);
+    rc |= e->d_dpsegs.ensure((Bt + N) * 8);
+    rc |= e->d_segs.ensure((Bt + N) * 8);
+    rc |= e->d_win.ensure((Bt + N) * 16);
+    rc |= e->d_bm.ensure(Bt * 8);
+    rc |= e->d_absz.ensure(Bt * 8);
+    rc |= e->d_sv_in.ensure(N * 32);
+    rc |= e->d_samp.ensure(N * MAX_TS_POINTS * 8);
+    rc |= e->d_lastrow.ensure(N * TBA_MAX_BAND * 8);
+    rc |= e->d_startvals.ensure(N * (size_t)p->start_n_bases * 8);
+    rc |= e->d_smoves.ensure(N * (size_t)e->start_moves_stride);
+    rc |= e->d_moves.ensure((size_t)e->moves_arena);
+    rc |= e->d_dscr.ensure(N * 3 * (size_t)e->skip_cap * 8);
+    rc |= e->d_iscr.ensure(N * 2 * (size_t)e->skip_cap * 8);
+    if (e->any_stall) rc |= e->d_stall.ensure((size_t)stall_off[n] * 16);
+    if (rc) return TBA_E_NOMEM;
+
+    hipStream_t s = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.data(), N * sizeof(ReadState), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_dp.p, &e->hp, sizeof(DevParams), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_raw.p, raw, (size_t)e->S_tot * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_seq.p, seq, (size_t)e->seq_tot, hipMemcpyHostToDevice, s));
+    if (e->have_sv) HIP_TRY(hipMemcpyAsync(e->d_sv_in.p, sv_in, N * 32, hipMemcpyHostToDevice, s));
+    if (e->have_samp)
+        HIP_TRY(hipMemcpyAsync(e->d_samp.p, samp_ind, N * MAX_TS_POINTS * 8, hipMemcpyHostToDevice, s));
+    if (e->any_stall)
+        HIP_TRY(hipMemcpyAsync(e->d_stall.p, stall_ints, (size_t)stall_off[n] * 16, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    e->have_batch = true;
+    return 0;
+}
+
+template <int CPL>
+static void launch_dp_t(tba_engine *e, int mode)
+{
+    k_dp<CPL><<<dim3((unsigned)e->n_reads), dim3(64), 0, e->stream>>>(
+        e->d_rs.as<ReadState>(), e->d_dp.as<DevParams>(), mode, e->d_evm.as<double>(),
+        e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), e->d_lo.as<i32>(),
+        e->d_hi.as<i32>(),
+        mode == DP_MAIN ? e->d_moves.as<unsigned char>() : e->d_smoves.as<unsigned char>(),
+        e->start_moves_stride, e->d_lastrow.as<double>());
+}
+static void launch_dp(tba_engine *e, int cpl, int mode)
+{
+    switch (cpl) {
+    case 4: launch_dp_t<4>(e, mode); break;
+    case 8: launch_dp_t<8>(e, mode); break;
+    case 12: launch_dp_t<12>(e, mode); break;
+    case 16: launch_dp_t<16>(e, mode); break;
+    case 24: launch_dp_t<24>(e, mode); break;
+    case 32: launch_dp_t<32>(e, mode); break;
+    case 48: launch_dp_t<48>(e, mode); break;
+    default: break;
+    }
+}
+
+extern "C" int tba_batch_enqueue(tba_engine *e)
+{
+    if (!e || !e->have_batch) return set_err(TBA_E_STATE, "no batch uploaded");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const i64 n = e->n_reads;
+    const tba_params &P = e->hp.p;
+    ReadState *rs = e->d_rs.as<ReadState>();
+    const DevParams *dp = e->d_dp.as<DevParams>();
+    // the state of a previous run of the same batch is discarded
+    HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.data(), (size_t)n * sizeof(ReadState), hipMemcpyHostToDevice, s));
+    const unsigned nb = (unsigned)n;
+    const unsigned tpr = (unsigned)((n + 63) / 64); // blocks for thread-per-read kernels
+    auto gx = [](i64 items) { i64 g = (items + 255) / 256; return (unsigned)std::min<i64>(std::max<i64>(g, 1), 128); };
+    const unsigned gS = gx(e->max_raw), gB = gx(e->max_B), gE = gx(e->max_raw / std::max<i64>(P.mean_obs_per_event, 1) + 1);
+    int st = 0;
+#define MARK() HIP_TRY(hipEventRecord(e->ev[st++], s))
+    const bool rna = P.use_t_test_seg != 0;
+    MARK(); // 0 normalize
+    if (!rna)
+        k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0);
+    MARK(); // 1 cumsum
+    if (!rna) k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
+    MARK(); // 2 scores
+    if (!rna) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>());
+    else k_scores_ttest<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_score.as<double>());
+    MARK(); // 3 peaks
+    k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
+    if (e->any_stall) k_remove_stalls<<<tpr, 64, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>());
+    MARK(); // 4 event means (RNA: after event-based scaling)
+    if (rna) {
+        k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_raw.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+        k_rna_event_scale<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_evm.as<double>());
+        k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1);
+    }
+    k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+    MARK(); // 5 ref levels
+    k_ref_levels<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_seq.as<uint8_t>(), e->d_kmeans.as<double>(), e->d_ksds.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>());
+    k_path0<<<tpr, 64, 0, s>>>(rs, n, dp);
+    MARK(); // 6 start dp (+7 start tb): find_seq_start_in_events, first try then retry
+    launch_dp(e, cpl_class(P.start_bw), DP_START_TRY);
+    k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_TRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+    MARK(); // 7
+    launch_dp(e, cpl_class(P.start_save_bw), DP_START_RETRY);
+    k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_RETRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+    MARK(); // 8 prep
+    k_prep<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_bst.as<i64>(), e->d_lo.as<i32>(), e->d_hi.as<i32>());
+    k_scan_moves<<<1, 64, 0, s>>>(rs, n, e->moves_arena);
+    MARK(); // 9 main dp
+    {
+        const int cls[] = {4, 8, 12, 16, 24, 32, 48};
+        for (int c : cls) launch_dp(e, c, DP_MAIN);
+    }
+    MARK(); // 10 main tb
+    k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
+    MARK(); // 11 skip resolve
+    k_skip_resolve<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>(), e->d_iscr.as<i64>(), e->skip_cap);
+    MARK(); // 12 theil-sen
+    k_base_means<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_bm.as<double>());
+    k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_bm.as<double>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr);
+    MARK(); // 13 rescale + score
+    k_rescale<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_norm_out.as<double>());
+    k_final_absz<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
+    k_final_score<<<tpr, 64, 0, s>>>(rs, n, e->d_absz.as<double>());
+    MARK(); // 14 end
+#undef MARK
+    HIP_TRY(hipGetLastError());
+    e->ran = true;
+    return 0;
+}
+
+extern "C" int tba_batch_sync(tba_engine *e)
+{
+    if (!e) return set_err(TBA_E_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->ran) {
+        memset(e->stage_ms, 0, sizeof(e->stage_ms));
+        for (int i = 0; i < 14; i++) (void)hipEventElapsedTime(&e->stage_ms[i], e->ev[i], e->ev[i + 1]);
+        (void)hipEventElapsedTime(&e->stage_ms[15], e->ev[0], e->ev[14]);
+    }
+    return 0;
+}
+
+extern "C" int tba_batch_run(tba_engine *e)
+{
+    int rc = tba_batch_enqueue(e);
+    if (rc) return rc;
+    return tba_batch_sync(e);
+}
+
+extern "C" int tba_batch_download(tba_engine *e, int32_t *status, int64_t *segs,
+                                  int64_t *read_start_rel_to_raw, double *norm_signal,
+                                  int64_t *norm_len, double *scale_values,
+                                  double *sig_match_score, int32_t *norm_params_changed)
+{
+    if (!e || !e->ran) return set_err(TBA_E_STATE, "no batch has been run");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t)e->n_reads;
+    std::vector<ReadState> rs(N);
+    HIP_TRY(hipMemcpy(rs.data(), e->d_rs.p, N * sizeof(ReadState), hipMemcpyDeviceToHost));
+    if (segs) HIP_TRY(hipMemcpy(segs, e->d_segs.p, (size_t)(e->B_tot + e->n_reads) * 8, hipMemcpyDeviceToHost));
+    if (norm_signal) HIP_TRY(hipMemcpy(norm_signal, e->d_norm_out.p, (size_t)e->S_tot * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        const ReadState &r = rs[i];
+        if (status) status[i] = r.status;
+        if (read_start_rel_to_raw) read_start_rel_to_raw[i] = r.read_start;
+        if (norm_len) norm_len[i] = r.status == TBA_OK ? r.norm_len : 0;
+        if (scale_values) {
+            scale_values[4 * i + 0] = r.shift; scale_values[4 * i + 1] = r.scale;
+            scale_values[4 * i + 2] = r.has_lims ? r.lower : NAN;
+            scale_values[4 * i + 3] = r.has_lims ? r.upper : NAN;
+        }
+        if (sig_match_score) sig_match_score[i] = r.score;
+        if (norm_params_changed) norm_params_changed[i] = r.changed;
+    }
+    return 0;
+}
+
+extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_bytes)
+{
+    if (!e || !e->ran || !out) return set_err(TBA_E_STATE, "no batch has been run");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t)e->n_reads;
+    auto copy = [&](const DevBuf &b, size_t bytes) -> int {
+        if ((size_t)out_bytes < bytes) return set_err(TBA_E_ARG, "output buffer too small");
+        HIP_TRY(hipMemcpy(out, b.p, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    std::vector<ReadState> rs;
+    auto fetch_rs = [&]() -> int {
+        rs.resize(N);
+        HIP_TRY(hipMemcpy(rs.data(), e->d_rs.p, N * sizeof(ReadState), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    switch (what) {
+    case TBA_GET_VALID_CPTS: return copy(e->d_cpts, (size_t)e->E_tot * 8);
+    case TBA_GET_EVENT_MEANS: return copy(e->d_evm, (size_t)e->E_tot * 8);
+    case TBA_GET_SEG_NORM: return copy(e->d_norm, (size_t)e->S_tot * 8);
+    case TBA_GET_BAND_STARTS: return copy(e->d_bst, (size_t)e->B_tot * 8);
+    case TBA_GET_READ_TB: return copy(e->d_readtb, (size_t)(e->B_tot + e->n_reads) * 8);
+    case TBA_GET_DP_SEGS: return copy(e->d_dpsegs, (size_t)(e->B_tot + e->n_reads) * 8);
+    case TBA_GET_LAST_ROW: return copy(e->d_lastrow, N * TBA_MAX_BAND * 8);
+    case TBA_GET_KERNEL_MS:
+        if ((size_t)out_bytes < sizeof(e->stage_ms)) return set_err(TBA_E_ARG, "output buffer too small");
+        memcpy(out, e->stage_ms, sizeof(e->stage_ms));
+        return 0;
+    default: break;
+    }
+    if (int rc = fetch_rs()) return rc;
+    if (what == TBA_GET_N_CPTS || what == TBA_GET_DP_READ_START) {
+        if ((size_t)out_bytes < N * 8) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++)
+            ((i64 *)out)[i] = what == TBA_GET_N_CPTS ? rs[i].n_cpts : rs[i].dp_read_start;
+        return 0;
+    }
+    if (what == TBA_GET_SEG_SV || what == TBA_GET_START || what == TBA_GET_THEIL_SEN) {
+        if ((size_t)out_bytes < N * 32) return set_err(TBA_E_ARG, "output buffer too small");
+        double *o = (double *)out;
+        for (size_t i = 0; i < N; i++)
+            for (int k = 0; k < 4; k++)
+                o[4 * i + k] = what == TBA_GET_START ? rs[i].start_res[k]
+                               : what == TBA_GET_THEIL_SEN ? rs[i].ts[k]
+                               : (k == 0 ? rs[i].shift : k == 1 ? rs[i].scale : k == 2 ? rs[i].lower : rs[i].upper);
+        return 0;
+    }
+    if (what == TBA_GET_PATH) {
+        if ((size_t)out_bytes < N * 16) return set_err(TBA_E_ARG, "output buffer too small");
+        i32 *o = (i32 *)out;
+        for (size_t i = 0; i < N; i++) {
+            o[4 * i + 0] = rs[i].path; o[4 * i + 1] = (i32)rs[i].n_static;
+            o[4 * i + 2] = (i32)rs[i].W; o[4 * i + 3] = rs[i].n_start_calls;
+        }
+        return 0;
+    }
+    return set_err(TBA_E_ARG, "unknown TBA_GET_* selector");
+}
+
+extern "C" int tba_batch_stats(tba_engine *e, double *algorithmic_bytes, double *dp_cells)
+{
+    if (!e || !e->have_batch) return set_err(TBA_E_STATE, "no batch uploaded");
+    if (algorithmic_bytes) *algorithmic_bytes = e->algo_bytes;
+    if (dp_cells) *dp_cells = e->dp_cells;
+    return 0;
+}
+
+extern "C" const char *tba_stage_name(int i) { return i >= 0 && i < N_STAGE ? STAGE_NAMES[i] : ""; }
