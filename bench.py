@@ -18,7 +18,6 @@ import sys
 import json
 import time
 import argparse
-import multiprocessing as mp
 
 import numpy as np
 
@@ -40,11 +39,25 @@ def _gen(args):
     return ts.encode_seq(seq).copy(), raw
 
 
+def _under_profiler():
+    keys = ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB', 'ROCPROFILER_REGISTER_LIBRARY')
+    return any('rocprof' in os.environ.get(k, '').lower() for k in keys)
+
+
 def make_reads(n_reads, n_bases, base_seed, workers):
+    """Synthetic reads (read i: seed base_seed + i).  Worker processes are forked before any
+    HIP state exists; under rocprofv3 forked workers deadlock in the tool's signal handler, so
+    threads are used there."""
     jobs = [(n_bases, base_seed + i) for i in range(n_reads)]
-    if workers > 1 and n_reads >= 64:
+    _gen(jobs[0])
+    if workers > 1 and n_reads >= 64 and not _under_profiler():
+        import multiprocessing as mp
         with mp.get_context('fork').Pool(workers) as pool:
             res = pool.map(_gen, jobs, chunksize=max(1, n_reads // (workers * 8)))
+    elif workers > 1 and n_reads >= 64:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as ex:
+            res = list(ex.map(_gen, jobs, chunksize=max(1, n_reads // (workers * 8))))
     else:
         res = [_gen(j) for j in jobs]
     return [r[0] for r in res], [r[1] for r in res]
@@ -89,15 +102,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev)
-
+    # synthetic input first: worker processes must be forked before HIP is initialised
     from tombo_amd import _native, tombo_stats as ts, tombo_helper as th
     samp = th.seqSampleType('DNA', False)
     model = ts.TomboModel(seq_samp_type=samp)
@@ -108,6 +113,15 @@ def main():
     si = None
     if a.bases > 1000:
         si = np.stack([rng.choice(a.bases, 1000, replace=False) for _ in range(a.reads)])
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev)
 
     eng = _native.Engine(dev)
     eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)

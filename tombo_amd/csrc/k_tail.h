@@ -33,40 +33,45 @@ __device__ inline int window_too_small(const i64 *segs, i64 n_segs, Win w, i64 m
     return (double)(se - ss) <= (double)((n_events + 1) * m) * EXTRA_SIG_FACTOR;
 }
 
-// raw-signal DP of one window; scratch: z, fw (cap doubles each), ld (2 * max_len i64),
-// cum (max_len doubles).  Layout identical to the oracle's orc_raw_window_dp.
+// raw-signal DP of one window.  scratch (8-byte units): fw[n*len] forward scores of every base
+// (the traceback compares adjacent rows), zp/zc[len] z-scores of the previous / current base,
+// cum[len] np.cumsum of the previous base's z-scores, ld[2*len] last-diagonal counters.
+// raw_window_need() is the matching size.
+__device__ __forceinline__ i64 raw_window_need(i64 n, i64 len) { return n * len + 5 * len; }
+
+__device__ inline void base_z_row(const double *x, i64 len, double mu, double sd, bool winsor,
+                                  double mh, double *z)
+{
+    for (i64 k = 0; k < len; k++) { // c_base_z_scores, pyx:17-32
+        double v = (x[k] - mu) / sd;
+        if (v > 0) v = -v;
+        if (winsor && v < -mh) v = -mh;
+        z[k] = v;
+    }
+}
+
 __device__ inline int raw_window_dp(const double *sig, i64 L, const double *means,
-    const double *sds, i64 n, i64 m, bool winsor, double mh, double *z, double *fw, i64 *ld,
-    double *cum, i64 cap, i64 *new_segs)
+    const double *sds, i64 n, i64 m, bool winsor, double mh, double *scratch, i64 *new_segs)
 {
     if (n < 2) return TBA_INTERNAL;
-    // admissible interval of base i: [i*m, L-(n-1-i)*m)  (pyx:56-81)
-    if (L - (n - 1) * m <= 0) return TBA_INTERNAL;
-    const i64 len = L - (n - 1) * m; // every base has the same interval length
-    if (n * len > cap) return TBA_UNSUPPORTED;
-    for (i64 i = 0; i < n; i++) {
-        const double mu = means[i], sd = sds[i];
-        const double *x = sig + i * m;
-        double *zi = z + i * len;
-        for (i64 k = 0; k < len; k++) { // c_base_z_scores, pyx:17-32
-            double v = (x[k] - mu) / sd;
-            if (v > 0) v = -v;
-            if (winsor && v < -mh) v = -mh;
-            zi[k] = v;
-        }
-    }
-    i64 *pl = ld, *bl = ld + len;
-    { // first row: np.cumsum, last_diag = m
+    // admissible interval of base i: [i*m, L-(n-1-i)*m)  (pyx:56-81): same length for all
+    const i64 len = L - (n - 1) * m;
+    if (len <= 0) return TBA_INTERNAL;
+    double *fw = scratch, *zp = fw + n * len, *zc = zp + len, *cum = zc + len;
+    i64 *pl = (i64 *)(cum + len), *bl = pl + len;
+    base_z_row(sig, len, means[0], sds[0], winsor, mh, zp);
+    { // first row: np.cumsum, last_diag = m (resquiggle.py:352-361)
         double acc = 0;
-        for (i64 k = 0; k < len; k++) { acc = k == 0 ? z[k] : acc + z[k]; fw[k] = acc; pl[k] = m; }
+        for (i64 k = 0; k < len; k++) { acc = k == 0 ? zp[k] : acc + zp[k]; fw[k] = acc; pl[k] = m; }
     }
-    for (i64 i = 1; i < n; i++) {
-        const double *pz = z + (i - 1) * len, *pf = fw + (i - 1) * len, *bz = z + i * len;
+    for (i64 i = 1; i < n; i++) { // c_base_forward_pass, pyx:99-163
+        base_z_row(sig + i * m, len, means[i], sds[i], winsor, mh, zc);
+        const double *pf = fw + (i - 1) * len;
         double *bf = fw + i * len;
         const i64 ps = (i - 1) * m, pe = ps + len, b_s = i * m, b_e = b_s + len;
-        { double acc = 0; for (i64 k = 0; k < len; k++) { acc = k == 0 ? pz[k] : acc + pz[k]; cum[k] = acc; } }
+        { double acc = 0; for (i64 k = 0; k < len; k++) { acc = k == 0 ? zp[k] : acc + zp[k]; cum[k] = acc; } }
         if (b_s - ps - 1 < 0 || b_s - ps - 1 >= len) return TBA_INTERNAL;
-        bf[0] = bz[0] + pf[b_s - ps - 1];
+        bf[0] = zc[0] + pf[b_s - ps - 1];
         bl[0] = 1;
         for (i64 pos = b_s + 1; pos < pe + 1; pos++) {
             if (pos - b_s >= len) break;
@@ -87,22 +92,23 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
             i64 dv;
             if (diag > stay) { best = diag; dv = 1; }
             else { best = stay; dv = bl[pos - b_s - 1] + 1; }
-            bf[pos - b_s] = bz[pos - b_s] + best;
+            bf[pos - b_s] = zc[pos - b_s] + best;
             bl[pos - b_s] = dv;
         }
         if (b_e > pe + 1) {
             double fv = bf[pe - b_s];
             i64 cl = bl[pe - b_s];
             for (i64 k = 0; k < b_e - pe - 1; k++) {
-                fv += bz[k + pe - b_s + 1];
+                fv += zc[k + pe - b_s + 1];
                 cl += 1;
                 bf[k + pe - b_s + 1] = fv;
                 bl[k + pe - b_s + 1] = cl;
             }
         }
         i64 *t = pl; pl = bl; bl = t;
+        double *tz = zp; zp = zc; zc = tz;
     }
-    i64 sig_start = (n - 1) * m + len - 1;
+    i64 sig_start = (n - 1) * m + len - 1; // raw_traceback / c_base_traceback, pyx:165-182
     for (i64 b = n - 1; b >= 1; b--) {
         const double *cf = fw + b * len, *nf = fw + (b - 1) * len;
         const i64 cs = b * m, ns = (b - 1) * m, ne = ns + len;
@@ -120,14 +126,99 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
     return TBA_OK;
 }
 
-__global__ void k_skip_resolve(ReadState *rs, i64 n_reads, const DevParams *dp,
-    const double *norm, const double *ref_means, const double *ref_sds, const i64 *dp_segs,
-    i64 *segs, i64 *win_scratch, double *dscratch, i64 *iscratch, i64 cap)
+// get_deletion_windows (resquiggle.py:462-498) + per-window scratch sizing; one thread per read.
+// win[3*k..] = (start, end, scratch offset inside the read's slice); r.n_win, r.skip_off (need,
+// turned into an arena offset by k_scan_skip).
+__global__ void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp, const i64 *dp_segs,
+    i64 *win_scratch)
 {
     i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (ri >= n_reads) return;
     ReadState &r = rs[ri];
+    r.n_win = 0; r.skip_off = 0;
     if (r.status != TBA_OK) return;
+    const i64 m = dp->p.raw_min_obs_per_base;
+    const i64 n_segs = r.B + 1;
+    const i64 *ds = dp_segs + r.seg_off;
+    // windows are built in place as (s, e) pairs, then widened to (s, e, off) triples back to
+    // front; capacity 3 * (B + 1) entries per read
+    Win *w = (Win *)(win_scratch + 3 * r.seg_off);
+    i64 nw = 0;
+    for (i64 d = 0; d + 1 < n_segs; d++) {
+        if (ds[d + 1] - ds[d] != 0) continue;
+        if (nw > 0 && d < w[nw - 1].e + DEL_FIX_WINDOW) w[nw - 1].e = d + DEL_FIX_WINDOW + 1;
+        else { w[nw].s = d - DEL_FIX_WINDOW; w[nw].e = d + DEL_FIX_WINDOW + 1; nw++; }
+    }
+    if (nw == 0) return;
+    bool expanded = false;
+    nw = merge_windows(w, nw);
+    trim_windows(w, nw, n_segs);
+    for (int it = 0; it < MAX_DEL_FIX_WINDOW - DEL_FIX_WINDOW; it++) {
+        expanded = false;
+        for (i64 i = 0; i < nw; i++) {
+            int ts = window_too_small(ds, n_segs, w[i], m);
+            if (ts < 0) { r.status = TBA_INTERNAL; return; }
+            if (ts) { expanded = true; w[i].s -= 1; w[i].e += 1; }
+        }
+        if (!expanded) break;
+        nw = merge_windows(w, nw);
+        trim_windows(w, nw, n_segs);
+    }
+    if (expanded) {
+        for (i64 i = 0; i < nw; i++) {
+            int ts = window_too_small(ds, n_segs, w[i], m);
+            if (ts < 0) { r.status = TBA_INTERNAL; return; }
+            if (ts) { r.status = TBA_NOT_ENOUGH_DEL_SIGNAL; return; }
+        }
+    }
+    if (dp->o.max_raw_cpts >= 0) {
+        i64 mx = 0;
+        for (i64 i = 0; i < nw; i++) mx = w[i].e - w[i].s > mx ? w[i].e - w[i].s : mx;
+        if (mx > dp->o.max_raw_cpts) { r.status = TBA_TOO_MANY_DELS; return; }
+    }
+    i64 *w3 = win_scratch + 3 * r.seg_off;
+    for (i64 i = nw - 1; i >= 0; i--) { // widen pairs to triples, back to front
+        const i64 s = w[i].s, e = w[i].e;
+        w3[3 * i] = s; w3[3 * i + 1] = e; w3[3 * i + 2] = 0;
+    }
+    i64 acc = 0;
+    for (i64 i = 0; i < nw; i++) {
+        const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
+        if (s < 0 || e >= n_segs) { r.status = TBA_INTERNAL; return; }
+        const i64 L = ds[e] - ds[s];
+        const i64 len = L - (n - 1) * m;
+        if (len <= 0 || n < 2) { r.status = TBA_INTERNAL; return; }
+        w3[3 * i + 2] = acc;
+        acc += raw_window_need(n, len);
+    }
+    r.n_win = nw;
+    r.skip_off = acc;
+}
+
+// exclusive scan of the per-read scratch needs into arena offsets (single thread)
+__global__ void k_scan_skip(ReadState *rs, i64 n_reads, i64 arena_units)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    i64 acc = 0;
+    for (i64 i = 0; i < n_reads; i++) {
+        ReadState &r = rs[i];
+        i64 sz = r.skip_off;
+        if (r.status != TBA_OK || sz == 0) { r.skip_off = 0; continue; }
+        if (acc + sz > arena_units) { r.status = TBA_UNSUPPORTED; r.skip_off = 0; continue; }
+        r.skip_off = acc;
+        acc += sz;
+    }
+}
+
+// rq.resolve_skipped_bases_with_raw window loop + final checks (resquiggle.py:500-538).
+// One wavefront per read, one window per lane at a time (windows own disjoint boundary ranges).
+__global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *dp,
+    const double *norm, const double *ref_means, const double *ref_sds, const i64 *dp_segs,
+    i64 *segs, const i64 *win_scratch, double *arena)
+{
+    ReadState &r = rs[blockIdx.x];
+    if (r.status != TBA_OK) return;
+    const int lane = threadIdx.x;
     const tba_params &P = dp->p;
     const i64 m = P.raw_min_obs_per_base;
     const i64 n_segs = r.B + 1;
@@ -136,61 +227,36 @@ __global__ void k_skip_resolve(ReadState *rs, i64 n_reads, const DevParams *dp,
     const double *sig = norm + r.raw_off + r.read_start; // norm_signal[read_start:...]
     const i64 n_norm = r.norm_len;
     const double *mu = ref_means + r.ref_off, *sd = ref_sds + r.ref_off;
-    for (i64 i = 0; i < n_segs; i++) out[i] = ds[i];
-    Win *w = (Win *)(win_scratch + 2 * r.seg_off);
-    i64 nw = 0;
-    for (i64 d = 0; d + 1 < n_segs; d++) {
-        if (ds[d + 1] - ds[d] != 0) continue;
-        if (nw > 0 && d < w[nw - 1].e + DEL_FIX_WINDOW) w[nw - 1].e = d + DEL_FIX_WINDOW + 1;
-        else { w[nw].s = d - DEL_FIX_WINDOW; w[nw].e = d + DEL_FIX_WINDOW + 1; nw++; }
+    for (i64 i = lane; i < n_segs; i += 64) out[i] = ds[i];
+    __syncthreads();
+    const i64 *w3 = win_scratch + 3 * r.seg_off;
+    int rc = TBA_OK;
+    for (i64 i = lane; i < r.n_win; i += 64) {
+        const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
+        const i64 sig_start = ds[s], sig_end = ds[e];
+        if (sig_start < 0 || sig_end > n_norm) { rc = TBA_INTERNAL; break; }
+        int rr = raw_window_dp(sig + sig_start, sig_end - sig_start, mu + s, sd + s, n, m,
+                               P.do_winsorize_z != 0, P.max_half_z_score,
+                               arena + r.skip_off + w3[3 * i + 2], out + s + 1);
+        if (rr != TBA_OK) { rc = rr; break; }
+        for (i64 k = 0; k < n - 1; k++) out[s + 1 + k] += sig_start;
     }
-    if (nw > 0) {
-        bool expanded = false;
-        nw = merge_windows(w, nw);
-        trim_windows(w, nw, n_segs);
-        for (int it = 0; it < MAX_DEL_FIX_WINDOW - DEL_FIX_WINDOW; it++) {
-            expanded = false;
-            for (i64 i = 0; i < nw; i++) {
-                int ts = window_too_small(ds, n_segs, w[i], m);
-                if (ts < 0) { r.status = TBA_INTERNAL; return; }
-                if (ts) { expanded = true; w[i].s -= 1; w[i].e += 1; }
-            }
-            if (!expanded) break;
-            nw = merge_windows(w, nw);
-            trim_windows(w, nw, n_segs);
-        }
-        if (expanded) {
-            for (i64 i = 0; i < nw; i++) {
-                int ts = window_too_small(ds, n_segs, w[i], m);
-                if (ts < 0) { r.status = TBA_INTERNAL; return; }
-                if (ts) { r.status = TBA_NOT_ENOUGH_DEL_SIGNAL; return; }
-            }
-        }
-        if (dp->o.max_raw_cpts >= 0) {
-            i64 mx = 0;
-            for (i64 i = 0; i < nw; i++) mx = w[i].e - w[i].s > mx ? w[i].e - w[i].s : mx;
-            if (mx > dp->o.max_raw_cpts) { r.status = TBA_TOO_MANY_DELS; return; }
-        }
-        // scratch of this read: z, fw: cap doubles each; cum: cap doubles; ld: 2*cap i64
-        double *z = dscratch + ri * 3 * cap, *fw = z + cap, *cum = fw + cap;
-        i64 *ld = iscratch + ri * 2 * cap;
-        for (i64 i = 0; i < nw; i++) {
-            const i64 s = w[i].s, e = w[i].e, n = e - s;
-            if (s < 0 || e >= n_segs) { r.status = TBA_INTERNAL; return; }
-            const i64 sig_start = ds[s], sig_end = ds[e];
-            if (sig_start < 0 || sig_end > n_norm) { r.status = TBA_INTERNAL; return; }
-            // new boundaries land directly in out[s+1 .. e-1] (relative to the window start)
-            int rc = raw_window_dp(sig + sig_start, sig_end - sig_start, mu + s, sd + s, n, m,
-                                   P.do_winsorize_z != 0, P.max_half_z_score, z, fw, ld, cum,
-                                   cap, out + s + 1);
-            if (rc != TBA_OK) { r.status = rc; return; }
-            for (i64 k = 0; k < n - 1; k++) out[s + 1 + k] += sig_start;
-        }
+    // first failing window in window order decides the status, as in the sequential loop
+    // (all window failures here are non-Tombo errors, so any of them is "unexpected")
+    if (__syncthreads_or(rc != TBA_OK)) {
+        int code = rc != TBA_OK ? rc : 0x7fffffff;
+        for (int o = 32; o >= 1; o >>= 1) { int t = __shfl_xor(code, o, 64); code = t < code ? t : code; }
+        if (lane == 0) r.status = code;
+        return;
     }
-    for (i64 i = 0; i + 1 < n_segs; i++)
-        if (out[i + 1] - out[i] < 1) { r.status = TBA_ZERO_LEN; return; }
-    if (out[0] < 0) { r.status = TBA_NEG_START; return; }
-    if (out[n_segs - 1] > n_norm) { r.status = TBA_PAST_END; return; }
+    int flag = 0; // 1: zero-length event
+    for (i64 i = lane; i + 1 < n_segs; i += 64)
+        if (out[i + 1] - out[i] < 1) flag = 1;
+    if (__syncthreads_or(flag)) { if (lane == 0) r.status = TBA_ZERO_LEN; return; }
+    if (lane == 0) {
+        if (out[0] < 0) r.status = TBA_NEG_START;
+        else if (out[n_segs - 1] > n_norm) r.status = TBA_PAST_END;
+    }
 }
 
 // c_new_means over base boundaries: means of sig[read_start + segs[i] : read_start + segs[i+1]]

@@ -40,6 +40,7 @@ struct ReadState {
     i64 mapped_start; double epb;
     i64 clip, offset, W, n_static, moves_off, top_pos;
     i64 read_start, norm_len, dp_read_start;
+    i64 n_win, skip_off;      // deletion windows of this read, scratch arena offset
     double ts[4]; double score;
 };
 

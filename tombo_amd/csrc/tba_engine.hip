@@ -54,21 +54,21 @@ struct tba_engine {
     bool have_model = false, have_batch = false, ran = false;
     DevParams hp;
     i64 n_reads = 0, S_tot = 0, seq_tot = 0, B_tot = 0, E_tot = 0, max_raw = 0, max_B = 0;
-    i64 start_moves_stride = 0, moves_arena = 0, skip_cap = 8192;
+    i64 start_moves_stride = 0, moves_arena = 0, skip_arena = 0;
     bool any_stall = false, have_samp = false, have_sv = false;
     double algo_bytes = 0, dp_cells = 0;
     std::vector<ReadState> h_rs;
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_bm, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
-        d_moves, d_dscr, d_iscr;
+        d_moves, d_dscr;
     void release_all()
     {
         DevBuf *all[] = {&d_rs, &d_dp, &d_kmeans, &d_ksds, &d_raw, &d_norm, &d_norm_out, &d_csum,
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_bm, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr, &d_iscr};
+                         &d_moves, &d_dscr};
         for (DevBuf *b : all) b->release();
     }
 };
@@ -236,7 +236,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     rc |= e->d_readtb.ensure((Bt + N) * 8);
     rc |= e->d_dpsegs.ensure((Bt + N) * 8);
     rc |= e->d_segs.ensure((Bt + N) * 8);
-    rc |= e->d_win.ensure((Bt + N) * 16);
+    rc |= e->d_win.ensure((Bt + N) * 24);
     rc |= e->d_bm.ensure(Bt * 8);
     rc |= e->d_absz.ensure(Bt * 8);
     rc |= e->d_sv_in.ensure(N * 32);
@@ -245,8 +245,10 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     rc |= e->d_startvals.ensure(N * (size_t)p->start_n_bases * 8);
     rc |= e->d_smoves.ensure(N * (size_t)e->start_moves_stride);
     rc |= e->d_moves.ensure((size_t)e->moves_arena);
-    rc |= e->d_dscr.ensure(N * 3 * (size_t)e->skip_cap * 8);
-    rc |= e->d_iscr.ensure(N * 2 * (size_t)e->skip_cap * 8);
+    // raw-DP scratch arena (8-byte units): windows are a few bases x tens of samples; reads that
+    // do not fit the arena get TBA_UNSUPPORTED
+    e->skip_arena = (i64)N * 32768 + (32ll << 20);
+    rc |= e->d_dscr.ensure((size_t)e->skip_arena * 8);
     if (e->any_stall) rc |= e->d_stall.ensure((size_t)stall_off[n] * 16);
     if (rc) return TBA_E_NOMEM;
 
@@ -345,7 +347,9 @@ extern "C" int tba_batch_enqueue(tba_engine *e)
     MARK(); // 10 main tb
     k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
     MARK(); // 11 skip resolve
-    k_skip_resolve<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>(), e->d_iscr.as<i64>(), e->skip_cap);
+    k_skip_plan<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
+    k_scan_skip<<<1, 64, 0, s>>>(rs, n, e->skip_arena);
+    k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
     MARK(); // 12 theil-sen
     k_base_means<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_bm.as<double>());
     k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_bm.as<double>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr);
