@@ -168,3 +168,70 @@ def resquiggle_read(raw, seq_codes, kmer_means, kmer_sds, params, opts, stall_in
             dp_read_start=int(dbg.dp_read_start), theil_sen=np.array(list(dbg.theil_sen)),
             used_static=bool(dbg.used_static), mask_seq_len=int(dbg.mask_seq_len))
     return out
+
+
+# ---- kernel-level restatements (used to check the tba_c_* entry points) ---------------------
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def base_z_scores(sig, mean, sd, winsor=False, mh=10.0):
+    sig = _c(sig, np.float64)
+    out = np.empty_like(sig)
+    lib().orc_base_z_scores(_p(sig), i64(sig.shape[0]), f64(mean), f64(sd), C.c_int(int(winsor)),
+                            f64(mh), _p(out))
+    return out
+
+
+def banded_forward_pass(z, starts, skip_pen, stay_pen):
+    z, starts = _c(z, np.float64), _c(starts, np.int64)
+    n, bw = z.shape
+    fwd = np.empty((n + 1, bw))
+    tb = np.empty((n + 1, bw), np.int8)
+    lib().orc_banded_forward_pass(_p(z), i64(n), i64(bw), _p(starts, C.c_int64), f64(skip_pen),
+                                  f64(stay_pen), _p(fwd), _p(tb, C.c_int8))
+    return fwd, tb.astype(np.int64)
+
+
+def adaptive_banded_forward_pass(fwd, tb, starts, event_means, mu, sd, z_shift, skip_pen,
+                                 stay_pen, start_seq_pos, fill, winsor, mh):
+    """in place on fwd (f64), tb (int8), starts (i64); returns status"""
+    n, bw = fwd.shape[0] - 1, fwd.shape[1]
+    ev, mu, sd = _c(event_means, np.float64), _c(mu, np.float64), _c(sd, np.float64)
+    return lib().orc_adaptive_banded_forward_pass(
+        _p(fwd), _p(tb, C.c_int8), i64(n), i64(bw), _p(starts, C.c_int64), _p(ev),
+        i64(ev.shape[0]), _p(mu), _p(sd), f64(z_shift), f64(skip_pen), f64(stay_pen),
+        i64(start_seq_pos), f64(fill), C.c_int(int(winsor)), f64(mh))
+
+
+def banded_traceback(tb, starts, band_pos, thresh=-1):
+    tb8 = _c(tb, np.int8)
+    starts = _c(starts, np.int64)
+    n, bw = tb8.shape[0] - 1, tb8.shape[1]
+    out = np.empty(n + 1, np.int64)
+    rc = lib().orc_banded_traceback(_p(tb8, C.c_int8), i64(n), i64(bw), _p(starts, C.c_int64),
+                                    i64(band_pos), i64(thresh), _p(out, C.c_int64))
+    return rc, out
+
+
+def new_means(sig, segs):
+    sig, segs = _c(sig, np.float64), _c(segs, np.int64)
+    out = np.empty(segs.shape[0] - 1)
+    lib().orc_new_means(_p(sig), _p(segs, C.c_int64), i64(segs.shape[0] - 1), _p(out))
+    return out
+
+
+def apply_outlier_thresh(sig, lo, hi):
+    sig = _c(sig, np.float64)
+    out = np.empty_like(sig)
+    lib().orc_apply_outlier_thresh(_p(sig), i64(sig.shape[0]), f64(lo), f64(hi), _p(out))
+    return out
+
+
+def valid_cpts(sig, min_base_obs, width, num_cpts, ttest=False):
+    sig = _c(sig, np.float64)
+    out = np.empty(num_cpts, np.int64)
+    fn = lib().orc_valid_cpts_w_cap_t_test if ttest else lib().orc_valid_cpts_w_cap
+    rc = fn(_p(sig), i64(sig.shape[0]), i64(min_base_obs), i64(width), i64(num_cpts),
+            _p(out, C.c_int64))
+    return rc, out

@@ -1,0 +1,106 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header
+declares, the host mirror of the reference interface behaves, errors map to the reference's
+strings, and the product path fails loudly without a GPU."""
+import os
+import re
+import ctypes
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def test_library_exports_every_declared_symbol():
+    from tombo_amd import _native
+    _native.build()
+    hdr = open(os.path.join(ROOT, 'include', 'tombo_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(tba_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, 'declared in include/tombo_amd.h but not exported: %s' % missing
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of tba_params / tba_opts have the header's field order"""
+    from tombo_amd import _native
+    hdr = open(os.path.join(ROOT, 'include', 'tombo_amd.h')).read()
+    body = hdr[hdr.index('typedef struct {', hdr.index('th.resquiggleParams')):hdr.index('} tba_params;')]
+    names = re.findall(r'\b([a-z_]+)\s*[,;]', re.sub(r'/\*.*?\*/', '', body, flags=re.S))
+    assert names == [f[0] for f in _native.Params._fields_]
+    body = hdr[hdr.index('typedef struct {', hdr.index('} tba_params;')):hdr.index('} tba_opts;')]
+    names = re.findall(r'\b([a-z_]+)\s*[,;]', re.sub(r'/\*.*?\*/', '', body, flags=re.S))
+    assert names == [f[0] for f in _native.Opts._fields_]
+
+
+def test_no_cpu_fallback_without_gpu():
+    from tombo_amd import _native
+    lib = _native.lib()
+    if lib.tba_device_count() > 0:
+        pytest.skip('a GPU is visible here')
+    with pytest.raises(_native.EngineError, match='no CPU fallback'):
+        _native.Engine(0)
+    from tombo_amd import resquiggle as rq, tombo_stats as ts, tombo_helper as th, synth
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    mr = synth.synth_map_res(model, 300, 1, **synth.DNA_SYNTH)
+    with pytest.raises(_native.EngineError):
+        rq.resquiggle_read(mr, model, ts.load_resquiggle_parameters(samp), 5.0)
+
+
+def test_error_table_is_the_reference_taxonomy():
+    from tombo_amd import errors, tombo_helper as th
+    hdr = open(os.path.join(ROOT, 'include', 'tombo_amd.h')).read()
+    codes = dict((int(v), k) for k, v in re.findall(r'(TBA_[A-Z_]+) = (\d+),', hdr))
+    for code in errors.MESSAGES:
+        assert code in codes
+    assert errors.MESSAGES[10] == 'Adaptive signal to seqeunce alignment extended beyond raw signal'
+    assert errors.MESSAGES[12] == 'Discordant reference and seqeunce lengths.'
+    with pytest.raises(th.TomboError, match='extends beyond bandwidth'):
+        errors.raise_for_status(11)
+    with pytest.raises(RuntimeError):
+        errors.raise_for_status(100)
+    errors.raise_for_status(0)
+
+
+def test_params_and_model_match_reference_values():
+    from tombo_amd import tombo_stats as ts, tombo_helper as th
+    dna = ts.load_resquiggle_parameters(th.seqSampleType('DNA', False))
+    assert dna == th.resquiggleParams(
+        4.2, 4.2, 300, 20.0, 5, 3, 1, 5, 4.9978845608028655, 4.2, False, 40, 750, 2500, 250)
+    rna = ts.load_resquiggle_parameters(th.seqSampleType('RNA', False), use_save_bandwidth=True)
+    assert (rna.bandwidth, rna.use_t_test_seg, rna.start_bw) == (1500, True, 1000)
+    assert float.hex(rna.z_shift - 6) == float.hex(float.fromhex('0x1.9884533d43651p-1') + 6 - 6)
+    m = ts.TomboModel(seq_samp_type=th.seqSampleType('DNA', False))
+    assert (m.kmer_width, m.central_pos) == (6, 2)
+    mu, sd = m.get_exp_levels_from_seq('ACGTACGTAC')
+    assert mu.shape == (5,) and mu[0] == m.means['ACGTAC'] and sd[4] == m.sds['ACGTAC']
+    assert ts.compute_num_events(92067, 10000, 5) == 18413
+    assert ts.compute_num_events(1000, 10000, 5) == 11000
+    with pytest.raises(th.TomboError):
+        m.get_exp_levels_from_seq('ACGTNCGTAC')
+    r = ts.TomboModel(seq_samp_type=th.seqSampleType('RNA', False))
+    assert (r.kmer_width, r.central_pos) == (5, 1)
+
+
+def test_resquiggle_results_tuple_is_field_compatible():
+    from tombo_amd import tombo_helper as th
+    assert th.resquiggleResults._fields == (
+        'align_info', 'genome_loc', 'genome_seq', 'mean_q_score', 'raw_signal', 'channel_info',
+        'read_start_rel_to_raw', 'segs', 'scale_values', 'sig_match_score',
+        'norm_params_changed', 'start_clip_bases', 'stall_ints')
+    assert th.scaleValues._fields == ('shift', 'scale', 'lower_lim', 'upper_lim', 'outlier_thresh')
+    assert th.dpResults._fields == ('read_start_rel_to_raw', 'segs', 'ref_means', 'ref_sds',
+                                    'genome_seq')
+    mr = th.resquiggleResults('a', 'b', 'ACGT', 1.0)
+    assert mr.raw_signal is None and mr.stall_ints is None
+
+
+def test_remove_stall_cpts_walk():
+    from tombo_amd import tombo_stats as ts
+    cpts = np.array([5, 10, 20, 30, 40, 50, 60, 100], dtype=np.int64)
+    out = ts.remove_stall_cpts([(8, 25), (45, 60)], cpts)
+    assert out.tolist() == [5, 30, 40, 60, 100]
+    assert ts.remove_stall_cpts([], cpts) is cpts

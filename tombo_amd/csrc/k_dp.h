@@ -26,71 +26,130 @@ __host__ __device__ inline int cpl_class(i64 W)
     return 0;
 }
 
-enum { DP_START_TRY = 0, DP_START_RETRY = 1, DP_MAIN = 2 };
+enum { DP_START_TRY = 0, DP_START_RETRY = 1, DP_MAIN = 2, DP_DIRECT = 3 };
 
-template <int CPL>
+// one forward pass described explicitly (per-kernel C ABI entry points, tba_c_*): same row
+// engine, geometry taken from here instead of ReadState
+struct DpJob {
+    i64 W, n_rows, row0, n_static, n_ev;
+    const double *ev, *mu, *sd;   // event means, per-row level mean / sd (unused with zmat)
+    const double *zmat;           // precomputed shifted z-scores [n_rows][W] or NULL
+    i64 *starts;                  // band starts [n_rows] (static rows in, adaptive rows out)
+    const double *init_row;       // forward row `row0` [W] or NULL (zeros)
+    double *fwd_out;              // all forward rows [(n_rows+1)][W] or NULL
+    unsigned char *mv;            // moves, rows of 64*CPL bytes
+    double z_shift, skip_pen, stay_pen, max_half_z, fill;
+    i32 winsor, status;
+    i64 top_pos;
+};
+
+template <int CPL, bool DIRECT>
 __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
     i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,
-    unsigned char *moves, i64 start_moves_stride, double *last_row)
+    unsigned char *moves, i64 start_moves_stride, double *last_row, DpJob *job)
 {
     __shared__ double rows[2][CPL * 64];
-    ReadState &r = rs[blockIdx.x];
-    if (r.status != TBA_OK) return;
+    ReadState &r = rs[DIRECT ? 0 : blockIdx.x];
+    if (!DIRECT && r.status != TBA_OK) return;
     const tba_params &P = dp->p;
     const int lane = threadIdx.x;
 
-    i64 W, n_rows, n_static, n_ev, ev_base;
+    i64 W, n_rows, n_static, n_ev, row0 = 0;
     bool identity;
     unsigned char *mv;
-    if (mode == DP_MAIN) {
-        if (r.path == PATH_NONE) return;
-        W = r.W;
-        if (cpl_class(W) != CPL) return;
-        n_rows = r.B;
-        n_static = r.n_static;
-        ev_base = r.ev_off + r.clip;
-        n_ev = r.n_ev - r.clip;
+    const double *ev, *rmu, *rsd, *zmat = nullptr;
+    i64 *bst;
+    const i32 *lo_a = lo_arr, *hi_a = hi_arr;
+    double stay_pen, skip_pen, z_shift, max_half_z, fill_masked;
+    bool winsor;
+    if constexpr (DIRECT) {
+        W = job->W; n_rows = job->n_rows; n_static = job->n_static; n_ev = job->n_ev;
+        row0 = job->row0;
         identity = false;
-        mv = moves + r.moves_off;
+        mv = job->mv;
+        ev = job->ev; rmu = job->mu; rsd = job->sd; zmat = job->zmat; bst = job->starts;
+        stay_pen = job->stay_pen; skip_pen = job->skip_pen; z_shift = job->z_shift;
+        max_half_z = job->max_half_z; fill_masked = job->fill; winsor = job->winsor != 0;
     } else {
-        if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
-        W = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
-        n_rows = P.start_n_bases;
-        n_static = n_rows;
-        ev_base = r.ev_off;
-        n_ev = r.n_ev;
-        identity = true;
-        mv = moves + (i64)blockIdx.x * start_moves_stride;
+        i64 ev_base;
+        if (mode == DP_MAIN) {
+            if (r.path == PATH_NONE) return;
+            W = r.W;
+            if (cpl_class(W) != CPL) return;
+            n_rows = r.B;
+            n_static = r.n_static;
+            ev_base = r.ev_off + r.clip;
+            n_ev = r.n_ev - r.clip;
+            identity = false;
+            mv = moves + r.moves_off;
+        } else {
+            if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
+            W = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
+            n_rows = P.start_n_bases;
+            n_static = n_rows;
+            ev_base = r.ev_off;
+            n_ev = r.n_ev;
+            identity = true;
+            mv = moves + (i64)blockIdx.x * start_moves_stride;
+        }
+        ev = event_means + ev_base;
+        rmu = ref_means + r.ref_off;
+        rsd = ref_sds + r.ref_off;
+        bst = band_starts + r.ref_off;
+        lo_a = lo_arr + r.ref_off;
+        hi_a = hi_arr + r.ref_off;
+        stay_pen = P.stay_pen; skip_pen = P.skip_pen; z_shift = P.z_shift;
+        max_half_z = P.max_half_z_score;
+        winsor = P.do_winsorize_z != 0;
+        fill_masked = dp->fill_masked;
     }
-    const double *ev = event_means + ev_base;
-    const double *rmu = ref_means + r.ref_off;
-    const double *rsd = ref_sds + r.ref_off;
-    i64 *bst = band_starts + r.ref_off;
-    const i32 *lo_a = lo_arr + r.ref_off;
-    const i32 *hi_a = hi_arr + r.ref_off;
-    const double stay_pen = P.stay_pen, skip_pen = P.skip_pen, z_shift = P.z_shift;
-    const double max_half_z = P.max_half_z_score;
-    const bool winsor = P.do_winsorize_z != 0;
-    const double fill_masked = dp->fill_masked;
     const i64 half_bw = W / 2; // integer division, pyx:327
     const double NEG_INF = -INFINITY;
     const i64 mv_stride = (i64)CPL * 64;
 
     double *prev = rows[0], *cur = rows[1];
-#pragma unroll
-    for (int j = 0; j < CPL; j++) prev[j * 64 + lane] = 0.0; // row 0: zeros (pyx:253-254)
-    __syncthreads();
-
     i64 prev_start = 0;
     i64 am = 0; // argmax of the previous row (row 0: all zeros -> 0)
+    if (DIRECT && job->init_row != nullptr) {
+        // resume from a given forward row (c_adaptive_banded_forward_pass is handed rows
+        // 0..start_seq_pos): load it, take its argmax
+        double lmax = NEG_INF;
+        i64 lidx = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const i64 b = (i64)lane * CPL + j;
+            double x = b < W ? job->init_row[b] : 0.0;
+            prev[j * 64 + lane] = x;
+            if (b < W && x > lmax) { lmax = x; lidx = b; }
+        }
+        double wm = lmax;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { double t = shfl_xor_f64(wm, o); wm = t > wm ? t : wm; }
+        u64 eq = __ballot(lmax == wm && (i64)lane * CPL < W);
+        am = shfl_i64(lidx, __ffsll((unsigned long long)eq) - 1);
+        if (row0 > 0) prev_start = bst[row0 - 1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPL; j++) prev[j * 64 + lane] = 0.0; // row 0: zeros (pyx:253-254)
+    }
+    __syncthreads();
+    if (DIRECT && job->fwd_out != nullptr && row0 == 0) {
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const i64 b = (i64)lane * CPL + j;
+            if (b < W) job->fwd_out[b] = 0.0;
+        }
+    }
+
     double v[CPL];
-    for (i64 row = 0; row < n_rows; row++) {
+    for (i64 row = row0; row < n_rows; row++) {
         i64 cur_start;
         i64 lo, hi;
         double fill;
         if (row < n_static) {
             if (identity) { cur_start = row; lo = 0; hi = W; }
+            else if (DIRECT) { cur_start = bst[row]; lo = 0; hi = W; }
             else { cur_start = bst[row]; lo = lo_a[row]; hi = hi_a[row]; }
             fill = fill_masked;
         } else {
@@ -99,7 +158,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             if (cur_start < prev_start) cur_start = prev_start;
             if (cur_start >= n_ev) {
                 if (row < n_rows - 2) {
-                    if (lane == 0) r.status = TBA_ADAPT_BEYOND;
+                    if (lane == 0) { if (DIRECT) job->status = TBA_ADAPT_BEYOND; else r.status = TBA_ADAPT_BEYOND; }
                     return;
                 }
                 cur_start = n_ev - 1;
@@ -107,10 +166,11 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             if (lane == 0) bst[row] = cur_start;
             lo = 0;
             hi = cur_start + W <= n_ev ? W : n_ev - cur_start;
-            fill = MASK_FILL_Z_SCORE; // literal, pyx:385-386
+            fill = DIRECT ? fill_masked : MASK_FILL_Z_SCORE; // literal -15, pyx:385-386
         }
         const i64 diff = row > 0 ? cur_start - prev_start : 0;
-        const double mu = rmu[row], sd = rsd[row];
+        double mu = 0, sd = 1;
+        if (!DIRECT || zmat == nullptr) { mu = rmu[row]; sd = rsd[row]; }
 
         // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720)
         double z[CPL], cv[CPL];
@@ -122,7 +182,9 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             const i64 b = (i64)lane * CPL + j;
             double zz = 0.0;
             if (b < W) { // cells past the band: z = 0, candidate = -inf (never read back)
-                if (b >= lo && b < hi) {
+                if (DIRECT && zmat != nullptr) {
+                    zz = zmat[row * W + b];
+                } else if (b >= lo && b < hi) {
                     double pz = (ev[cur_start + b] - mu) / sd;
                     pz = fabs(pz);
                     if (winsor) pz = max_half_z < pz ? max_half_z : pz;
@@ -184,7 +246,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             in = nin;
         }
         if (!converged) { // only reachable with NaNs in the signal
-            if (lane == 0) r.status = TBA_INTERNAL;
+            if (lane == 0) { if (DIRECT) job->status = TBA_INTERNAL; else r.status = TBA_INTERNAL; }
             return;
         }
         // move codes (0 stay, 1 skip, 2 diag; pyx:216-231), lane-local argmax (pyx:186-197)
@@ -210,6 +272,13 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         for (int q = 0; q < CPL / 4; q++) ((u32 *)mrow)[q] = mvw[q];
 #pragma unroll
         for (int j = 0; j < CPL; j++) cur[j * 64 + lane] = v[j];
+        if (DIRECT && job->fwd_out != nullptr) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                const i64 b = (i64)lane * CPL + j;
+                if (b < W) job->fwd_out[(row + 1) * W + b] = v[j];
+            }
+        }
         // wave argmax, first index among equal maxima
         double wm = lmax;
 #pragma unroll
@@ -225,13 +294,17 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         double *t = prev; prev = cur; cur = t;
     }
     // last row + traceback start (np.argmax of the last row, resquiggle.py:728,1032)
-    double *lr = last_row + (i64)blockIdx.x * TBA_MAX_BAND;
+    if constexpr (DIRECT) {
+        if (lane == 0) job->top_pos = am;
+    } else {
+        double *lr = last_row + (i64)blockIdx.x * TBA_MAX_BAND;
 #pragma unroll
-    for (int j = 0; j < CPL; j++) {
-        const i64 b = (i64)lane * CPL + j;
-        if (b < W) lr[b] = prev[j * 64 + lane];
+        for (int j = 0; j < CPL; j++) {
+            const i64 b = (i64)lane * CPL + j;
+            if (b < W) lr[b] = prev[j * 64 + lane];
+        }
+        if (lane == 0) r.top_pos = am;
     }
-    if (lane == 0) r.top_pos = am;
 }
 
 // c_banded_traceback (pyx:281-310) on byte moves with padded row stride; python wrap-around

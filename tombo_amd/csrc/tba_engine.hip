@@ -6,6 +6,7 @@
 #include "k_segment.h"
 #include "k_dp.h"
 #include "k_tail.h"
+#include "k_cabi.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -270,12 +271,12 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
 template <int CPL>
 static void launch_dp_t(tba_engine *e, int mode)
 {
-    k_dp<CPL><<<dim3((unsigned)e->n_reads), dim3(64), 0, e->stream>>>(
+    k_dp<CPL, false><<<dim3((unsigned)e->n_reads), dim3(64), 0, e->stream>>>(
         e->d_rs.as<ReadState>(), e->d_dp.as<DevParams>(), mode, e->d_evm.as<double>(),
         e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), e->d_lo.as<i32>(),
         e->d_hi.as<i32>(),
         mode == DP_MAIN ? e->d_moves.as<unsigned char>() : e->d_smoves.as<unsigned char>(),
-        e->start_moves_stride, e->d_lastrow.as<double>());
+        e->start_moves_stride, e->d_lastrow.as<double>(), nullptr);
 }
 static void launch_dp(tba_engine *e, int cpl, int mode)
 {
@@ -480,3 +481,264 @@ extern "C" int tba_batch_stats(tba_engine *e, double *algorithmic_bytes, double 
 }
 
 extern "C" const char *tba_stage_name(int i) { return i >= 0 && i < N_STAGE ? STAGE_NAMES[i] : ""; }
+
+// ---------------------------------------------------------------------------------------------
+// per-kernel entry points (tba_c_*): host buffers in, host buffers out, batch of one
+namespace {
+struct Tmp { // scoped device allocation
+    void *p = nullptr;
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : 1; }
+    ~Tmp() { if (p) (void)hipFree(p); }
+    template <class T> T *as() { return (T *)p; }
+};
+#define C_TRY(expr) HIP_TRY(expr)
+static unsigned grid_for(i64 n) { return (unsigned)std::min<i64>(std::max<i64>((n + 255) / 256, 1), 4096); }
+
+template <int CPL>
+static void launch_direct_t(tba_engine *e, DpJob *job)
+{
+    k_dp<CPL, true><<<dim3(1), dim3(64), 0, e->stream>>>(
+        e->d_rs.as<ReadState>(), e->d_dp.as<DevParams>(), DP_DIRECT, nullptr, nullptr, nullptr,
+        nullptr, nullptr, nullptr, nullptr, 0, nullptr, job);
+}
+static void launch_direct(tba_engine *e, int cpl, DpJob *job)
+{
+    switch (cpl) {
+    case 4: launch_direct_t<4>(e, job); break;
+    case 8: launch_direct_t<8>(e, job); break;
+    case 12: launch_direct_t<12>(e, job); break;
+    case 16: launch_direct_t<16>(e, job); break;
+    case 24: launch_direct_t<24>(e, job); break;
+    case 32: launch_direct_t<32>(e, job); break;
+    case 48: launch_direct_t<48>(e, job); break;
+    default: break;
+    }
+}
+
+// shared by the two forward-pass entry points
+static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i64 row0,
+                         double *fwd_host, int64_t *tb_host, int64_t *starts_host, i64 starts_from)
+{
+    const i64 stride = (i64)cpl * 64;
+    Tmp d_fwd, d_mv, d_job;
+    if (d_fwd.alloc((size_t)(n_rows + 1) * W * 8) || d_mv.alloc((size_t)(n_rows + 1) * stride) ||
+        d_job.alloc(sizeof(DpJob)))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    // the kernel needs *some* ReadState / DevParams to bind its references to
+    if (e->d_rs.ensure(sizeof(ReadState)) || e->d_dp.ensure(sizeof(DevParams))) return TBA_E_NOMEM;
+    hj.fwd_out = d_fwd.as<double>();
+    hj.mv = d_mv.as<unsigned char>();
+    hj.status = TBA_OK;
+    C_TRY(hipMemcpyAsync(d_job.p, &hj, sizeof(DpJob), hipMemcpyHostToDevice, e->stream));
+    launch_direct(e, cpl, d_job.as<DpJob>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipMemcpyAsync(&hj, d_job.p, sizeof(DpJob), hipMemcpyDeviceToHost, e->stream));
+    std::vector<unsigned char> mv((size_t)(n_rows + 1) * stride);
+    C_TRY(hipMemcpyAsync(mv.data(), d_mv.p, mv.size(), hipMemcpyDeviceToHost, e->stream));
+    C_TRY(hipStreamSynchronize(e->stream));
+    if (hj.status != TBA_OK) return hj.status;
+    // rows row0+1 .. n_rows are new
+    C_TRY(hipMemcpy(fwd_host + (row0 + (row0 == 0 ? 0 : 1)) * W,
+                    d_fwd.as<double>() + (row0 + (row0 == 0 ? 0 : 1)) * W,
+                    (size_t)(n_rows + 1 - row0 - (row0 == 0 ? 0 : 1)) * W * 8, hipMemcpyDeviceToHost));
+    for (i64 r = row0 + 1; r <= n_rows; r++)
+        for (i64 b = 0; b < W; b++) tb_host[r * W + b] = mv[(size_t)(r * stride + b)];
+    if (starts_host)
+        C_TRY(hipMemcpy(starts_host + starts_from, hj.starts + starts_from,
+                        (size_t)(n_rows - starts_from) * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+} // namespace
+
+extern "C" int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pass,
+    int64_t *fwd_pass_tb, int64_t n_bases, int64_t bandwidth, int64_t *event_starts,
+    const double *event_means, int64_t n_events, const double *r_ref_means,
+    const double *r_ref_sds, double z_shift, double skip_pen, double stay_pen,
+    int64_t start_seq_pos, double mask_fill_z_score, int do_winsorize_z, double max_half_z_score)
+{
+    if (!e || !fwd_pass || !fwd_pass_tb || !event_starts || !event_means || !r_ref_means ||
+        !r_ref_sds || n_bases < 1 || bandwidth < 2 || start_seq_pos < 1 || start_seq_pos > n_bases)
+        return set_err(TBA_E_ARG, "bad arguments");
+    const int cpl = cpl_class(bandwidth);
+    if (!cpl) return TBA_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_ev, d_mu, d_sd, d_st, d_init;
+    if (d_ev.alloc((size_t)n_events * 8) || d_mu.alloc((size_t)n_bases * 8) ||
+        d_sd.alloc((size_t)n_bases * 8) || d_st.alloc((size_t)n_bases * 8) ||
+        d_init.alloc((size_t)bandwidth * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_ev.p, event_means, (size_t)n_events * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_mu.p, r_ref_means, (size_t)n_bases * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_sd.p, r_ref_sds, (size_t)n_bases * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_st.p, event_starts, (size_t)n_bases * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_init.p, fwd_pass + start_seq_pos * bandwidth, (size_t)bandwidth * 8, hipMemcpyHostToDevice));
+    DpJob j;
+    memset(&j, 0, sizeof(j));
+    j.W = bandwidth; j.n_rows = n_bases; j.row0 = start_seq_pos; j.n_static = start_seq_pos;
+    j.n_ev = n_events; j.ev = d_ev.as<double>(); j.mu = d_mu.as<double>(); j.sd = d_sd.as<double>();
+    j.zmat = nullptr; j.starts = d_st.as<i64>(); j.init_row = d_init.as<double>();
+    j.z_shift = z_shift; j.skip_pen = skip_pen; j.stay_pen = stay_pen; j.max_half_z = max_half_z_score;
+    j.fill = mask_fill_z_score; j.winsor = do_winsorize_z ? 1 : 0;
+    return run_direct_dp(e, j, cpl, n_bases, bandwidth, start_seq_pos, fwd_pass, fwd_pass_tb,
+                         event_starts, start_seq_pos);
+}
+
+extern "C" int tba_c_banded_forward_pass(tba_engine *e, const double *shifted_z_scores,
+    int64_t n_bases, int64_t bandwidth, const int64_t *event_starts, double skip_pen,
+    double stay_pen, double *fwd_pass, int64_t *fwd_pass_tb)
+{
+    if (!e || !shifted_z_scores || !event_starts || !fwd_pass || !fwd_pass_tb || n_bases < 1 ||
+        bandwidth < 2)
+        return set_err(TBA_E_ARG, "bad arguments");
+    const int cpl = cpl_class(bandwidth);
+    if (!cpl) return TBA_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_z, d_st;
+    if (d_z.alloc((size_t)n_bases * bandwidth * 8) || d_st.alloc((size_t)n_bases * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_z.p, shifted_z_scores, (size_t)n_bases * bandwidth * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_st.p, event_starts, (size_t)n_bases * 8, hipMemcpyHostToDevice));
+    DpJob j;
+    memset(&j, 0, sizeof(j));
+    j.W = bandwidth; j.n_rows = n_bases; j.row0 = 0; j.n_static = n_bases; j.n_ev = 0;
+    j.zmat = d_z.as<double>(); j.starts = d_st.as<i64>(); j.init_row = nullptr;
+    j.skip_pen = skip_pen; j.stay_pen = stay_pen;
+    int rc = run_direct_dp(e, j, cpl, n_bases, bandwidth, 0, fwd_pass, fwd_pass_tb, nullptr, 0);
+    if (rc == TBA_OK) // row 0 of the move matrix is never read; the reference leaves it empty
+        for (i64 b = 0; b < bandwidth; b++) fwd_pass_tb[b] = 0;
+    return rc;
+}
+
+extern "C" int tba_c_banded_traceback(tba_engine *e, const int64_t *fwd_pass_tb, int64_t n_bases,
+    int64_t bandwidth, const int64_t *event_starts, int64_t band_pos,
+    int64_t band_boundary_thresh, int64_t *seq_poss)
+{
+    if (!e || !fwd_pass_tb || !event_starts || !seq_poss || n_bases < 1 || bandwidth < 1 ||
+        band_pos < 0 || band_pos >= bandwidth)
+        return set_err(TBA_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t cells = (size_t)(n_bases + 1) * bandwidth;
+    std::vector<unsigned char> mv(cells);
+    for (size_t i = 0; i < cells; i++) mv[i] = (unsigned char)fwd_pass_tb[i];
+    Tmp d_mv, d_st, d_out, d_status;
+    if (d_mv.alloc(cells) || d_st.alloc((size_t)n_bases * 8) || d_out.alloc((size_t)(n_bases + 1) * 8) ||
+        d_status.alloc(4))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_mv.p, mv.data(), cells, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_st.p, event_starts, (size_t)n_bases * 8, hipMemcpyHostToDevice));
+    k_c_traceback<<<1, 64, 0, e->stream>>>(d_mv.as<unsigned char>(), bandwidth, n_bases, bandwidth,
+                                           d_st.as<i64>(), band_pos, band_boundary_thresh,
+                                           d_out.as<i64>(), d_status.as<i32>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    i32 st = 0;
+    C_TRY(hipMemcpy(&st, d_status.p, 4, hipMemcpyDeviceToHost));
+    if (st == TBA_OK) C_TRY(hipMemcpy(seq_poss, d_out.p, (size_t)(n_bases + 1) * 8, hipMemcpyDeviceToHost));
+    return st;
+}
+
+extern "C" int tba_c_base_z_scores(tba_engine *e, const double *b_sig, int64_t n, double ref_mean,
+    double ref_sd, int do_winsorize_z, double max_half_z_score, double *out)
+{
+    if (!e || !b_sig || !out || n < 0) return set_err(TBA_E_ARG, "bad arguments");
+    if (n == 0) return TBA_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_in, d_out;
+    if (d_in.alloc((size_t)n * 8) || d_out.alloc((size_t)n * 8)) return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_in.p, b_sig, (size_t)n * 8, hipMemcpyHostToDevice));
+    k_c_base_z_scores<<<grid_for(n), 256, 0, e->stream>>>(d_in.as<double>(), n, ref_mean, ref_sd,
+                                                          do_winsorize_z, max_half_z_score, d_out.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+extern "C" int tba_c_new_means(tba_engine *e, const double *norm_signal, int64_t n_sig,
+    const int64_t *new_segs, int64_t n_segs, double *means)
+{
+    if (!e || !norm_signal || !new_segs || !means || n_segs < 0 || n_sig < 0)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (n_segs == 0) return TBA_OK;
+    for (i64 i = 0; i <= n_segs; i++)
+        if (new_segs[i] < 0 || new_segs[i] > n_sig || (i > 0 && new_segs[i] < new_segs[i - 1]))
+            return set_err(TBA_E_ARG, "segment boundaries outside the signal");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_sig, d_segs, d_out;
+    if (d_sig.alloc((size_t)n_sig * 8) || d_segs.alloc((size_t)(n_segs + 1) * 8) || d_out.alloc((size_t)n_segs * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_sig.p, norm_signal, (size_t)n_sig * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_segs.p, new_segs, (size_t)(n_segs + 1) * 8, hipMemcpyHostToDevice));
+    k_c_new_means<<<grid_for(n_segs), 256, 0, e->stream>>>(d_sig.as<double>(), d_segs.as<i64>(), n_segs, d_out.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(means, d_out.p, (size_t)n_segs * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+extern "C" int tba_c_apply_outlier_thresh(tba_engine *e, const double *sig, int64_t n,
+    double lower_lim, double upper_lim, double *out)
+{
+    if (!e || !sig || !out || n < 0) return set_err(TBA_E_ARG, "bad arguments");
+    if (n == 0) return TBA_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_in, d_out;
+    if (d_in.alloc((size_t)n * 8) || d_out.alloc((size_t)n * 8)) return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_in.p, sig, (size_t)n * 8, hipMemcpyHostToDevice));
+    k_c_clip<<<grid_for(n), 256, 0, e->stream>>>(d_in.as<double>(), n, lower_lim, upper_lim, d_out.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+// the two change-point detectors run the batch kernels on a one-read batch
+static int c_valid_cpts(tba_engine *e, const double *sig, int64_t n, int64_t min_base_obs,
+                        int64_t width, int64_t num_cpts, int64_t *cpts, int ttest)
+{
+    if (!e || !sig || !cpts || n < 1 || min_base_obs < 1 || width < 1 || num_cpts < 1)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if ((ttest ? n - 2 * width : n + 1 - 2 * width) <= 0) return TBA_INTERNAL;
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_sig, d_csum, d_score, d_state, d_cpts, d_rs, d_dp;
+    if (d_sig.alloc((size_t)n * 8) || d_csum.alloc((size_t)(n + 1) * 8) || d_score.alloc((size_t)n * 8) ||
+        d_state.alloc((size_t)n) || d_cpts.alloc((size_t)num_cpts * 8) || d_rs.alloc(sizeof(ReadState)) ||
+        d_dp.alloc(sizeof(DevParams)))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    ReadState r;
+    memset(&r, 0, sizeof(r));
+    r.n_raw = n; r.num_events = num_cpts; r.status = TBA_OK;
+    DevParams dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.p.running_stat_width = width; dp.p.min_obs_per_base = min_base_obs;
+    C_TRY(hipMemcpy(d_sig.p, sig, (size_t)n * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_rs.p, &r, sizeof(r), hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_dp.p, &dp, sizeof(dp), hipMemcpyHostToDevice));
+    hipStream_t s = e->stream;
+    const unsigned g = grid_for(n) > 128 ? 128 : grid_for(n);
+    if (!ttest) {
+        k_cumsum<<<1, 64, 0, s>>>(d_rs.as<ReadState>(), 1, d_sig.as<double>(), d_csum.as<double>());
+        k_scores_dna<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_csum.as<double>(), d_score.as<double>());
+    } else {
+        k_scores_ttest<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
+    }
+    k_peaks<<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_score.as<double>(),
+                                 d_state.as<unsigned char>(), d_cpts.as<i64>(), ttest);
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(s));
+    C_TRY(hipMemcpy(&r, d_rs.p, sizeof(r), hipMemcpyDeviceToHost));
+    if (r.status == TBA_OK) C_TRY(hipMemcpy(cpts, d_cpts.p, (size_t)num_cpts * 8, hipMemcpyDeviceToHost));
+    return r.status;
+}
+
+extern "C" int tba_c_valid_cpts_w_cap(tba_engine *e, const double *sig, int64_t n,
+    int64_t min_base_obs, int64_t running_stat_width, int64_t num_cpts, int64_t *cpts)
+{
+    return c_valid_cpts(e, sig, n, min_base_obs, running_stat_width, num_cpts, cpts, 0);
+}
+
+extern "C" int tba_c_valid_cpts_w_cap_t_test(tba_engine *e, const double *sig, int64_t n,
+    int64_t min_base_obs, int64_t running_stat_width, int64_t num_cpts, int64_t *cpts)
+{
+    return c_valid_cpts(e, sig, n, min_base_obs, running_stat_width, num_cpts, cpts, 1);
+}
