@@ -98,8 +98,17 @@ def test_forward_pass_and_traceback_kernels(read):
     np.testing.assert_array_equal(st_a, o_st)
     np.testing.assert_array_equal(fwd_a, o_fwd)
     np.testing.assert_array_equal(tb_a[1:], o_tb[1:].astype(np.int64))
-    # band runs off the end of the events: the reference's error
+    # band start pushed past the last event (argmax at the right edge of a row that already sits
+    # at the end of the events): the reference's error, pyx:349-357
+    fwd_b, tb_b, st_b = fwd_a.copy(), tb_a.copy(), st_a.copy()
+    fwd_b[nb] = np.arange(bw, dtype=np.float64)
+    st_b[nb - 1] = ev.shape[0] - 10
+    o_fwd, o_tb, o_st = fwd_b.copy(), tb_b.astype(np.int8), st_b.copy()
+    rc = oracle.adaptive_banded_forward_pass(o_fwd, o_tb, o_st, ev, mu[:n_bases], sd[:n_bases],
+                                             p.z_shift, p.skip_pen, p.stay_pen, nb, -15.0, True,
+                                             p.max_half_z_score)
+    assert rc == 10
     with pytest.raises(NotImplementedError, match='extended beyond raw signal'):
         cdp.c_adaptive_banded_forward_pass(
-            fwd_a, tb_a, st_a, ev[:400], mu[:n_bases], sd[:n_bases], p.z_shift, p.skip_pen,
+            fwd_b, tb_b, st_b, ev, mu[:n_bases], sd[:n_bases], p.z_shift, p.skip_pen,
             p.stay_pen, nb, -15.0, True, p.max_half_z_score)
