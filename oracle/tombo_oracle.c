@@ -560,7 +560,7 @@ static int orc_find_seq_start_in_events(const double *event_means, i64 n_ev,
 /* rq.find_static_base_assignment, resquiggle.py:547-600 */
 static int orc_find_static_base_assignment(const double *event_means, i64 n_ev,
     const double *ref_means, const double *ref_sds, i64 seq_len, const orc_params *p,
-    i64 *read_tb)
+    i64 *read_tb, orc_debug *dbg)
 {
     i64 mask_len = imin(seq_len, n_ev) / 4;
     i64 bw = n_ev - mask_len;
@@ -579,6 +579,13 @@ static int orc_find_static_base_assignment(const double *event_means, i64 n_ev,
     int8_t *tb = (int8_t *)malloc((size_t)((seq_len + 1) * bw));
     orc_banded_forward_pass(z, seq_len, bw, starts, p->skip_pen, p->stay_pen, fwd, tb);
     i64 top = orc_argmax(fwd + seq_len * bw, bw);
+    if (dbg) {
+        if (dbg->band_event_starts) memcpy(dbg->band_event_starts, starts, sizeof(i64) * (size_t)seq_len);
+        if (dbg->fwd_last_row) {
+            memcpy(dbg->fwd_last_row, fwd + seq_len * bw, sizeof(double) * (size_t)bw);
+            dbg->fwd_last_row_len = bw;
+        }
+    }
     int rc = orc_banded_traceback(tb, seq_len, bw, starts, top, -1, read_tb);
     free(z); free(fwd); free(tb); free(starts);
     return rc;
@@ -742,7 +749,7 @@ static int orc_find_adaptive_base_assignment(const i64 *valid_cpts, const double
     if (use_static) {
         clip = 0;
         rc = orc_find_static_base_assignment(event_means, n_ev, ref_means, ref_sds, seq_len, p,
-                                             read_tb);
+                                             read_tb, dbg);
         if (rc != ORC_OK) { free(read_tb); return rc; }
         for (i64 i = 0; i <= seq_len; i++)
             if (read_tb[i] < -(n_ev + 1) || read_tb[i] > n_ev) { free(read_tb); return ORC_INTERNAL; }

@@ -86,8 +86,10 @@ def compare_batch(eng, oracles, out, label=''):
             s0, s1 = eng.seg_off[i], eng.seg_off[i + 1]
             if not d['used_static']:
                 chk(i, 'mask_seq_len', path[i, 1], d['mask_seq_len'])
-                chk(i, 'band_starts', bst[r0:r1], d['band_event_starts'])
-                chk(i, 'last_row', lastrow[i, :len(d['fwd_last_row'])], d['fwd_last_row'])
+            else:
+                chk(i, 'static_W', path[i, 2], len(d['fwd_last_row']))
+            chk(i, 'band_starts', bst[r0:r1], d['band_event_starts'])
+            chk(i, 'last_row', lastrow[i, :len(d['fwd_last_row'])], d['fwd_last_row'])
             chk(i, 'read_tb', rtb[s0:s1], d['read_tb'])
             chk(i, 'dp_segs', dps[s0:s1], d['dp_segs'])
             chk(i, 'dp_read_start', dprs[i], d['dp_read_start'])

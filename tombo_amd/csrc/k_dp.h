@@ -43,6 +43,39 @@ struct DpJob {
     i64 top_pos;
 };
 
+// wave-level helpers on the DPP crossbar (no LDS round trip): lane i <- lane i-1, and a full
+// wave max (quad_perm / row_ror / row_bcast ladder, result broadcast from lane 63)
+__device__ __forceinline__ double wave_shr1_f64(double x, double lane0_val)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(lane0_val), lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0_val), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+    double t;
+    t = dpp_mov_f64<0xb1, 0xf>(v); v = t > v ? t : v;   // quad_perm:[1,0,3,2]
+    t = dpp_mov_f64<0x4e, 0xf>(v); v = t > v ? t : v;   // quad_perm:[2,3,0,1]
+    t = dpp_mov_f64<0x124, 0xf>(v); v = t > v ? t : v;  // row_ror:4
+    t = dpp_mov_f64<0x128, 0xf>(v); v = t > v ? t : v;  // row_ror:8
+    t = dpp_mov_f64<0x142, 0xa>(v); v = t > v ? t : v;  // row_bcast:15 -> rows 1,3
+    t = dpp_mov_f64<0x143, 0xc>(v); v = t > v ? t : v;  // row_bcast:31 -> rows 2,3
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// Row body is straight-line code (selects, clamped loads): the only branches are wave-uniform
+// (static vs adaptive row, sweep loop).
 template <int CPL, bool DIRECT>
 __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
@@ -104,9 +137,13 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         winsor = P.do_winsorize_z != 0;
         fill_masked = dp->fill_masked;
     }
+    const int Wi = (int)W;
     const i64 half_bw = W / 2; // integer division, pyx:327
     const double NEG_INF = -INFINITY;
     const i64 mv_stride = (i64)CPL * 64;
+    const int b0 = lane * CPL;   // my first band cell
+    // without winsorising the clamp value is +inf (no effect)
+    const double zcap = winsor ? max_half_z : INFINITY;
 
     double *prev = rows[0], *cur = rows[1];
     i64 prev_start = 0;
@@ -115,19 +152,21 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         // resume from a given forward row (c_adaptive_banded_forward_pass is handed rows
         // 0..start_seq_pos): load it, take its argmax
         double lmax = NEG_INF;
-        i64 lidx = 0;
+        int lidx = 0;
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
-            const i64 b = (i64)lane * CPL + j;
-            double x = b < W ? job->init_row[b] : 0.0;
+            const int b = b0 + j;
+            const bool valid = b < Wi;
+            double x = job->init_row[valid ? b : Wi - 1];
+            x = valid ? x : 0.0;
             prev[j * 64 + lane] = x;
-            if (b < W && x > lmax) { lmax = x; lidx = b; }
+            const bool better = valid && x > lmax;
+            lmax = better ? x : lmax;
+            lidx = better ? b : lidx;
         }
-        double wm = lmax;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { double t = shfl_xor_f64(wm, o); wm = t > wm ? t : wm; }
-        u64 eq = __ballot(lmax == wm && (i64)lane * CPL < W);
-        am = shfl_i64(lidx, __ffsll((unsigned long long)eq) - 1);
+        const double wm = wave_max_f64(lmax);
+        u64 eq = __ballot(lmax == wm && b0 < Wi);
+        am = __shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64);
         if (row0 > 0) prev_start = bst[row0 - 1];
     } else {
 #pragma unroll
@@ -136,20 +175,17 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     __syncthreads();
     if (DIRECT && job->fwd_out != nullptr && row0 == 0) {
 #pragma unroll
-        for (int j = 0; j < CPL; j++) {
-            const i64 b = (i64)lane * CPL + j;
-            if (b < W) job->fwd_out[b] = 0.0;
-        }
+        for (int j = 0; j < CPL; j++) job->fwd_out[b0 + j] = 0.0; // rows padded to 64*CPL
     }
 
     double v[CPL];
     for (i64 row = row0; row < n_rows; row++) {
         i64 cur_start;
-        i64 lo, hi;
+        int lo, hi;
         double fill;
         if (row < n_static) {
-            if (identity) { cur_start = row; lo = 0; hi = W; }
-            else if (DIRECT) { cur_start = bst[row]; lo = 0; hi = W; }
+            if (identity) { cur_start = row; lo = 0; hi = Wi; }
+            else if (DIRECT) { cur_start = bst[row]; lo = 0; hi = Wi; }
             else { cur_start = bst[row]; lo = lo_a[row]; hi = hi_a[row]; }
             fill = fill_masked;
         } else {
@@ -165,70 +201,74 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             }
             if (lane == 0) bst[row] = cur_start;
             lo = 0;
-            hi = cur_start + W <= n_ev ? W : n_ev - cur_start;
+            hi = cur_start + W <= n_ev ? Wi : (int)(n_ev - cur_start);
             fill = DIRECT ? fill_masked : MASK_FILL_Z_SCORE; // literal -15, pyx:385-386
         }
-        const i64 diff = row > 0 ? cur_start - prev_start : 0;
+        const int diff_i = __builtin_amdgcn_readfirstlane((int)(row > 0 ? cur_start - prev_start : 0));
         double mu = 0, sd = 1;
         if (!DIRECT || zmat == nullptr) { mu = rmu[row]; sd = rsd[row]; }
 
-        // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720)
-        double z[CPL], cv[CPL];
+        // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720);
+        // loads are clamped into the event array, masked / overrun cells are selected afterwards
+        double z[CPL];
+        {
+            const i64 e_last = n_ev - 1;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                const int b = b0 + j;
+                double zz;
+                if (DIRECT && zmat != nullptr) {
+                    zz = zmat[row * W + (b < Wi ? b : Wi - 1)];
+                } else {
+                    i64 ei = cur_start + b;
+                    ei = ei < 0 ? 0 : (ei > e_last ? e_last : ei);
+                    double pz = fabs((ev[ei] - mu) / sd);
+                    pz = zcap < pz ? zcap : pz;
+                    zz = z_shift - pz;
+                    zz = (b >= lo && b < hi) ? zz : fill;
+                }
+                z[j] = b < Wi ? zz : 0.0; // cells past the band: z = 0, candidate = -inf
+            }
+        }
+        // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401.
+        // previous-row cell c = lane*CPL + t sits at LDS [(t mod CPL)*64 + lane + floor(t/CPL)];
+        // t is wave-uniform (scalar index math); lane + floor(t/CPL) is clamped into the row and
+        // out-of-band candidates are deselected.
+        double cv[CPL];
         u32 cfw[(CPL + 15) / 16];
 #pragma unroll
         for (int q = 0; q < (CPL + 15) / 16; q++) cfw[q] = 0;
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
-            const i64 b = (i64)lane * CPL + j;
-            double zz = 0.0;
-            if (b < W) { // cells past the band: z = 0, candidate = -inf (never read back)
-                if (DIRECT && zmat != nullptr) {
-                    zz = zmat[row * W + b];
-                } else if (b >= lo && b < hi) {
-                    double pz = (ev[cur_start + b] - mu) / sd;
-                    pz = fabs(pz);
-                    if (winsor) pz = max_half_z < pz ? max_half_z : pz;
-                    zz = z_shift - pz;
-                } else {
-                    zz = fill;
-                }
-            }
-            z[j] = zz;
-        }
-        // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401.
-        // previous-row cell c = lane*CPL + t sits at LDS [(t mod CPL)*64 + lane + floor(t/CPL)];
-        // t = j + diff - 1 is wave-uniform, so the index split is scalar work.
-        const int diff_i = __builtin_amdgcn_readfirstlane((int)diff);
-        const int Wi = (int)W;
-#pragma unroll
-        for (int j = 0; j < CPL; j++) {
-            const int b = lane * CPL + j;
+            const int b = b0 + j;
             const int t1 = j + diff_i - 1;           // >= -1
             const int q1 = t1 >= 0 ? t1 / CPL : -1;
             const int r1 = t1 - q1 * CPL;
             const int t2 = t1 + 1;
             const int q2 = t2 / CPL;
             const int r2 = t2 - q2 * CPL;
-            const int c1 = b + diff_i - 1;           // prev cell for the diagonal move
-            double c = NEG_INF;
-            u32 f = 0;
-            if (b < Wi) {
-                if (b == 0) {
-                    if (diff_i == 0) { c = prev[0] - skip_pen; f = 1; }
-                    else { c = prev[r1 * 64 + q1] + z[j]; f = 2; }
-                } else if (c1 < Wi) {
-                    double d = prev[r1 * 64 + lane + q1] + z[j];
-                    c = d; f = 2;
-                    if (c1 + 1 < Wi) {
-                        double s = prev[r2 * 64 + lane + q2] - skip_pen;
-                        if (s > d) { c = s; f = 1; }
-                    }
-                }
+            int l1 = lane + q1; l1 = l1 < 0 ? 0 : (l1 > 63 ? 63 : l1);
+            int l2 = lane + q2; l2 = l2 > 63 ? 63 : l2;
+            const double p1 = prev[r1 * 64 + l1];
+            const double p2 = prev[r2 * 64 + l2];
+            const int c1 = b + diff_i - 1;           // previous-row cell of the diagonal move
+            const double d = p1 + z[j];
+            const double s = p2 - skip_pen;
+            bool has_d = b < Wi && c1 < Wi;
+            bool has_s = has_d && c1 + 1 < Wi;
+            if (j == 0) { // band cell 0 (lane 0): skip only when the band did not move, else diag only
+                const bool first = lane == 0;
+                has_d = first ? diff_i != 0 : has_d;
+                has_s = first ? diff_i == 0 : has_s;
             }
+            const bool take_s = has_s && (!has_d || s > d);
+            double c = has_d ? d : NEG_INF;
+            c = take_s ? s : c;
+            const u32 f = take_s ? 1u : (has_d ? 2u : 0u);
             cv[j] = c;
             cfw[j / 16] |= f << (2 * (j % 16));
         }
-        // stay chain: monotone fixed-point sweeps
+        // stay chain: monotone fixed-point sweeps, chunk exit values shifted one lane up
         double in = NEG_INF;
         bool converged = false;
         for (int it = 0; it < 66; it++) { // <= 64 sweeps by induction over lanes (NaN-proof bound)
@@ -239,10 +279,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 x = cv[j] > s ? cv[j] : s;
                 v[j] = x;
             }
-            double nin = shfl_up_f64(x, 1);
-            if (lane == 0) nin = NEG_INF;
-            u64 ch = __ballot(nin != in);
-            if (ch == 0) { converged = true; break; }
+            const double nin = wave_shr1_f64(x, NEG_INF);
+            if (__ballot(nin != in) == 0) { converged = true; break; }
             in = nin;
         }
         if (!converged) { // only reachable with NaNs in the signal
@@ -254,41 +292,34 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
 #pragma unroll
         for (int q = 0; q < CPL / 4; q++) mvw[q] = 0;
         double lmax = NEG_INF;
-        i64 lidx = 0;
+        int lidx = 0;
         {
             double x = in;
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
-                const i64 b = (i64)lane * CPL + j;
+                const int b = b0 + j;
                 double s = (x - stay_pen) + z[j];
                 u32 f = cv[j] > s ? ((cfw[j / 16] >> (2 * (j % 16))) & 3u) : 0u;
                 mvw[j / 4] |= f << (8 * (j % 4));
                 x = v[j];
-                if (b < W && x > lmax) { lmax = x; lidx = b; }
+                const bool better = b < Wi && x > lmax;
+                lmax = better ? x : lmax;
+                lidx = better ? b : lidx;
             }
         }
-        unsigned char *mrow = mv + (row + 1) * mv_stride + (i64)lane * CPL;
+        unsigned char *mrow = mv + (row + 1) * mv_stride + b0;
 #pragma unroll
         for (int q = 0; q < CPL / 4; q++) ((u32 *)mrow)[q] = mvw[q];
 #pragma unroll
         for (int j = 0; j < CPL; j++) cur[j * 64 + lane] = v[j];
         if (DIRECT && job->fwd_out != nullptr) {
 #pragma unroll
-            for (int j = 0; j < CPL; j++) {
-                const i64 b = (i64)lane * CPL + j;
-                if (b < W) job->fwd_out[(row + 1) * W + b] = v[j];
-            }
+            for (int j = 0; j < CPL; j++) job->fwd_out[(row + 1) * mv_stride + b0 + j] = v[j];
         }
         // wave argmax, first index among equal maxima
-        double wm = lmax;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            double t = shfl_xor_f64(wm, o);
-            wm = t > wm ? t : wm;
-        }
-        u64 eq = __ballot(lmax == wm && (i64)lane * CPL < W);
-        int first = __ffsll((unsigned long long)eq) - 1;
-        am = shfl_i64(lidx, first);
+        const double wm = wave_max_f64(lmax);
+        u64 eq = __ballot(lmax == wm && b0 < Wi);
+        am = __shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64);
         prev_start = cur_start;
         __syncthreads();
         double *t = prev; prev = cur; cur = t;
@@ -297,12 +328,9 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     if constexpr (DIRECT) {
         if (lane == 0) job->top_pos = am;
     } else {
-        double *lr = last_row + (i64)blockIdx.x * TBA_MAX_BAND;
+        double *lr = last_row + (i64)blockIdx.x * TBA_MAX_BAND; // 64*CPL <= TBA_MAX_BAND
 #pragma unroll
-        for (int j = 0; j < CPL; j++) {
-            const i64 b = (i64)lane * CPL + j;
-            if (b < W) lr[b] = prev[j * 64 + lane];
-        }
+        for (int j = 0; j < CPL; j++) lr[b0 + j] = prev[j * 64 + lane];
         if (lane == 0) r.top_pos = am;
     }
 }

@@ -521,7 +521,7 @@ static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i6
 {
     const i64 stride = (i64)cpl * 64;
     Tmp d_fwd, d_mv, d_job;
-    if (d_fwd.alloc((size_t)(n_rows + 1) * W * 8) || d_mv.alloc((size_t)(n_rows + 1) * stride) ||
+    if (d_fwd.alloc((size_t)(n_rows + 1) * stride * 8) || d_mv.alloc((size_t)(n_rows + 1) * stride) ||
         d_job.alloc(sizeof(DpJob)))
         return set_err(TBA_E_NOMEM, "hipMalloc failed");
     // the kernel needs *some* ReadState / DevParams to bind its references to
@@ -537,10 +537,14 @@ static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i6
     C_TRY(hipMemcpyAsync(mv.data(), d_mv.p, mv.size(), hipMemcpyDeviceToHost, e->stream));
     C_TRY(hipStreamSynchronize(e->stream));
     if (hj.status != TBA_OK) return hj.status;
-    // rows row0+1 .. n_rows are new
-    C_TRY(hipMemcpy(fwd_host + (row0 + (row0 == 0 ? 0 : 1)) * W,
-                    d_fwd.as<double>() + (row0 + (row0 == 0 ? 0 : 1)) * W,
-                    (size_t)(n_rows + 1 - row0 - (row0 == 0 ? 0 : 1)) * W * 8, hipMemcpyDeviceToHost));
+    // rows row0+1 .. n_rows are new (row 0 too when starting from scratch); device rows are
+    // padded to the moves stride
+    {
+        std::vector<double> fw((size_t)(n_rows + 1) * stride);
+        C_TRY(hipMemcpy(fw.data(), d_fwd.p, fw.size() * 8, hipMemcpyDeviceToHost));
+        for (i64 r = row0 == 0 ? 0 : row0 + 1; r <= n_rows; r++)
+            memcpy(fwd_host + r * W, fw.data() + r * stride, (size_t)W * 8);
+    }
     for (i64 r = row0 + 1; r <= n_rows; r++)
         for (i64 b = 0; b < W; b++) tb_host[r * W + b] = mv[(size_t)(r * stride + b)];
     if (starts_host)
