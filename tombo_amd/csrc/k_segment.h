@@ -10,7 +10,7 @@
 __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevParams *dp,
     const double *raw, double *norm, const double *sv_in, int mode)
 {
-    __shared__ SelectSmem sm;
+    __shared__ BucketSmem sm;
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
     const int tid = threadIdx.x;
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
     double *y = norm + r.raw_off;
     const tba_opts &o = dp->o;
     double shift, scale, lo = 0, hi = 0;
+    double xlo = 0, xhi = 0, mn = 0, mx = 0; // middle order statistics / range of the raw signal
     bool have_lims = false, use_sv = false;
     if (r.sv_flags & 1) {
         use_sv = true;
@@ -29,17 +30,42 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         use_sv = true; // get_scale_values_from_events result, tombo_stats.py:217-233
         shift = r.shift; scale = r.scale; have_lims = true; lo = r.lower; hi = r.upper;
     } else {
-        shift = block_median([&](i64 i) { return f64_key(x[i]); }, n, &sm);
+        // range of the raw signal (one pass), then bucket-select medians (k_select.h)
+        mn = INFINITY; mx = -INFINITY;
+        for (i64 i = tid; i < n; i += SEL_NT) { double v = x[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+            double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
+            mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
+        }
+        if ((tid & 63) == 0) { sm.redd[2 * (tid >> 6)] = mn; sm.redd[2 * (tid >> 6) + 1] = mx; }
+        __syncthreads();
+        mn = sm.redd[0]; mx = sm.redd[1];
+        for (int w = 1; w < SEL_NT / 64; w++) {
+            mn = sm.redd[2 * w] < mn ? sm.redd[2 * w] : mn;
+            mx = sm.redd[2 * w + 1] > mx ? sm.redd[2 * w + 1] : mx;
+        }
+        __syncthreads();
+        shift = block_median_fast([&](i64 i) { return x[i]; }, n, mn, mx, &sm, &xlo, &xhi);
         if (o.has_const_scale) scale = o.const_scale;
-        else scale = block_median([&](i64 i) { return f64_key(fabs(x[i] - shift)); }, n, &sm);
+        else {
+            const double a = mx - shift, b2 = shift - mn;
+            scale = block_median_fast([&](i64 i) { return fabs(x[i] - shift); }, n, 0.0,
+                                      a > b2 ? a : b2, &sm);
+        }
     }
     for (i64 i = tid; i < n; i += SEL_NT) y[i] = (x[i] - shift) / scale;
     __syncthreads();
     // RNA with scale_values=None and no event scaling normalises without an outlier threshold
     bool thresh = !use_sv && o.has_outlier_thresh && !(mode == 1 && !o.has_const_scale);
     if (thresh) {
-        double med = block_median([&](i64 i) { return f64_key(y[i]); }, n, &sm);
-        double mad = block_median([&](i64 i) { return f64_key(fabs(y[i] - med)); }, n, &sm);
+        // np.median(norm): x -> (x - shift) / scale is monotone, so the middle order statistics of
+        // the normalised signal are the images of the raw ones found above (same two values the
+        // reference averages; for a negative const scale they swap places, the sum does not care)
+        const double ylo = (xlo - shift) / scale, yhi = (xhi - shift) / scale;
+        const double med = (n & 1) ? ylo : (ylo + yhi) / 2.0;
+        const double e0 = fabs((mn - shift) / scale - med), e1 = fabs((mx - shift) / scale - med);
+        const double mad = block_median_fast([&](i64 i) { return fabs(y[i] - med); }, n, 0.0,
+                                             e0 > e1 ? e0 : e1, &sm);
         lo = med - (mad * o.outlier_thresh);
         hi = med + (mad * o.outlier_thresh);
         have_lims = true;
@@ -62,17 +88,28 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
 // change-point ranking, so a parallel scan is not an option): one lane per read.
 // csum has n_raw + 1 entries per read at raw_off + read_index.
 __global__ __launch_bounds__(64) void k_cumsum(const ReadState *rs, i64 n_reads,
-    const double *norm, double *csum)
+    const double *__restrict__ norm, double *__restrict__ csum)
 {
     i64 ri = (i64)blockIdx.x * 64 + threadIdx.x;
     if (ri >= n_reads) return;
     const ReadState &r = rs[ri];
     if (r.status != TBA_OK) return;
-    const double *x = norm + r.raw_off;
-    double *c = csum + r.raw_off + ri;
+    const double *__restrict__ x = norm + r.raw_off;
+    double *__restrict__ c = csum + r.raw_off + ri;
     double acc = 0.0;
     c[0] = acc;
-    for (i64 i = 0; i < r.n_raw; i++) {
+    const i64 n = r.n_raw;
+    i64 i = 0;
+    for (; i + 16 <= n; i += 16) { // loads first, then the dependent adds, then the stores
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = x[i + k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { acc = acc + t[k]; t[k] = acc; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) c[i + 1 + k] = t[k];
+    }
+    for (; i < n; i++) {
         acc = acc + x[i];
         c[i + 1] = acc;
     }
@@ -133,10 +170,11 @@ __device__ __forceinline__ bool prio_before(double sp, i64 p, double sq, i64 q)
 }
 
 __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams *dp,
-    const double *score, unsigned char *state, i64 *valid_cpts, int ttest)
+    const double *score, unsigned char *state, double *dense, i64 *valid_cpts, int ttest)
 {
-    __shared__ SelectSmem sm;
-    __shared__ i64 s_cnt[SEL_NT];
+    __shared__ BucketSmem sm;
+    __shared__ i64 s_w[SEL_NT / 64];
+    __shared__ i64 s_idx_thr;
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
     const int tid = threadIdx.x;
@@ -146,6 +184,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     const i64 num_cpts = r.num_events;
     const double *s = score + r.raw_off;
     unsigned char *st = state + r.raw_off;
+    double *dn = dense + r.raw_off + blockIdx.x; // scratch: taken scores, densely packed
     i64 *cpts = valid_cpts + r.ev_off;
     if (ns <= 0 || num_cpts <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
 
@@ -171,77 +210,80 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
             else undecided++;
         }
         __threadfence_block();
-        i64 tot = block_sum_i64(undecided, &sm);
+        i64 tot = block_sum_i64(undecided, &sm.rad);
         if (tot == 0) break;
     }
-    // number taken
-    i64 mine = 0;
-    for (i64 p = tid; p < ns; p += SEL_NT) mine += st[p] == 1;
-    i64 n_taken = block_sum_i64(mine, &sm);
+    // taken scores -> dense array (+ their range)
+    double mn = INFINITY, mx = -INFINITY;
+    const i64 n_taken = block_compact(
+        ns, [&](i64 p) { return st[p] == 1; },
+        [&](i64 p, i64 o) { double v = s[p]; dn[o] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; },
+        s_w);
     if (n_taken < num_cpts) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
-
-    // the num_cpts-th taken position in priority order: select on the score key among taken
-    // (descending rank num_cpts-1 == ascending rank n_taken-num_cpts); untaken map to key 0
-    // which sorts below every real score key (scores are >= 0 -> keys >= 0x8000...)
-    auto fk = [&](i64 p) { return st[p] == 1 ? f64_key(s[p]) : 0ull; };
-    block_select(fk, ns, (ns - n_taken) + (n_taken - num_cpts), &sm);
-    const u64 tkey = sm.prefix;
+    for (int mm = 32; mm >= 1; mm >>= 1) {
+        double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
+        mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
+    }
+    if ((tid & 63) == 0) { sm.redd[2 * (tid >> 6)] = mn; sm.redd[2 * (tid >> 6) + 1] = mx; }
     __syncthreads();
-    // ties on the threshold score (never with continuous input): take the highest indices
-    i64 c_gt = 0, c_eq = 0;
-    for (i64 p = tid; p < ns; p += SEL_NT)
-        if (st[p] == 1) { u64 k = f64_key(s[p]); c_gt += k > tkey; c_eq += k == tkey; }
-    c_gt = block_sum_i64(c_gt, &sm);
-    c_eq = block_sum_i64(c_eq, &sm);
+    mn = sm.redd[0]; mx = sm.redd[1];
+    for (int q = 1; q < SEL_NT / 64; q++) {
+        mn = sm.redd[2 * q] < mn ? sm.redd[2 * q] : mn;
+        mx = sm.redd[2 * q + 1] > mx ? sm.redd[2 * q + 1] : mx;
+    }
+    __syncthreads();
+    // score of the num_cpts-th best taken position (ascending rank n_taken - num_cpts)
+    const double tval = block_kth([&](i64 i) { return dn[i]; }, n_taken, n_taken - num_cpts, mn,
+                                  mx, &sm);
+    __syncthreads();
+    // one pass: taken above / at the threshold, all positions above / at it, lowest taken index
+    // at the threshold
+    i64 c_gt = 0, c_eq = 0, a_gt = 0, a_eq = 0, min_eq = ns;
+    for (i64 p = tid; p < ns; p += SEL_NT) {
+        const double v = s[p];
+        const bool tk = st[p] == 1;
+        a_gt += v > tval; a_eq += v == tval;
+        c_gt += tk && v > tval;
+        if (tk && v == tval) { c_eq++; min_eq = p < min_eq ? p : min_eq; }
+    }
+    c_gt = block_sum_i64(c_gt, &sm.rad);
+    c_eq = block_sum_i64(c_eq, &sm.rad);
+    a_gt = block_sum_i64(a_gt, &sm.rad);
+    a_eq = block_sum_i64(a_eq, &sm.rad);
+    for (int mm = 32; mm >= 1; mm >>= 1) { i64 t = shfl_i64(min_eq, (tid & 63) ^ mm); min_eq = t < min_eq ? t : min_eq; }
+    if ((tid & 63) == 0) s_w[tid >> 6] = min_eq;
+    __syncthreads();
+    min_eq = s_w[0];
+    for (int q = 1; q < SEL_NT / 64; q++) min_eq = s_w[q] < min_eq ? s_w[q] : min_eq;
+    __syncthreads();
     const i64 need_eq = num_cpts - c_gt;
-    __shared__ i64 s_idx_thr;
-    if (tid == 0) {
-        i64 thr = 0;
+    i64 idx_thr = min_eq; // take every taken position at the threshold score
+    i64 before = a_gt;    // rank of the last pick in the argsort order
+    if (need_eq < c_eq || a_eq > 1) {
+        // exact ties on the threshold score (never with continuous input): priority falls to
+        // the higher index; resolve sequentially, then recount
         if (need_eq < c_eq) {
-            i64 left = need_eq;
-            for (i64 p = ns - 1; p >= 0; p--)
-                if (st[p] == 1 && f64_key(s[p]) == tkey) { if (--left == 0) { thr = p; break; } }
-        } else {
-            for (i64 p = 0; p < ns; p++)
-                if (st[p] == 1 && f64_key(s[p]) == tkey) { thr = p; break; }
+            if (tid == 0) {
+                i64 thr = 0, left = need_eq;
+                for (i64 p = ns - 1; p >= 0; p--)
+                    if (st[p] == 1 && s[p] == tval) { if (--left == 0) { thr = p; break; } }
+                s_idx_thr = thr;
+            }
+            __syncthreads();
+            idx_thr = s_idx_thr;
         }
-        s_idx_thr = thr;
+        i64 extra = 0;
+        for (i64 p = tid; p < ns; p += SEL_NT) extra += s[p] == tval && p > idx_thr;
+        before = a_gt + block_sum_i64(extra, &sm.rad);
     }
-    __syncthreads();
-    const i64 idx_thr = s_idx_thr;
-    // rank (0-based position in the argsort order) of the last pick; the reference raises when
-    // rank + 1 >= num_cands (cand_idx is advanced past the pick before the bound check)
-    if (num_cpts > 1) {
-        i64 before = 0;
-        for (i64 p = tid; p < ns; p += SEL_NT) {
-            u64 k = f64_key(s[p]);
-            before += (k > tkey) || (k == tkey && p > idx_thr);
-        }
-        before = block_sum_i64(before, &sm);
-        if (before + 1 >= num_cands) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
-    }
-    // ordered compaction (the .sort() of tombo_helper.py:76-82): contiguous chunk per thread
-    const i64 chunk = (ns + SEL_NT - 1) / SEL_NT;
-    const i64 b0 = (i64)tid * chunk, b1 = b0 + chunk > ns ? ns : b0 + chunk;
-    i64 cnt = 0;
-    for (i64 p = b0; p < b1; p++) {
-        if (st[p] != 1) continue;
-        u64 k = f64_key(s[p]);
-        cnt += (k > tkey) || (k == tkey && p >= idx_thr);
-    }
-    s_cnt[tid] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        i64 acc = 0;
-        for (int t = 0; t < SEL_NT; t++) { i64 c = s_cnt[t]; s_cnt[t] = acc; acc += c; }
-    }
-    __syncthreads();
-    i64 outp = s_cnt[tid];
-    for (i64 p = b0; p < b1; p++) {
-        if (st[p] != 1) continue;
-        u64 k = f64_key(s[p]);
-        if ((k > tkey) || (k == tkey && p >= idx_thr)) cpts[outp++] = p + w;
-    }
+    // the reference raises when rank + 1 >= num_cands (cand_idx is advanced past the pick before
+    // the bound check, _c_helper.pyx:116-118)
+    if (num_cpts > 1 && before + 1 >= num_cands) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
+    // ordered compaction of the picks (the .sort() of tombo_helper.py:76-82)
+    block_compact(
+        ns,
+        [&](i64 p) { if (st[p] != 1) return false; const double v = s[p]; return v > tval || (v == tval && p >= idx_thr); },
+        [&](i64 p, i64 o) { cpts[o] = p + w; }, s_w);
     if (tid == 0) { r.n_cpts = num_cpts; r.n_ev = num_cpts - 1; }
 }
 

@@ -153,3 +153,230 @@ __device__ inline i64 block_sum_i64(i64 v, SelectSmem *sm)
     __syncthreads();
     return t;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Bucket select: exact k-th order statistic in ~2 passes for data whose range is roughly known.
+// Pass 1 histograms a monotone (non-decreasing) value->bucket map over [lo, hi]; the bucket that
+// holds rank k is gathered into LDS (pass 2) and resolved by rank counting.  Any range gives the
+// right answer (values outside fall into the edge buckets); a bad range only costs refinement
+// levels (re-bucket the members of the chosen bucket over their exact min/max), and after
+// BS_LEVELS levels the radix select above takes over.  Comparisons and counting only: exact.
+#define BS_NB 4096
+#define BS_CAP 2048
+#define BS_LEVELS 4
+
+struct BucketSmem {
+    u32 hist[BS_NB];
+    double cand[BS_CAP];
+    double lo[BS_LEVELS], scale[BS_LEVELS];
+    i32 bk[BS_LEVELS];
+    i32 nlev, found;
+    u32 n_cand;
+    i64 k, cnt;
+    double result, next; // next: smallest candidate above result (or +inf)
+    i64 n_le;            // number of elements <= result (valid when has_le)
+    double redd[2 * (SEL_NT / 64)];
+    SelectSmem rad;      // fallback
+};
+
+__device__ __forceinline__ int bs_bucket(double v, double lo, double scale)
+{
+    double t = (v - lo) * scale;
+    int b = t >= (double)(BS_NB - 1) ? BS_NB - 1 : (t > 0.0 ? (int)t : 0);
+    return b;
+}
+__device__ __forceinline__ bool bs_member(const BucketSmem *sm, int nlev, double v)
+{
+    for (int l = 0; l < nlev; l++)
+        if (bs_bucket(v, sm->lo[l], sm->scale[l]) != sm->bk[l]) return false;
+    return true;
+}
+
+// k-th smallest (0-based) of { val(i) }, all threads call, all return the value.
+// On return sm->next holds the (k+1)-th smallest if it could be determined cheaply
+// (sm->found & 2), i.e. when it lies in the same final bucket or equals the k-th.
+template <class F>
+__device__ double block_kth(F val, i64 n, i64 k, double lo, double hi, BucketSmem *sm)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) { sm->nlev = 0; sm->k = k; sm->found = 0; sm->cnt = n; }
+    __syncthreads();
+    const bool small = n <= BS_CAP; // everything fits the candidate buffer: no histogram
+    for (int level = 0; level < BS_LEVELS; level++) {
+        double scale = (double)BS_NB / (hi - lo);
+        if (!small && (!(hi > lo) || !(scale < 1e300))) break; // degenerate range -> radix
+        if (!small) {
+        for (int b = tid; b < BS_NB; b += SEL_NT) sm->hist[b] = 0;
+        __syncthreads();
+        const int nlev = sm->nlev;
+        for (i64 base = 0; base < n; base += SEL_NT) {
+            i64 i = base + tid;
+            bool part = false;
+            u32 bin = 0;
+            if (i < n) {
+                double v = val(i);
+                part = bs_member(sm, nlev, v);
+                bin = (u32)bs_bucket(v, lo, scale);
+            }
+            hist_add(sm->hist, part, bin);
+        }
+        __syncthreads();
+        if (tid < 64) { // wave 0: locate the bucket of rank k (BS_NB/64 bins per lane)
+            const int per = BS_NB / 64;
+            i64 c = 0;
+            for (int q = 0; q < per; q++) c += sm->hist[tid * per + q];
+            i64 inc = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                i64 t = shfl_i64(inc, tid - d < 0 ? 0 : tid - d);
+                if (tid >= d) inc += t;
+            }
+            i64 exc = inc - c, kk = sm->k;
+            if (exc <= kk && kk < inc) {
+                i64 acc = exc;
+                for (int q = 0; q < per; q++) {
+                    u32 h = sm->hist[tid * per + q];
+                    if (kk < acc + h) {
+                        sm->bk[nlev] = tid * per + q;
+                        sm->lo[nlev] = lo; sm->scale[nlev] = scale;
+                        sm->k = kk - acc; sm->cnt = h;
+                        break;
+                    }
+                    acc += h;
+                }
+                sm->nlev = nlev + 1;
+            }
+        }
+        } // !small
+        __syncthreads();
+        const i64 cnt = sm->cnt;
+        const int nl = sm->nlev;
+        if (cnt <= BS_CAP) {
+            // gather the bucket and pick rank k inside it by counting
+            if (tid == 0) sm->n_cand = 0;
+            __syncthreads();
+            for (i64 i = tid; i < n; i += SEL_NT) {
+                double v = val(i);
+                if (bs_member(sm, nl, v)) { u32 p = atomicAdd(&sm->n_cand, 1u); if (p < BS_CAP) sm->cand[p] = v; }
+            }
+            __syncthreads();
+            const int m = (int)cnt;
+            const i64 kk = sm->k;
+            for (int a = tid; a < m; a += SEL_NT) {
+                const double va = sm->cand[a];
+                int less = 0, eq_before = 0, le = 0;
+                double nxt = INFINITY;
+                for (int b2 = 0; b2 < m; b2++) {
+                    const double vb = sm->cand[b2];
+                    less += vb < va;
+                    le += vb <= va;
+                    eq_before += (vb == va) && (b2 < a);
+                    nxt = (vb > va && vb < nxt) ? vb : nxt;
+                }
+                if (less + eq_before == kk) { // exactly one candidate has this rank
+                    sm->result = va;
+                    // the next order statistic: same value if another copy follows, else the
+                    // smallest larger candidate of this bucket (if any)
+                    if (le - 1 > kk) { sm->next = va; sm->found = 3; }
+                    else if (nxt < INFINITY) { sm->next = nxt; sm->found = 3; }
+                    else sm->found = 1;
+                }
+            }
+            __syncthreads();
+            return sm->result;
+        }
+        // too many members: re-bucket them over their exact min / max
+        double mn = INFINITY, mx = -INFINITY;
+        for (i64 i = tid; i < n; i += SEL_NT) {
+            double v = val(i);
+            if (bs_member(sm, nl, v)) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        }
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+            double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
+            mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
+        }
+        if ((tid & 63) == 0) { sm->redd[2 * (tid >> 6)] = mn; sm->redd[2 * (tid >> 6) + 1] = mx; }
+        __syncthreads();
+        mn = sm->redd[0]; mx = sm->redd[1];
+        for (int w = 1; w < SEL_NT / 64; w++) {
+            mn = sm->redd[2 * w] < mn ? sm->redd[2 * w] : mn;
+            mx = sm->redd[2 * w + 1] > mx ? sm->redd[2 * w + 1] : mx;
+        }
+        __syncthreads();
+        if (mn == mx) { // every member equal: that is the answer, and the next one too if cnt > k+1
+            if (tid == 0) { sm->result = mn; sm->next = mn; sm->found = sm->cnt - 1 > sm->k ? 3 : 1; }
+            __syncthreads();
+            return mn;
+        }
+        lo = mn; hi = mx;
+    }
+    // pathological input: exact radix select on the whole set
+    block_select([&](i64 i) { return f64_key(val(i)); }, n, k, &sm->rad);
+    double res = key_f64(sm->rad.prefix);
+    if (tid == 0) { sm->result = res; sm->found = 1; }
+    __syncthreads();
+    return res;
+}
+
+// np.median through block_kth: (lower middle + upper middle) / 2.  The upper middle comes for
+// free when it shares the final bucket with the lower one, else one min-greater pass.
+// Returns the median; *lo_mid / *hi_mid (if not NULL) get the two middle order statistics.
+template <class F>
+__device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSmem *sm,
+                                    double *lo_mid = nullptr, double *hi_mid = nullptr)
+{
+    const i64 k_lo = (n - 1) / 2;
+    double a = block_kth(val, n, k_lo, lo, hi, sm);
+    double b = a;
+    if (!(n & 1)) {
+        const int found = sm->found;
+        const double nxt = sm->next;
+        __syncthreads();
+        if (found & 2) {
+            b = nxt;
+        } else {
+            // count elements <= a; if that exceeds k_lo + 1 the next one equals a, otherwise it
+            // is the smallest element above a
+            i64 le = 0;
+            double mn = INFINITY;
+            for (i64 i = threadIdx.x; i < n; i += SEL_NT) {
+                double v = val(i);
+                le += v <= a;
+                mn = (v > a && v < mn) ? v : mn;
+            }
+            le = block_sum_i64(le, &sm->rad);
+            for (int mm = 32; mm >= 1; mm >>= 1) { double t = shfl_xor_f64(mn, mm); mn = t < mn ? t : mn; }
+            if ((threadIdx.x & 63) == 0) sm->redd[threadIdx.x >> 6] = mn;
+            __syncthreads();
+            mn = sm->redd[0];
+            for (int w = 1; w < SEL_NT / 64; w++) mn = sm->redd[w] < mn ? sm->redd[w] : mn;
+            __syncthreads();
+            b = le > k_lo + 1 ? a : mn;
+        }
+    }
+    if (lo_mid) *lo_mid = a;
+    if (hi_mid) *hi_mid = b;
+    return (n & 1) ? a : (a + b) / 2.0;
+}
+
+// ordered stream compaction over [0, n): emit(i, out_index) for every i with pred(i), output
+// indices ascending in i.  All threads call; returns the number emitted.  s_w: >= SEL_NT/64 i64.
+template <class Pred, class Emit>
+__device__ i64 block_compact(i64 n, Pred pred, Emit emit, i64 *s_w)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    i64 run = 0;
+    for (i64 base = 0; base < n; base += SEL_NT) {
+        const i64 i = base + tid;
+        const bool flag = i < n && pred(i);
+        const u64 mask = __ballot(flag);
+        const int pre = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[w] = __popcll(mask);
+        __syncthreads();
+        i64 off = 0, tot = 0;
+        for (int q = 0; q < SEL_NT / 64; q++) { i64 c = s_w[q]; off += q < w ? c : 0; tot += c; }
+        if (flag) emit(i, run + off + pre);
+        run += tot;
+        __syncthreads();
+    }
+    return run;
+}

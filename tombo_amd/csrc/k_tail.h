@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const d
 __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevParams *dp,
     const double *base_means, const double *ref_means, const i64 *samp_ind)
 {
-    __shared__ SelectSmem sm;
+    __shared__ BucketSmem sm;
     __shared__ double s_ev[MAX_TS_POINTS], s_md[MAX_TS_POINTS];
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
@@ -309,17 +309,20 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     }
     const i64 ns = n * (n - 1) / 2;
     if (ns <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
-    const i64 full = n * ((n - 1) / 2); // distances 1..(n-1)/2 cover n pairs each
-    auto slope_key = [&](i64 idx) {
-        i64 i, j;
-        if (idx < full) { i64 d = idx / n + 1; i = idx - (d - 1) * n; j = i + d; if (j >= n) j -= n; }
-        else { i = idx - full; j = i + n / 2; }
-        double ei = s_ev[i], ej = s_ev[j];
-        double sl = (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) / (ei - ej);
-        return f64_key(sl);
+    const u32 nn = (u32)n, full = nn * ((nn - 1) / 2); // distances 1..(n-1)/2: n pairs each
+    auto slope_val = [&](i64 idx64) {
+        const u32 idx = (u32)idx64;
+        u32 i, j;
+        if (idx < full) { u32 d = idx / nn + 1; i = idx - (d - 1) * nn; j = i + d; if (j >= nn) j -= nn; }
+        else { i = idx - full; j = i + nn / 2; }
+        const double ei = s_ev[i], ej = s_ev[j];
+        return (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) / (ei - ej);
     };
-    double slope = block_median(slope_key, ns, &sm);
-    double inter = block_median([&](i64 i) { return f64_key(s_md[i] - (slope * s_ev[i])); }, n, &sm);
+    // slopes of a normalised read cluster around 1: [0.5, 1.5] is only the first bucket range,
+    // any other distribution costs refinement passes, not correctness (k_select.h)
+    double slope = block_median_fast(slope_val, ns, 0.5, 1.5, &sm);
+    double inter = block_median_fast([&](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, 0.0,
+                                     1.0, &sm); // n <= 1000: gathered directly
     if (tid == 0) {
         if (slope == 0) { r.status = TBA_RESCALE_FAIL; return; }
         double scale_corr = 1 / slope;

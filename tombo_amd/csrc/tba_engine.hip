@@ -319,7 +319,7 @@ extern "C" int tba_batch_enqueue(tba_engine *e)
     if (!rna) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>());
     else k_scores_ttest<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_score.as<double>());
     MARK(); // 3 peaks
-    k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
+    k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
     if (e->any_stall) k_remove_stalls<<<tpr, 64, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>());
     MARK(); // 4 event means (RNA: after event-based scaling)
     if (rna) {
@@ -727,7 +727,7 @@ static int c_valid_cpts(tba_engine *e, const double *sig, int64_t n, int64_t min
         k_scores_ttest<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
     }
     k_peaks<<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_score.as<double>(),
-                                 d_state.as<unsigned char>(), d_cpts.as<i64>(), ttest);
+                                 d_state.as<unsigned char>(), d_csum.as<double>(), d_cpts.as<i64>(), ttest);
     C_TRY(hipGetLastError());
     C_TRY(hipStreamSynchronize(s));
     C_TRY(hipMemcpy(&r, d_rs.p, sizeof(r), hipMemcpyDeviceToHost));
