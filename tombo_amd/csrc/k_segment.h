@@ -164,6 +164,9 @@ __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const
 // positions by exact selection.  Priority = (score, index) descending -- identical to
 // np.argsort(score)[::-1] for tie-free scores; ties fall to the higher index.
 // One workgroup per read.  state: 0 undecided, 1 taken, 2 suppressed.
+#define PK_CORE 3072
+#define PK_HALO 64
+#define PK_SPAN (PK_CORE + 2 * PK_HALO)
 __device__ __forceinline__ bool prio_before(double sp, i64 p, double sq, i64 q)
 {
     return sp > sq || (sp == sq && p > q);
@@ -188,30 +191,80 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     i64 *cpts = valid_cpts + r.ev_off;
     if (ns <= 0 || num_cpts <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
 
-    for (i64 p = tid; p < ns; p += SEL_NT) st[p] = 0;
-    __syncthreads();
-    // fixed point of the greedy; every round settles at least the best undecided position
-    for (i64 round = 0; round <= ns; round++) {
-        i64 undecided = 0;
-        for (i64 p = tid; p < ns; p += SEL_NT) {
-            if (st[p] != 0) continue;
-            const double sp_ = s[p];
-            bool any_taken = false, any_undecided = false;
-            i64 q0 = p - m + 1 < 0 ? 0 : p - m + 1, q1 = p + m - 1 >= ns ? ns - 1 : p + m - 1;
-            for (i64 q = q0; q <= q1; q++) {
-                if (q == p) continue;
-                if (!prio_before(s[q], q, sp_, p)) continue;
-                unsigned char sq = st[q];
-                if (sq == 1) any_taken = true;
-                else if (sq == 0) any_undecided = true;
+    // Phase 1: resolve the greedy inside LDS tiles (core PK_CORE positions + PK_HALO each side).
+    // A position is only decided from neighbours that are themselves decided, so every decision
+    // made here is final; positions whose dependency chain leaves the tile stay undecided (0)
+    // and are finished by the global rounds below (rare: chains are a few positions long).
+    {
+        static_assert((PK_SPAN + PK_SPAN / 8 + 1) <= BS_NB / 2 + BS_CAP, "tile does not fit");
+        double *ts = sm.raw8;                                   // PK_SPAN scores
+        unsigned char *tst = (unsigned char *)(sm.raw8 + PK_SPAN); // PK_SPAN states
+        i64 left_undecided = 0;
+        for (i64 t0 = 0; t0 < ns; t0 += PK_CORE) {
+            const i64 g0 = t0 - PK_HALO;                        // global index of tile slot 0
+            for (int k = tid; k < PK_SPAN; k += SEL_NT) {
+                const i64 p = g0 + k;
+                const bool in = p >= 0 && p < ns;
+                ts[k] = in ? s[p] : -1.0;                       // scores are >= 0: -1 never wins
+                // slots outside the signal are "suppressed" (they constrain nobody); the outermost
+                // m-1 slots of a tile that do have outside neighbours can never be decided here
+                unsigned char v0 = in ? 0 : 2;
+                tst[k] = v0;
             }
-            if (any_taken) st[p] = 2;
-            else if (!any_undecided) st[p] = 1;
-            else undecided++;
+            __syncthreads();
+            for (int round = 0; round < PK_SPAN; round++) {
+                int progress = 0;
+                for (int k = tid; k < PK_SPAN; k += SEL_NT) {
+                    if (tst[k] != 0) continue;
+                    const i64 p = g0 + k;
+                    // neighbours outside the loaded span (and inside the signal) are unknown
+                    const bool edge_lo = k < m - 1 && g0 > 0, edge_hi = k > PK_SPAN - m && g0 + PK_SPAN < ns;
+                    if (edge_lo || edge_hi) continue;
+                    const double sp_ = ts[k];
+                    bool any_taken = false, any_undecided = false;
+                    int q0 = k - (int)m + 1 < 0 ? 0 : k - (int)m + 1;
+                    int q1 = k + (int)m - 1 >= PK_SPAN ? PK_SPAN - 1 : k + (int)m - 1;
+                    for (int q = q0; q <= q1; q++) {
+                        if (q == k) continue;
+                        if (!prio_before(ts[q], g0 + q, sp_, p)) continue;
+                        const unsigned char sq = tst[q];
+                        any_taken |= sq == 1;
+                        any_undecided |= sq == 0;
+                    }
+                    if (any_taken) { tst[k] = 2; progress = 1; }
+                    else if (!any_undecided) { tst[k] = 1; progress = 1; }
+                }
+                if (!__syncthreads_or(progress)) break;
+            }
+            for (int k = tid; k < PK_CORE; k += SEL_NT) {
+                const i64 p = t0 + k;
+                if (p < ns) { const unsigned char v0 = tst[k + PK_HALO]; st[p] = v0; left_undecided += v0 == 0; }
+            }
+            __syncthreads();
         }
-        __threadfence_block();
-        i64 tot = block_sum_i64(undecided, &sm.rad);
-        if (tot == 0) break;
+        left_undecided = block_sum_i64(left_undecided, &sm.rad);
+        // Phase 2: global rounds for whatever the tiles could not settle
+        for (i64 round = 0; left_undecided > 0 && round <= ns; round++) {
+            i64 undecided = 0;
+            for (i64 p = tid; p < ns; p += SEL_NT) {
+                if (st[p] != 0) continue;
+                const double sp_ = s[p];
+                bool any_taken = false, any_undecided = false;
+                i64 q0 = p - m + 1 < 0 ? 0 : p - m + 1, q1 = p + m - 1 >= ns ? ns - 1 : p + m - 1;
+                for (i64 q = q0; q <= q1; q++) {
+                    if (q == p) continue;
+                    if (!prio_before(s[q], q, sp_, p)) continue;
+                    unsigned char sq = st[q];
+                    if (sq == 1) any_taken = true;
+                    else if (sq == 0) any_undecided = true;
+                }
+                if (any_taken) st[p] = 2;
+                else if (!any_undecided) st[p] = 1;
+                else undecided++;
+            }
+            __threadfence_block();
+            left_undecided = block_sum_i64(undecided, &sm.rad);
+        }
     }
     // taken scores -> dense array (+ their range)
     double mn = INFINITY, mx = -INFINITY;

@@ -166,8 +166,10 @@ __device__ inline i64 block_sum_i64(i64 v, SelectSmem *sm)
 #define BS_LEVELS 4
 
 struct BucketSmem {
-    u32 hist[BS_NB];
-    double cand[BS_CAP];
+    union { // the 32 KB histogram + candidate area doubles as a raw tile buffer (k_peaks)
+        struct { u32 hist[BS_NB]; double cand[BS_CAP]; };
+        double raw8[BS_NB / 2 + BS_CAP];
+    };
     double lo[BS_LEVELS], scale[BS_LEVELS];
     i32 bk[BS_LEVELS];
     i32 nlev, found;
