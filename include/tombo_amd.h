@@ -184,6 +184,11 @@ int tba_c_valid_cpts_w_cap(tba_engine *e, const double *sig, int64_t n, int64_t 
 int tba_c_valid_cpts_w_cap_t_test(tba_engine *e, const double *sig, int64_t n,
     int64_t min_base_obs, int64_t running_stat_width, int64_t num_cpts, int64_t *cpts);
 
+/* self-test: out[i] = the row-constant division used inside the DP kernel (reciprocal + two
+ * residual corrections) for a[i] / b[i]; must equal the IEEE quotient bit for bit */
+int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,
+                          double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,3 +136,29 @@ def test_row_engine_every_band_class(bw):
     rc, want = oracle.banded_traceback(otb, starts, top)
     assert rc == 0
     np.testing.assert_array_equal(cdp.c_banded_traceback(tb, starts, top), want)
+
+
+def test_row_constant_division_is_ieee():
+    """div_by_recip (k_dp's z-score division by a per-row sd) == a / b bit for bit"""
+    import ctypes as C
+    from tombo_amd import resquiggle as rq
+    eng = rq.get_engine(0)
+    rng = np.random.default_rng(3)
+    n = 1 << 21
+    a = np.concatenate([
+        rng.normal(0, 3, n // 4), rng.normal(0, 1e-3, n // 4), rng.uniform(-30, 30, n // 4),
+        rng.normal(0, 1, n // 4) * 10.0 ** rng.uniform(-12, 6, n // 4)])
+    b = np.concatenate([
+        np.full(n // 4, 0.3528720791815676), np.full(n // 4, 0.2252531482690988),
+        rng.uniform(0.05, 3.0, n // 4), 10.0 ** rng.uniform(-3, 3, n // 4)])
+    a[:64] = 0.0
+    a[64:128] = np.nextafter(b[64:128], 10)          # quotients next to 1
+    a[128:192] = b[128:192] * (1 + 2.0 ** -52)
+    out = np.empty(n)
+    pd = C.POINTER(C.c_double)
+    rc = eng._L.tba_selftest_division(eng._h, a.ctypes.data_as(pd), b.ctypes.data_as(pd),
+                                      C.c_int64(n), out.ctypes.data_as(pd))
+    assert rc == 0
+    want = a / b
+    bad = np.flatnonzero(out != want)
+    assert bad.size == 0, (bad[:5], a[bad[:5]], b[bad[:5]], out[bad[:5]], want[bad[:5]])

@@ -41,6 +41,15 @@ __global__ void k_c_traceback(const unsigned char *mv, i64 stride, i64 n_bases, 
                               i32 *status)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0)
-        *status = dev_banded_traceback(mv, stride, n_bases, bw, starts, false, band_pos, thresh,
+        *status = dev_banded_traceback(mv, stride, 0, n_bases, bw, starts, false, band_pos, thresh,
                                        seq_poss);
+}
+
+// self-test of the row-constant division used by k_dp (div_by_recip vs the IEEE quotient)
+__global__ void k_c_div_check(const double *a, const double *b, i64 n, double *out)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const double y = 1.0 / b[i];
+        out[i] = div_by_recip(a[i], b[i], y);
+    }
 }

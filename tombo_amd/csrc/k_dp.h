@@ -74,15 +74,58 @@ __device__ __forceinline__ double wave_max_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-// Row body is straight-line code (selects, clamped loads): the only branches are wave-uniform
-// (static vs adaptive row, sweep loop).
+// a / b for a row-constant divisor, bit-identical to IEEE division: y = RN(1/b) comes from one
+// true division per row, q0 = RN(a*y) is within 2 ulp, one residual correction makes it
+// faithful, a second one rounds correctly (Markstein: q faithful, y = RN(1/b), r = a - b*q exact
+// => RN(q + r*y) = RN(a/b)).  Results that underflow are far below the 1e-17 granularity of the
+// z_shift they are subtracted from.  tests/test_gpu_kernel_abi.py checks it against true division.
+__device__ __forceinline__ double div_by_recip(double a, double b, double y)
+{
+    double q = a * y;
+    double e = __builtin_fma(-b, q, a);
+    q = __builtin_fma(e, y, q);
+    e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, y, q);
+}
+
+// bytes of packed 2-bit moves per lane per row (4 cells per byte), padded to a store width
+__host__ __device__ constexpr int mv_bpl(int cpl)
+{
+    return cpl <= 4 ? 1 : cpl <= 8 ? 2 : cpl <= 16 ? 4 : cpl <= 32 ? 8 : 12;
+}
+
+// wave-uniform values the compiler cannot prove uniform (they come from vector loads or
+// shuffles) are moved to scalar registers explicitly, so that control flow on them is scalar
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ i64 uni(i64 x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)(x & 0xffffffff));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
+    return ((i64)hi << 32) | (u32)lo;
+}
+template <class T> __device__ __forceinline__ T *uni(T *p) { return (T *)uni((i64)p); }
+__device__ __forceinline__ double uni(double x) { return __longlong_as_double((long long)uni((i64)__double_as_longlong(x))); }
+__device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
+
+// Row body is straight-line code; the only branches are wave-uniform (static vs adaptive row,
+// masked row, band-jump size, sweep loop).  Data flow per row:
+//   events   : LDS ring of the read's event means around the band (refilled by coalesced
+//              prefetches one chunk ahead, so no global-load latency sits on the row chain)
+//   prev row : LDS, cells >= W hold -inf so out-of-band candidates need no guards
+//   mu/sd    : prefetched one row ahead
 template <int CPL, bool DIRECT>
 __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
     i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,
     unsigned char *moves, i64 start_moves_stride, double *last_row, DpJob *job)
 {
-    __shared__ double rows[2][CPL * 64];
+    constexpr int QPAD = 4;              // extra "lanes" of -inf at the end of each LDS row slice
+    constexpr int LD = 64 + QPAD;
+    constexpr int RL = 128;              // ring: 128 slots per residue class -> 128*CPL events
+    constexpr int RING = RL * CPL;
+    constexpr int BPL = mv_bpl(CPL);
+    __shared__ double rows[2][CPL * LD];
+    __shared__ double ring[RING];
     ReadState &r = rs[DIRECT ? 0 : blockIdx.x];
     if (!DIRECT && r.status != TBA_OK) return;
     const tba_params &P = dp->p;
@@ -115,7 +158,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             ev_base = r.ev_off + r.clip;
             n_ev = r.n_ev - r.clip;
             identity = false;
-            mv = moves + r.moves_off;
+            mv = moves + uni(r.moves_off);
         } else {
             if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
             W = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
@@ -126,25 +169,36 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             identity = true;
             mv = moves + (i64)blockIdx.x * start_moves_stride;
         }
-        ev = event_means + ev_base;
-        rmu = ref_means + r.ref_off;
-        rsd = ref_sds + r.ref_off;
-        bst = band_starts + r.ref_off;
-        lo_a = lo_arr + r.ref_off;
-        hi_a = hi_arr + r.ref_off;
+        const i64 ro = uni(r.ref_off);
+        ev = event_means + uni(ev_base);
+        rmu = ref_means + ro;
+        rsd = ref_sds + ro;
+        bst = band_starts + ro;
+        lo_a = lo_arr + ro;
+        hi_a = hi_arr + ro;
         stay_pen = P.stay_pen; skip_pen = P.skip_pen; z_shift = P.z_shift;
         max_half_z = P.max_half_z_score;
         winsor = P.do_winsorize_z != 0;
         fill_masked = dp->fill_masked;
     }
+    // everything above came through vector loads: make it scalar once
+    W = uni(W); n_rows = uni(n_rows); n_static = uni(n_static); n_ev = uni(n_ev); row0 = uni(row0);
+    identity = uni(identity); winsor = uni(winsor);
+    stay_pen = uni(stay_pen); skip_pen = uni(skip_pen); z_shift = uni(z_shift);
+    max_half_z = uni(max_half_z); fill_masked = uni(fill_masked);
+    const bool use_z = DIRECT && zmat != nullptr;
     const int Wi = (int)W;
     const i64 half_bw = W / 2; // integer division, pyx:327
     const double NEG_INF = -INFINITY;
-    const i64 mv_stride = (i64)CPL * 64;
+    const i64 mv_stride = (i64)BPL * 64;
     const int b0 = lane * CPL;   // my first band cell
-    // without winsorising the clamp value is +inf (no effect)
-    const double zcap = winsor ? max_half_z : INFINITY;
+    int nvalid = Wi - b0;        // how many of my cells are inside the band
+    nvalid = nvalid < 0 ? 0 : (nvalid > CPL ? CPL : nvalid);
+    const double zcap = winsor ? max_half_z : INFINITY; // no winsorising: clamp at +inf
 
+    // LDS rows: everything -inf (cells past the band and the pad lanes stay -inf for good)
+    for (int k = lane; k < 2 * CPL * LD; k += 64) (&rows[0][0])[k] = NEG_INF;
+    __syncthreads();
     double *prev = rows[0], *cur = rows[1];
     i64 prev_start = 0;
     i64 am = 0; // argmax of the previous row (row 0: all zeros -> 0)
@@ -156,37 +210,70 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
             const int b = b0 + j;
-            const bool valid = b < Wi;
-            double x = job->init_row[valid ? b : Wi - 1];
-            x = valid ? x : 0.0;
-            prev[j * 64 + lane] = x;
-            const bool better = valid && x > lmax;
+            double x = job->init_row[j < nvalid ? b : Wi - 1];
+            x = j < nvalid ? x : NEG_INF;
+            prev[j * LD + lane] = x;
+            const bool better = x > lmax;
             lmax = better ? x : lmax;
             lidx = better ? b : lidx;
         }
         const double wm = wave_max_f64(lmax);
-        u64 eq = __ballot(lmax == wm && b0 < Wi);
-        am = __shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64);
-        if (row0 > 0) prev_start = bst[row0 - 1];
+        u64 eq = __ballot(lmax == wm && nvalid > 0);
+        am = uni(__shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64));
+        if (row0 > 0) prev_start = uni(bst[row0 - 1]);
     } else {
 #pragma unroll
-        for (int j = 0; j < CPL; j++) prev[j * 64 + lane] = 0.0; // row 0: zeros (pyx:253-254)
+        for (int j = 0; j < CPL; j++) prev[j * LD + lane] = j < nvalid ? 0.0 : NEG_INF; // row 0: zeros
     }
-    __syncthreads();
     if (DIRECT && job->fwd_out != nullptr && row0 == 0) {
 #pragma unroll
         for (int j = 0; j < CPL; j++) job->fwd_out[b0 + j] = 0.0; // rows padded to 64*CPL
     }
 
+    // event ring: absolute event index a (shifted by RING so it is never negative) lives at
+    // [(a' mod CPL) * RL + (a' div CPL) mod RL]; filled = first absolute index not yet loaded
+    i64 filled = 0;
+    auto ring_store = [&](i64 a, double x) {
+        const i64 ap = a + RING;
+        ring[(int)(ap % CPL) * RL + (int)((ap / CPL) & (RL - 1))] = x;
+    };
+    auto ev_load = [&](i64 a) { // clamped load + select: no divergent branch in the row loop
+        const i64 ac = a < 0 ? 0 : (a >= n_ev ? n_ev - 1 : a);
+        const double x = ev[ac];
+        return (a >= 0 && a < n_ev) ? x : 0.0;
+    };
+    double pf = 0.0;      // one prefetched chunk (event pf_at + lane), in flight
+    i64 pf_at = 0;
+    bool pf_pending = false;
+    if (!use_z) {
+        // the first band start positions the ring: [start, start + RING - 128) is loaded up front
+        i64 first_start = row0 < n_static ? (identity ? row0 : uni(bst[row0])) : prev_start;
+        filled = first_start;
+        for (int c = 0; c < RING / 64 - 2; c++) { ring_store(filled + lane, ev_load(filled + lane)); filled += 64; }
+    }
+    __syncthreads();
+
+    double mu_n = 0, sd_n = 1;
+    i64 st_n = 0; int lo_n = 0, hi_n = Wi;
+    auto fetch_row = [&](i64 rr) { // per-row inputs, fetched one row ahead
+        const i64 rc = rr < n_rows ? rr : n_rows - 1;
+        if (!use_z) { mu_n = rmu[rc]; sd_n = rsd[rc]; }
+        if (rc < n_static) {
+            if (identity) { st_n = rc; lo_n = 0; hi_n = Wi; }
+            else if (DIRECT) { st_n = bst[rc]; lo_n = 0; hi_n = Wi; }
+            else { st_n = bst[rc]; lo_n = lo_a[rc]; hi_n = hi_a[rc]; }
+        }
+    };
+    fetch_row(row0);
+
     double v[CPL];
     for (i64 row = row0; row < n_rows; row++) {
+        const double mu = mu_n, sd = sd_n;
         i64 cur_start;
         int lo, hi;
         double fill;
         if (row < n_static) {
-            if (identity) { cur_start = row; lo = 0; hi = Wi; }
-            else if (DIRECT) { cur_start = bst[row]; lo = 0; hi = Wi; }
-            else { cur_start = bst[row]; lo = lo_a[row]; hi = hi_a[row]; }
+            cur_start = uni(st_n); lo = uni(lo_n); hi = uni(hi_n);
             fill = fill_masked;
         } else {
             // adaptive band placement, pyx:342-358
@@ -204,69 +291,79 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             hi = cur_start + W <= n_ev ? Wi : (int)(n_ev - cur_start);
             fill = DIRECT ? fill_masked : MASK_FILL_Z_SCORE; // literal -15, pyx:385-386
         }
-        const int diff_i = __builtin_amdgcn_readfirstlane((int)(row > 0 ? cur_start - prev_start : 0));
-        double mu = 0, sd = 1;
-        if (!DIRECT || zmat == nullptr) { mu = rmu[row]; sd = rsd[row]; }
+        fetch_row(row + 1); // next row's inputs travel while this row computes
+        const int diff_i = (int)(row > 0 ? cur_start - prev_start : 0);
 
-        // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720);
-        // loads are clamped into the event array, masked / overrun cells are selected afterwards
+        // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720)
         double z[CPL];
-        {
-            const i64 e_last = n_ev - 1;
+        if (use_z) {
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
-                const int b = b0 + j;
-                double zz;
-                if (DIRECT && zmat != nullptr) {
-                    zz = zmat[row * W + (b < Wi ? b : Wi - 1)];
-                } else {
-                    i64 ei = cur_start + b;
-                    ei = ei < 0 ? 0 : (ei > e_last ? e_last : ei);
-                    double pz = fabs((ev[ei] - mu) / sd);
-                    pz = zcap < pz ? zcap : pz;
-                    zz = z_shift - pz;
-                    zz = (b >= lo && b < hi) ? zz : fill;
-                }
-                z[j] = b < Wi ? zz : 0.0; // cells past the band: z = 0, candidate = -inf
+                const double zz = zmat[row * W + (j < nvalid ? b0 + j : Wi - 1)];
+                z[j] = j < nvalid ? zz : NEG_INF;
+            }
+        } else {
+            // make sure the ring covers [cur_start, cur_start + W) (only a large band jump gets here)
+            if (cur_start + W > filled) {
+                if (pf_pending) { ring_store(pf_at + lane, pf); filled = pf_at + 64; pf_pending = false; }
+                while (cur_start + W > filled) { ring_store(filled + lane, ev_load(filled + lane)); filled += 64; }
+                __syncthreads();
+            }
+            const double y = 1.0 / sd;
+            const i64 up = cur_start + RING;                    // >= 0
+            const int u0 = (int)(up % CPL), c0 = (int)(up / CPL);
+            const int a0 = ((lane + c0) & (RL - 1)), a1 = ((lane + c0 + 1) & (RL - 1));
+            const bool full = lo == 0 && hi == Wi;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                const int t = u0 + j;                            // < 2*CPL
+                const int rr = t >= CPL ? t - CPL : t;
+                const double e = ring[rr * RL + (t >= CPL ? a1 : a0)];
+                double pz = fabs(div_by_recip(e - mu, sd, y));
+                pz = __builtin_fmin(pz, zcap);
+                double zz = z_shift - pz;
+                if (!full) zz = (b0 + j >= lo && b0 + j < hi) ? zz : fill;
+                z[j] = j < nvalid ? zz : NEG_INF; // cells past the band: -inf keeps them -inf
             }
         }
         // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401.
-        // previous-row cell c = lane*CPL + t sits at LDS [(t mod CPL)*64 + lane + floor(t/CPL)];
-        // t is wave-uniform (scalar index math); lane + floor(t/CPL) is clamped into the row and
-        // out-of-band candidates are deselected.
+        // previous-row cell lane*CPL + t sits at LDS [(t mod CPL)*LD + lane + t div CPL]; t is
+        // wave-uniform.  Neighbouring cells share reads: pp[j] is cell j's diagonal source and
+        // cell j-1's skip source.  Cells at or past W read -inf.
         double cv[CPL];
         u32 cfw[(CPL + 15) / 16];
 #pragma unroll
         for (int q = 0; q < (CPL + 15) / 16; q++) cfw[q] = 0;
+        {
+            double pp[CPL + 1];
+            if (diff_i <= CPL * QPAD) { // the usual case: every source lane is < 64 + QPAD
 #pragma unroll
-        for (int j = 0; j < CPL; j++) {
-            const int b = b0 + j;
-            const int t1 = j + diff_i - 1;           // >= -1
-            const int q1 = t1 >= 0 ? t1 / CPL : -1;
-            const int r1 = t1 - q1 * CPL;
-            const int t2 = t1 + 1;
-            const int q2 = t2 / CPL;
-            const int r2 = t2 - q2 * CPL;
-            int l1 = lane + q1; l1 = l1 < 0 ? 0 : (l1 > 63 ? 63 : l1);
-            int l2 = lane + q2; l2 = l2 > 63 ? 63 : l2;
-            const double p1 = prev[r1 * 64 + l1];
-            const double p2 = prev[r2 * 64 + l2];
-            const int c1 = b + diff_i - 1;           // previous-row cell of the diagonal move
-            const double d = p1 + z[j];
-            const double s = p2 - skip_pen;
-            bool has_d = b < Wi && c1 < Wi;
-            bool has_s = has_d && c1 + 1 < Wi;
-            if (j == 0) { // band cell 0 (lane 0): skip only when the band did not move, else diag only
-                const bool first = lane == 0;
-                has_d = first ? diff_i != 0 : has_d;
-                has_s = first ? diff_i == 0 : has_s;
+                for (int k = 0; k <= CPL; k++) {
+                    const int t = k + diff_i - 1;            // >= -1
+                    const int q = t >= 0 ? t / CPL : -1;
+                    const int rr = t - q * CPL;
+                    pp[k] = prev[rr * LD + lane + q];        // lane 0, t = -1 reads a pad (-inf)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k <= CPL; k++) {
+                    const int t = k + diff_i - 1;
+                    const int q = t / CPL;
+                    const int rr = t - q * CPL;
+                    const int l = lane + q;
+                    const double x = prev[rr * LD + (l > 63 ? 63 : l)];
+                    pp[k] = l > 63 ? NEG_INF : x;
+                }
             }
-            const bool take_s = has_s && (!has_d || s > d);
-            double c = has_d ? d : NEG_INF;
-            c = take_s ? s : c;
-            const u32 f = take_s ? 1u : (has_d ? 2u : 0u);
-            cv[j] = c;
-            cfw[j / 16] |= f << (2 * (j % 16));
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                const double d = pp[j] + z[j];
+                const double s = pp[j + 1] - skip_pen;
+                bool take_s = s > d;
+                if (j == 0) take_s = lane == 0 ? diff_i == 0 : take_s; // band cell 0: skip xor diag
+                cv[j] = take_s ? s : d;
+                cfw[j / 16] |= (take_s ? 1u : 2u) << (2 * (j % 16));
+            }
         }
         // stay chain: monotone fixed-point sweeps, chunk exit values shifted one lane up
         double in = NEG_INF;
@@ -275,8 +372,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             double x = in;
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
-                double s = (x - stay_pen) + z[j];
-                x = cv[j] > s ? cv[j] : s;
+                x = __builtin_fmax(cv[j], (x - stay_pen) + z[j]);
                 v[j] = x;
             }
             const double nin = wave_shr1_f64(x, NEG_INF);
@@ -287,39 +383,52 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             if (lane == 0) { if (DIRECT) job->status = TBA_INTERNAL; else r.status = TBA_INTERNAL; }
             return;
         }
-        // move codes (0 stay, 1 skip, 2 diag; pyx:216-231), lane-local argmax (pyx:186-197)
-        u32 mvw[CPL / 4];
+        // move codes (0 stay, 1 skip, 2 diag; pyx:216-231) packed 2 bits per cell, lane-local
+        // argmax (pyx:186-197; -inf cells never win)
+        u32 mvw[(CPL + 15) / 16];
 #pragma unroll
-        for (int q = 0; q < CPL / 4; q++) mvw[q] = 0;
+        for (int q = 0; q < (CPL + 15) / 16; q++) mvw[q] = 0;
         double lmax = NEG_INF;
         int lidx = 0;
         {
             double x = in;
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
-                const int b = b0 + j;
-                double s = (x - stay_pen) + z[j];
-                u32 f = cv[j] > s ? ((cfw[j / 16] >> (2 * (j % 16))) & 3u) : 0u;
-                mvw[j / 4] |= f << (8 * (j % 4));
+                const double s = (x - stay_pen) + z[j];
+                const u32 f = cv[j] > s ? ((cfw[j / 16] >> (2 * (j % 16))) & 3u) : 0u;
+                mvw[j / 16] |= f << (2 * (j % 16));
                 x = v[j];
-                const bool better = b < Wi && x > lmax;
+                const bool better = x > lmax;
                 lmax = better ? x : lmax;
-                lidx = better ? b : lidx;
+                lidx = better ? b0 + j : lidx;
             }
         }
-        unsigned char *mrow = mv + (row + 1) * mv_stride + b0;
+        {
+            unsigned char *mrow = mv + (row + 1) * mv_stride + lane * BPL;
+            if constexpr (BPL == 1) *mrow = (unsigned char)mvw[0];
+            else if constexpr (BPL == 2) *(unsigned short *)mrow = (unsigned short)mvw[0];
+            else {
 #pragma unroll
-        for (int q = 0; q < CPL / 4; q++) ((u32 *)mrow)[q] = mvw[q];
+                for (int q = 0; q < BPL / 4; q++) ((u32 *)mrow)[q] = q < (CPL + 15) / 16 ? mvw[q] : 0u;
+            }
+        }
 #pragma unroll
-        for (int j = 0; j < CPL; j++) cur[j * 64 + lane] = v[j];
+        for (int j = 0; j < CPL; j++) cur[j * LD + lane] = v[j];
         if (DIRECT && job->fwd_out != nullptr) {
 #pragma unroll
-            for (int j = 0; j < CPL; j++) job->fwd_out[(row + 1) * mv_stride + b0 + j] = v[j];
+            for (int j = 0; j < CPL; j++) job->fwd_out[(row + 1) * (i64)(64 * CPL) + b0 + j] = v[j];
+        }
+        // event ring upkeep: land the chunk that was in flight, ask for the next one
+        if (!use_z) {
+            if (pf_pending) { ring_store(pf_at + lane, pf); filled = pf_at + 64; pf_pending = false; }
+            if (filled < cur_start + W + 192 && filled < n_ev + W) {
+                pf_at = filled; pf = ev_load(filled + lane); pf_pending = true;
+            }
         }
         // wave argmax, first index among equal maxima
         const double wm = wave_max_f64(lmax);
-        u64 eq = __ballot(lmax == wm && b0 < Wi);
-        am = __shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64);
+        u64 eq = __ballot(lmax == wm && nvalid > 0);
+        am = uni(__shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64));
         prev_start = cur_start;
         __syncthreads();
         double *t = prev; prev = cur; cur = t;
@@ -330,18 +439,30 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     } else {
         double *lr = last_row + (i64)blockIdx.x * TBA_MAX_BAND; // 64*CPL <= TBA_MAX_BAND
 #pragma unroll
-        for (int j = 0; j < CPL; j++) lr[b0 + j] = prev[j * 64 + lane];
+        for (int j = 0; j < CPL; j++) lr[b0 + j] = prev[j * LD + lane];
         if (lane == 0) r.top_pos = am;
     }
 }
 
-// c_banded_traceback (pyx:281-310) on byte moves with padded row stride; python wrap-around
-// indexing of a negative band position kept.  Returns a TBA status.
-__device__ inline int dev_banded_traceback(const unsigned char *mv, i64 stride, i64 n_bases,
-    i64 bw, const i64 *starts, bool identity, i64 band_pos, i64 thresh, i64 *seq_poss)
+// one 2-bit move code out of the packed rows written by k_dp
+__device__ __forceinline__ int mv_get(const unsigned char *mv, i64 row, int cpl, int bpl, i64 b)
 {
+    const i64 lane = b / cpl;
+    const int j = (int)(b - lane * cpl);
+    return (mv[row * (i64)(64 * bpl) + lane * bpl + (j >> 2)] >> (2 * (j & 3))) & 3;
+}
+
+// c_banded_traceback (pyx:281-310); python wrap-around indexing of a negative band position
+// kept.  packed != 0: 2-bit moves in k_dp's row layout (cpl = cells per lane); else one byte per
+// cell with row stride `stride`.  Returns a TBA status.
+__device__ inline int dev_banded_traceback(const unsigned char *mv, i64 stride, int cpl,
+    i64 n_bases, i64 bw, const i64 *starts, bool identity, i64 band_pos, i64 thresh,
+    i64 *seq_poss)
+{
+    const int bpl = cpl ? mv_bpl(cpl) : 0;
 #define ST_AT(r_) (identity ? (i64)(r_) : starts[(r_)])
-#define MV_AT(r_, b_) mv[(r_) * stride + ((b_) < 0 ? (b_) + bw : (b_))]
+#define MV_AT(r_, b_) (cpl ? mv_get(mv, (r_), cpl, bpl, (b_) < 0 ? (b_) + bw : (b_)) \
+                           : (int)mv[(r_) * stride + ((b_) < 0 ? (b_) + bw : (b_))])
     i64 cur_ev = band_pos + ST_AT(n_bases - 1);
     seq_poss[n_bases] = cur_ev + 1;
     for (i64 rr = n_bases; rr > 0; rr--) {
@@ -380,10 +501,9 @@ __global__ void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int 
     const tba_params &P = dp->p;
     const i64 nb = P.start_n_bases;
     const i64 bw = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
-    const i64 stride = (i64)cpl_class(bw) * 64;
     i64 *tb = read_tb + r.seg_off;
-    int rc = dev_banded_traceback(moves + ri * start_moves_stride, stride, nb, bw, nullptr, true,
-                                  r.top_pos, -1, tb);
+    int rc = dev_banded_traceback(moves + ri * start_moves_stride, 0, cpl_class(bw), nb, bw,
+                                  nullptr, true, r.top_pos, -1, tb);
     const double *ev = event_means + r.ev_off;
     if (rc == TBA_OK && mode == DP_START_TRY && dp->o.check_start_score) {
         const double *mu = ref_means + r.ref_off, *sd = ref_sds + r.ref_off;
@@ -466,7 +586,7 @@ __global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *ban
             bst[i] = s; lo_a[i] = 0; hi_a[i] = (i32)Ws;
         }
         r.path = PATH_STATIC; r.clip = 0; r.offset = 0; r.W = Ws; r.n_static = seq_len;
-        r.moves_off = (seq_len + 1) * (i64)cpl_class(Ws) * 64;
+        r.moves_off = (seq_len + 1) * (i64)mv_bpl(cpl_class(Ws)) * 64;
         return;
     }
     // _get_masked_start_fwd_pass on event_means[clip:]
@@ -507,7 +627,7 @@ __global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *ban
         hi_a[sp] = (i32)(sml + nzs);
     }
     r.path = PATH_ADAPTIVE; r.clip = clip; r.offset = offset; r.W = bw; r.n_static = msl;
-    r.moves_off = (r.B + 1) * (i64)cpl_class(bw) * 64;
+    r.moves_off = (r.B + 1) * (i64)mv_bpl(cpl_class(bw)) * 64;
 }
 
 // exclusive scan of the per-read moves sizes into arena offsets (single thread; N is small)
@@ -539,7 +659,7 @@ __global__ void k_main_tb(ReadState *rs, i64 n_reads, const DevParams *dp,
     const i64 B = r.B, W = r.W;
     i64 *tb = read_tb + r.seg_off;
     const bool adaptive = r.path == PATH_ADAPTIVE;
-    int rc = dev_banded_traceback(moves + r.moves_off, (i64)cpl_class(W) * 64, B, W,
+    int rc = dev_banded_traceback(moves + r.moves_off, 0, cpl_class(W), B, W,
                                   band_starts + r.ref_off, false, r.top_pos,
                                   adaptive ? dp->p.band_bound_thresh : -1, tb);
     if (rc != TBA_OK) { r.status = rc; return; }

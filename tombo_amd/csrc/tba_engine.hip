@@ -191,7 +191,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
         const bool short_read = n_ev < p->start_bw + p->start_n_bases || B < p->start_n_bases;
         int cpl = cpl_main;
         if (short_read) cpl = std::max(cpl, cpl_class(std::min<i64>(n_ev, TBA_MAX_BAND)));
-        moves_need += (B + 1) * 64 * (i64)(cpl > 0 ? cpl : 48);
+        moves_need += (B + 1) * 64 * (i64)mv_bpl(cpl > 0 ? cpl : 48);
         // algorithmic traffic: raw in + seq + norm out + segs + band starts +
         // 2-bit moves + scalars
         algo_bytes += 8.0 * r.n_raw + (double)r.seq_len + 8.0 * r.n_raw + 8.0 * (B + 1) + 8.0 * B +
@@ -212,7 +212,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     const i64 start_w = std::max(p->start_bw, p->start_save_bw);
     if (cpl_class(p->start_bw) == 0 || cpl_class(p->start_save_bw) == 0 || cpl_main == 0)
         return set_err(TBA_E_ARG, "bandwidth / start bandwidth above TBA_MAX_BAND");
-    e->start_moves_stride = (p->start_n_bases + 1) * 64 * (i64)cpl_class(start_w);
+    e->start_moves_stride = (p->start_n_bases + 1) * 64 * (i64)mv_bpl(cpl_class(start_w));
     e->moves_arena = moves_need + moves_need / 8 + (64ll << 20);
 
     const size_t S = (size_t)std::max<i64>(e->S_tot, 1), Bt = (size_t)std::max<i64>(e->B_tot, 1),
@@ -519,9 +519,10 @@ static void launch_direct(tba_engine *e, int cpl, DpJob *job)
 static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i64 row0,
                          double *fwd_host, int64_t *tb_host, int64_t *starts_host, i64 starts_from)
 {
-    const i64 stride = (i64)cpl * 64;
+    const i64 stride = (i64)cpl * 64;            // forward rows
+    const i64 mstride = (i64)mv_bpl(cpl) * 64;   // packed 2-bit move rows
     Tmp d_fwd, d_mv, d_job;
-    if (d_fwd.alloc((size_t)(n_rows + 1) * stride * 8) || d_mv.alloc((size_t)(n_rows + 1) * stride) ||
+    if (d_fwd.alloc((size_t)(n_rows + 1) * stride * 8) || d_mv.alloc((size_t)(n_rows + 1) * mstride) ||
         d_job.alloc(sizeof(DpJob)))
         return set_err(TBA_E_NOMEM, "hipMalloc failed");
     // the kernel needs *some* ReadState / DevParams to bind its references to
@@ -533,7 +534,7 @@ static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i6
     launch_direct(e, cpl, d_job.as<DpJob>());
     C_TRY(hipGetLastError());
     C_TRY(hipMemcpyAsync(&hj, d_job.p, sizeof(DpJob), hipMemcpyDeviceToHost, e->stream));
-    std::vector<unsigned char> mv((size_t)(n_rows + 1) * stride);
+    std::vector<unsigned char> mv((size_t)(n_rows + 1) * mstride);
     C_TRY(hipMemcpyAsync(mv.data(), d_mv.p, mv.size(), hipMemcpyDeviceToHost, e->stream));
     C_TRY(hipStreamSynchronize(e->stream));
     if (hj.status != TBA_OK) return hj.status;
@@ -545,8 +546,13 @@ static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i6
         for (i64 r = row0 == 0 ? 0 : row0 + 1; r <= n_rows; r++)
             memcpy(fwd_host + r * W, fw.data() + r * stride, (size_t)W * 8);
     }
+    const int bpl = mv_bpl(cpl);
     for (i64 r = row0 + 1; r <= n_rows; r++)
-        for (i64 b = 0; b < W; b++) tb_host[r * W + b] = mv[(size_t)(r * stride + b)];
+        for (i64 b = 0; b < W; b++) {
+            const i64 ln = b / cpl;
+            const int j = (int)(b - ln * cpl);
+            tb_host[r * W + b] = (mv[(size_t)(r * mstride + ln * bpl + (j >> 2))] >> (2 * (j & 3))) & 3;
+        }
     if (starts_host)
         C_TRY(hipMemcpy(starts_host + starts_from, hj.starts + starts_from,
                         (size_t)(n_rows - starts_from) * 8, hipMemcpyDeviceToHost));
@@ -745,4 +751,21 @@ extern "C" int tba_c_valid_cpts_w_cap_t_test(tba_engine *e, const double *sig, i
     int64_t min_base_obs, int64_t running_stat_width, int64_t num_cpts, int64_t *cpts)
 {
     return c_valid_cpts(e, sig, n, min_base_obs, running_stat_width, num_cpts, cpts, 1);
+}
+
+extern "C" int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,
+                                     double *out)
+{
+    if (!e || !a || !b || !out || n < 1) return set_err(TBA_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_a, d_b, d_o;
+    if (d_a.alloc((size_t)n * 8) || d_b.alloc((size_t)n * 8) || d_o.alloc((size_t)n * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_a.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_b.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
+    k_c_div_check<<<grid_for(n), 256, 0, e->stream>>>(d_a.as<double>(), d_b.as<double>(), n, d_o.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(out, d_o.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
 }
