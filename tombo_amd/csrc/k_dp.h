@@ -52,6 +52,13 @@ __device__ __forceinline__ double wave_shr1_f64(double x, double lane0_val)
     hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0_val), hi, 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double wave_shl1_f64(double x, double lane63_val) // lane i <- lane i+1
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(lane63_val), lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane63_val), hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_mov_f64(double x)
 {
@@ -88,11 +95,9 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
     return __builtin_fma(e, y, q);
 }
 
-// bytes of packed 2-bit moves per lane per row (4 cells per byte), padded to a store width
-__host__ __device__ constexpr int mv_bpl(int cpl)
-{
-    return cpl <= 4 ? 1 : cpl <= 8 ? 2 : cpl <= 16 ? 4 : cpl <= 32 ? 8 : 12;
-}
+// bytes of packed 2-bit moves per lane per row: 4 cells per byte, so a row is plainly linear
+// (cell b -> byte b/4, bits 2*(b%4)) and 16*CPL bytes long
+__host__ __device__ constexpr int mv_bpl(int cpl) { return cpl / 4; }
 
 // wave-uniform values the compiler cannot prove uniform (they come from vector loads or
 // shuffles) are moved to scalar registers explicitly, so that control flow on them is scalar
@@ -107,11 +112,39 @@ template <class T> __device__ __forceinline__ T *uni(T *p) { return (T *)uni((i6
 __device__ __forceinline__ double uni(double x) { return __longlong_as_double((long long)uni((i64)__double_as_longlong(x))); }
 __device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
 
-// Row body is straight-line code; the only branches are wave-uniform (static vs adaptive row,
-// masked row, band-jump size, sweep loop).  Data flow per row:
-//   events   : LDS ring of the read's event means around the band (refilled by coalesced
-//              prefetches one chunk ahead, so no global-load latency sits on the row chain)
-//   prev row : LDS, cells >= W hold -inf so out-of-band candidates need no guards
+// Previous-row access without memory: every lane keeps its CPL cells of the previous row in
+// registers; the cells a row needs are that row shifted by the (wave-uniform) band offset, i.e. a
+// compile-time register renaming per offset plus a few wave_shl DPP moves for the cells that come
+// from the next lane.  A[k] = previous-row cell (lane*CPL + D + k - 1), k = 0..CPL.
+template <int CPL, int D>
+__device__ __forceinline__ void shifted_row(const double (&Q)[CPL], double left, double (&A)[CPL + 1])
+{
+#pragma unroll
+    for (int k = 0; k <= CPL; k++) {
+        const int idx = k - 1 + D;
+        if (idx < 0) A[k] = left;
+        else if (idx < CPL) A[k] = Q[idx];
+        else A[k] = wave_shl1_f64(Q[idx - CPL], -INFINITY);
+    }
+}
+// Q <- Q shifted by S cells (S <= CPL); returns the cell just left of the new Q[0]
+template <int CPL, int S>
+__device__ __forceinline__ double shift_cells(double (&Q)[CPL])
+{
+    double T[CPL];
+    const double left = Q[S - 1];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) T[k] = k + S < CPL ? Q[k + S] : wave_shl1_f64(Q[k + S - CPL], -INFINITY);
+#pragma unroll
+    for (int k = 0; k < CPL; k++) Q[k] = T[k];
+    return left;
+}
+
+// Row body: the only branches are wave-uniform (static vs adaptive row, masked row, band offset
+// switch, sweep loop).  Data flow per row:
+//   events   : linear LDS ring of the read's event means around the band, refilled by coalesced
+//              prefetches one chunk ahead (no global-load latency on the row chain)
+//   prev row : registers + DPP (above); cells >= W hold -inf so out-of-band candidates need no guards
 //   mu/sd    : prefetched one row ahead
 template <int CPL, bool DIRECT>
 __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, int mode,
@@ -119,13 +152,10 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,
     unsigned char *moves, i64 start_moves_stride, double *last_row, DpJob *job)
 {
-    constexpr int QPAD = 4;              // extra "lanes" of -inf at the end of each LDS row slice
-    constexpr int LD = 64 + QPAD;
-    constexpr int RL = 128;              // ring: 128 slots per residue class -> 128*CPL events
-    constexpr int RING = RL * CPL;
+    constexpr int S = CPL < 8 ? CPL : 8;     // band offsets 0..S take the register-renaming path
+    constexpr int RING = CPL <= 4 ? 512 : CPL <= 8 ? 1024 : CPL <= 16 ? 2048 : CPL <= 32 ? 4096 : 8192; // power of two >= 128*CPL
     constexpr int BPL = mv_bpl(CPL);
-    __shared__ double rows[2][CPL * LD];
-    __shared__ double ring[RING];
+    __shared__ double ring[RING + CPL];      // + mirror of the first CPL slots: reads never wrap
     ReadState &r = rs[DIRECT ? 0 : blockIdx.x];
     if (!DIRECT && r.status != TBA_OK) return;
     const tba_params &P = dp->p;
@@ -196,10 +226,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     nvalid = nvalid < 0 ? 0 : (nvalid > CPL ? CPL : nvalid);
     const double zcap = winsor ? max_half_z : INFINITY; // no winsorising: clamp at +inf
 
-    // LDS rows: everything -inf (cells past the band and the pad lanes stay -inf for good)
-    for (int k = lane; k < 2 * CPL * LD; k += 64) (&rows[0][0])[k] = NEG_INF;
-    __syncthreads();
-    double *prev = rows[0], *cur = rows[1];
+    double v[CPL]; // my cells of the previous row (cells past the band: -inf for good)
     i64 prev_start = 0;
     i64 am = 0; // argmax of the previous row (row 0: all zeros -> 0)
     if (DIRECT && job->init_row != nullptr) {
@@ -212,7 +239,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             const int b = b0 + j;
             double x = job->init_row[j < nvalid ? b : Wi - 1];
             x = j < nvalid ? x : NEG_INF;
-            prev[j * LD + lane] = x;
+            v[j] = x;
             const bool better = x > lmax;
             lmax = better ? x : lmax;
             lidx = better ? b : lidx;
@@ -223,21 +250,22 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         if (row0 > 0) prev_start = uni(bst[row0 - 1]);
     } else {
 #pragma unroll
-        for (int j = 0; j < CPL; j++) prev[j * LD + lane] = j < nvalid ? 0.0 : NEG_INF; // row 0: zeros
+        for (int j = 0; j < CPL; j++) v[j] = j < nvalid ? 0.0 : NEG_INF; // row 0: zeros (pyx:253-254)
     }
     if (DIRECT && job->fwd_out != nullptr && row0 == 0) {
 #pragma unroll
         for (int j = 0; j < CPL; j++) job->fwd_out[b0 + j] = 0.0; // rows padded to 64*CPL
     }
 
-    // event ring: absolute event index a (shifted by RING so it is never negative) lives at
-    // [(a' mod CPL) * RL + (a' div CPL) mod RL]; filled = first absolute index not yet loaded
+    // event ring: absolute event index a lives at slot (a + RING) & (RING - 1) (plus a mirror of
+    // slots 0..CPL-1 behind the end); filled = first absolute index not yet loaded
     i64 filled = 0;
     auto ring_store = [&](i64 a, double x) {
-        const i64 ap = a + RING;
-        ring[(int)(ap % CPL) * RL + (int)((ap / CPL) & (RL - 1))] = x;
+        const int sl = (int)((a + RING) & (RING - 1));
+        ring[sl] = x;
+        if (sl < CPL) ring[RING + sl] = x;
     };
-    auto ev_load = [&](i64 a) { // clamped load + select: no divergent branch in the row loop
+    auto ev_load = [&](i64 a) { // clamped load + select
         const i64 ac = a < 0 ? 0 : (a >= n_ev ? n_ev - 1 : a);
         const double x = ev[ac];
         return (a >= 0 && a < n_ev) ? x : 0.0;
@@ -266,7 +294,6 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     };
     fetch_row(row0);
 
-    double v[CPL];
     for (i64 row = row0; row < n_rows; row++) {
         const double mu = mu_n, sd = sd_n;
         i64 cur_start;
@@ -303,57 +330,46 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 z[j] = j < nvalid ? zz : NEG_INF;
             }
         } else {
-            // make sure the ring covers [cur_start, cur_start + W) (only a large band jump gets here)
-            if (cur_start + W > filled) {
+            // make sure the ring covers [cur_start, cur_start + 64*CPL) (only a large band jump
+            // gets here; the prefetch below normally stays ahead)
+            if (cur_start + 64 * CPL > filled) {
                 if (pf_pending) { ring_store(pf_at + lane, pf); filled = pf_at + 64; pf_pending = false; }
-                while (cur_start + W > filled) { ring_store(filled + lane, ev_load(filled + lane)); filled += 64; }
-                __syncthreads();
+                while (cur_start + 64 * CPL > filled) { ring_store(filled + lane, ev_load(filled + lane)); filled += 64; }
             }
             const double y = 1.0 / sd;
-            const i64 up = cur_start + RING;                    // >= 0
-            const int u0 = (int)(up % CPL), c0 = (int)(up / CPL);
-            const int a0 = ((lane + c0) & (RL - 1)), a1 = ((lane + c0 + 1) & (RL - 1));
+            const double *er = ring + (int)((cur_start + RING + b0) & (RING - 1)); // + j < RING + CPL
             const bool full = lo == 0 && hi == Wi;
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
-                const int t = u0 + j;                            // < 2*CPL
-                const int rr = t >= CPL ? t - CPL : t;
-                const double e = ring[rr * RL + (t >= CPL ? a1 : a0)];
-                double pz = fabs(div_by_recip(e - mu, sd, y));
+                double pz = fabs(div_by_recip(er[j] - mu, sd, y));
                 pz = __builtin_fmin(pz, zcap);
                 double zz = z_shift - pz;
                 if (!full) zz = (b0 + j >= lo && b0 + j < hi) ? zz : fill;
                 z[j] = j < nvalid ? zz : NEG_INF; // cells past the band: -inf keeps them -inf
             }
         }
-        // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401.
-        // previous-row cell lane*CPL + t sits at LDS [(t mod CPL)*LD + lane + t div CPL]; t is
-        // wave-uniform.  Neighbouring cells share reads: pp[j] is cell j's diagonal source and
-        // cell j-1's skip source.  Cells at or past W read -inf.
+        // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401:
+        // pp[j] is cell j's diagonal source and cell j-1's skip source
         double cv[CPL];
         u32 cfw[(CPL + 15) / 16];
 #pragma unroll
         for (int q = 0; q < (CPL + 15) / 16; q++) cfw[q] = 0;
         {
             double pp[CPL + 1];
-            if (diff_i <= CPL * QPAD) { // the usual case: every source lane is < 64 + QPAD
-#pragma unroll
-                for (int k = 0; k <= CPL; k++) {
-                    const int t = k + diff_i - 1;            // >= -1
-                    const int q = t >= 0 ? t / CPL : -1;
-                    const int rr = t - q * CPL;
-                    pp[k] = prev[rr * LD + lane + q];        // lane 0, t = -1 reads a pad (-inf)
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k <= CPL; k++) {
-                    const int t = k + diff_i - 1;
-                    const int q = t / CPL;
-                    const int rr = t - q * CPL;
-                    const int l = lane + q;
-                    const double x = prev[rr * LD + (l > 63 ? 63 : l)];
-                    pp[k] = l > 63 ? NEG_INF : x;
-                }
+            int rem = diff_i;
+            double left = NEG_INF;
+            while (rem > S) { left = shift_cells<CPL, S>(v); rem -= S; } // rare: big band jump
+            switch (rem) {
+            case 0: left = diff_i == 0 ? wave_shr1_f64(v[CPL - 1], NEG_INF) : left;
+                    shifted_row<CPL, 0>(v, left, pp); break;
+            case 1: shifted_row<CPL, 1>(v, left, pp); break;
+            case 2: if constexpr (S >= 2) shifted_row<CPL, 2>(v, left, pp); break;
+            case 3: if constexpr (S >= 3) shifted_row<CPL, 3>(v, left, pp); break;
+            case 4: if constexpr (S >= 4) shifted_row<CPL, 4>(v, left, pp); break;
+            case 5: if constexpr (S >= 5) shifted_row<CPL, 5>(v, left, pp); break;
+            case 6: if constexpr (S >= 6) shifted_row<CPL, 6>(v, left, pp); break;
+            case 7: if constexpr (S >= 7) shifted_row<CPL, 7>(v, left, pp); break;
+            default: if constexpr (S >= 8) shifted_row<CPL, 8>(v, left, pp); break;
             }
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
@@ -407,13 +423,14 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             unsigned char *mrow = mv + (row + 1) * mv_stride + lane * BPL;
             if constexpr (BPL == 1) *mrow = (unsigned char)mvw[0];
             else if constexpr (BPL == 2) *(unsigned short *)mrow = (unsigned short)mvw[0];
-            else {
+            else if constexpr (BPL % 4 == 0) {
 #pragma unroll
-                for (int q = 0; q < BPL / 4; q++) ((u32 *)mrow)[q] = q < (CPL + 15) / 16 ? mvw[q] : 0u;
+                for (int q = 0; q < BPL / 4; q++) ((u32 *)mrow)[q] = mvw[q];
+            } else { // 3 or 6 bytes per lane
+#pragma unroll
+                for (int q = 0; q < BPL; q++) mrow[q] = (unsigned char)(mvw[q / 4] >> (8 * (q % 4)));
             }
         }
-#pragma unroll
-        for (int j = 0; j < CPL; j++) cur[j * LD + lane] = v[j];
         if (DIRECT && job->fwd_out != nullptr) {
 #pragma unroll
             for (int j = 0; j < CPL; j++) job->fwd_out[(row + 1) * (i64)(64 * CPL) + b0 + j] = v[j];
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         // event ring upkeep: land the chunk that was in flight, ask for the next one
         if (!use_z) {
             if (pf_pending) { ring_store(pf_at + lane, pf); filled = pf_at + 64; pf_pending = false; }
-            if (filled < cur_start + W + 192 && filled < n_ev + W) {
+            if (filled < cur_start + 64 * CPL + 192 && filled < n_ev + 64 * CPL) {
                 pf_at = filled; pf = ev_load(filled + lane); pf_pending = true;
             }
         }
@@ -430,8 +447,6 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         u64 eq = __ballot(lmax == wm && nvalid > 0);
         am = uni(__shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64));
         prev_start = cur_start;
-        __syncthreads();
-        double *t = prev; prev = cur; cur = t;
     }
     // last row + traceback start (np.argmax of the last row, resquiggle.py:728,1032)
     if constexpr (DIRECT) {
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     } else {
         double *lr = last_row + (i64)blockIdx.x * TBA_MAX_BAND; // 64*CPL <= TBA_MAX_BAND
 #pragma unroll
-        for (int j = 0; j < CPL; j++) lr[b0 + j] = prev[j * LD + lane];
+        for (int j = 0; j < CPL; j++) lr[b0 + j] = v[j];
         if (lane == 0) r.top_pos = am;
     }
 }
@@ -447,9 +462,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
 // one 2-bit move code out of the packed rows written by k_dp
 __device__ __forceinline__ int mv_get(const unsigned char *mv, i64 row, int cpl, int bpl, i64 b)
 {
-    const i64 lane = b / cpl;
-    const int j = (int)(b - lane * cpl);
-    return (mv[row * (i64)(64 * bpl) + lane * bpl + (j >> 2)] >> (2 * (j & 3))) & 3;
+    (void)cpl;
+    return (mv[row * (i64)(64 * bpl) + (b >> 2)] >> (2 * (b & 3))) & 3;
 }
 
 // c_banded_traceback (pyx:281-310); python wrap-around indexing of a negative band position
@@ -646,46 +660,118 @@ __global__ void k_scan_moves(ReadState *rs, i64 n_reads, i64 arena_bytes)
 }
 
 // main traceback + _trim_traceback (resquiggle.py:754-764) + get_rel_raw_coords (:858-864).
-// One thread per read.
-__global__ void k_main_tb(ReadState *rs, i64 n_reads, const DevParams *dp,
+// One wavefront per read: the packed move rows are streamed through LDS in coalesced chunks
+// (the pointer chase of c_banded_traceback then runs at LDS latency instead of HBM latency, one
+// lane walking), the event -> raw coordinate gather at the end uses all lanes.
+#define TBW_BYTES 16384
+__global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, const DevParams *dp,
     const unsigned char *moves, const i64 *band_starts, const i64 *valid_cpts, i64 *read_tb,
     i64 *dp_segs)
 {
-    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ri >= n_reads) return;
-    ReadState &r = rs[ri];
+    __shared__ __attribute__((aligned(16))) unsigned char s_mv[TBW_BYTES];
+    __shared__ i64 s_st[TBW_BYTES / 64 + 1];
+    __shared__ i64 s_out[TBW_BYTES / 64 + 1];
+    __shared__ i64 s_state[4]; // cur_ev, status, rows done marker
+    ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
-    if (r.path == PATH_NONE) { r.status = TBA_INTERNAL; return; }
+    const int lane = threadIdx.x;
+    if (r.path == PATH_NONE) { if (lane == 0) r.status = TBA_INTERNAL; return; }
     const i64 B = r.B, W = r.W;
+    const int Wi = (int)W;
+    const int cpl = cpl_class(W), bpl = mv_bpl(cpl);
+    const i64 rowb = (i64)64 * bpl;
+    const int chunk = (int)(TBW_BYTES / rowb);          // rows per LDS chunk (>= 21)
+    const unsigned char *mv = moves + r.moves_off;
+    const i64 *st = band_starts + r.ref_off;
     i64 *tb = read_tb + r.seg_off;
     const bool adaptive = r.path == PATH_ADAPTIVE;
-    int rc = dev_banded_traceback(moves + r.moves_off, 0, cpl_class(W), B, W,
-                                  band_starts + r.ref_off, false, r.top_pos,
-                                  adaptive ? dp->p.band_bound_thresh : -1, tb);
-    if (rc != TBA_OK) { r.status = rc; return; }
-    const i64 n_ev = r.n_ev - r.clip;
-    if (adaptive) {
-        i64 i = 0;
-        while (tb[i] < 0) { tb[i] = 0; i++; if (i > B) { r.status = TBA_INTERNAL; return; } }
-        i64 j = 1;
-        while (tb[B + 1 - j] > n_ev) { tb[B + 1 - j] = n_ev; j++; if (j > B + 1) { r.status = TBA_INTERNAL; return; } }
-    } else {
-        for (i64 i = 0; i <= B; i++)
-            if (tb[i] < -(n_ev + 1) || tb[i] > n_ev) { r.status = TBA_INTERNAL; return; }
+    const i64 thresh = adaptive ? dp->p.band_bound_thresh : -1;
+    if (lane == 0) {
+        const i64 cur_ev = r.top_pos + st[B - 1];
+        tb[B] = cur_ev + 1;
+        s_state[0] = cur_ev; s_state[1] = TBA_OK;
     }
+    __syncthreads();
+    // rows hi .. lo (inclusive), hi descending from B; row rr uses starts[rr-1]
+    for (i64 hi = B; hi >= 1; hi -= chunk) {
+        const i64 lo = hi - chunk + 1 < 1 ? 1 : hi - chunk + 1;
+        const i64 nrow = hi - lo + 1;
+        { // coalesced copy of rows lo..hi (contiguous in memory) into LDS, 16 bytes per lane
+            const i64 nbytes = nrow * rowb;
+            const uint4 *src = (const uint4 *)(mv + lo * rowb); // arena offsets / rows are 64-B multiples
+            uint4 *dst = (uint4 *)s_mv;
+            for (i64 k = lane; k < nbytes / 16; k += 64) dst[k] = src[k];
+            for (i64 k = lane; k < nrow; k += 64) s_st[k] = st[lo - 1 + k];
+        }
+        __syncthreads();
+        if (lane == 0 && s_state[1] == TBA_OK) {
+            i64 cur_ev = s_state[0];
+            int rc = TBA_OK;
+            for (i64 rr = hi; rr >= lo; rr--) {
+                const i64 stv = s_st[rr - lo];
+                const i64 bp64 = cur_ev - stv;
+                if (bp64 >= W || bp64 < -W) { rc = TBA_INTERNAL; break; }
+                int band_pos = (int)bp64;
+                const unsigned char *row = s_mv + (rr - lo) * rowb;
+#define MVL(b_) ({ int bb_ = (b_) < 0 ? (b_) + Wi : (b_); (int)((row[bb_ >> 2] >> (2 * (bb_ & 3))) & 3); })
+                int m = MVL(band_pos);
+                while (m == 0) {
+                    band_pos--;
+                    if (band_pos < -Wi) { rc = TBA_INTERNAL; break; }
+                    m = MVL(band_pos);
+                }
+                if (rc != TBA_OK) break;
+                if (m == 2) band_pos--;
+#undef MVL
+                if (thresh >= 0) {
+                    const int a = band_pos, b2 = Wi - band_pos - 1;
+                    if ((a < b2 ? a : b2) < thresh) { rc = TBA_BEYOND_BANDWIDTH; break; }
+                }
+                cur_ev = stv + band_pos;
+                s_out[rr - lo] = cur_ev + 1;
+            }
+            s_state[0] = cur_ev; s_state[1] = rc;
+        }
+        __syncthreads();
+        if (s_state[1] != TBA_OK) break;
+        for (i64 k = lane; k < nrow; k += 64) tb[lo - 1 + k] = s_out[k]; // seq_poss[rr-1]
+        __syncthreads();
+    }
+    if (s_state[1] != TBA_OK) { if (lane == 0) r.status = (i32)s_state[1]; return; }
+    __threadfence_block();
+    const i64 n_ev = r.n_ev - r.clip;
+    if (lane == 0) {
+        int rc = TBA_OK;
+        if (adaptive) {
+            i64 i = 0;
+            while (tb[i] < 0) { tb[i] = 0; i++; if (i > B) { rc = TBA_INTERNAL; break; } }
+            i64 j = 1;
+            while (rc == TBA_OK && tb[B + 1 - j] > n_ev) { tb[B + 1 - j] = n_ev; j++; if (j > B + 1) { rc = TBA_INTERNAL; break; } }
+        }
+        s_state[1] = rc;
+    }
+    __syncthreads();
+    if (s_state[1] != TBA_OK) { if (lane == 0) r.status = (i32)s_state[1]; return; }
     const i64 *c = valid_cpts + r.ev_off + r.clip;
     const i64 n_c = n_ev + 1;
     i64 *sg = dp_segs + r.seg_off;
+    int bad = 0;
+    if (!adaptive)
+        for (i64 i = lane; i <= B; i += 64) bad |= tb[i] < -(n_ev + 1) || tb[i] > n_ev;
+    if (__syncthreads_or(bad)) { if (lane == 0) r.status = TBA_INTERNAL; return; }
     i64 t0 = tb[0];
     if (t0 < 0) t0 += n_c;
     const i64 first = c[t0];
-    for (i64 i = 0; i <= B; i++) {
+    for (i64 i = lane; i <= B; i += 64) {
         i64 t = tb[i];
         if (t < 0) t += n_c;
         sg[i] = c[t] - first;
     }
-    r.dp_read_start = first;
-    r.read_start = first;
-    r.norm_len = sg[B];
-    if (first < 0 || r.norm_len < 0 || first + r.norm_len > r.n_raw) r.status = TBA_INTERNAL;
+    __syncthreads();
+    if (lane == 0) {
+        r.dp_read_start = first;
+        r.read_start = first;
+        r.norm_len = sg[B];
+        if (first < 0 || r.norm_len < 0 || first + r.norm_len > r.n_raw) r.status = TBA_INTERNAL;
+    }
 }

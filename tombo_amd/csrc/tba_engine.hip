@@ -346,7 +346,7 @@ extern "C" int tba_batch_enqueue(tba_engine *e)
         for (int c : cls) launch_dp(e, c, DP_MAIN);
     }
     MARK(); // 10 main tb
-    k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
+    k_main_tb<<<nb, 64, 0, s>>>(rs, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
     MARK(); // 11 skip resolve
     k_skip_plan<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
     k_scan_skip<<<1, 64, 0, s>>>(rs, n, e->skip_arena);
@@ -546,13 +546,9 @@ static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i6
         for (i64 r = row0 == 0 ? 0 : row0 + 1; r <= n_rows; r++)
             memcpy(fwd_host + r * W, fw.data() + r * stride, (size_t)W * 8);
     }
-    const int bpl = mv_bpl(cpl);
     for (i64 r = row0 + 1; r <= n_rows; r++)
-        for (i64 b = 0; b < W; b++) {
-            const i64 ln = b / cpl;
-            const int j = (int)(b - ln * cpl);
-            tb_host[r * W + b] = (mv[(size_t)(r * mstride + ln * bpl + (j >> 2))] >> (2 * (j & 3))) & 3;
-        }
+        for (i64 b = 0; b < W; b++)
+            tb_host[r * W + b] = (mv[(size_t)(r * mstride + (b >> 2))] >> (2 * (b & 3))) & 3;
     if (starts_host)
         C_TRY(hipMemcpy(starts_host + starts_from, hj.starts + starts_from,
                         (size_t)(n_rows - starts_from) * 8, hipMemcpyDeviceToHost));
