@@ -338,15 +338,19 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             }
             const double y = 1.0 / sd;
             const double *er = ring + (int)((cur_start + RING + b0) & (RING - 1)); // + j < RING + CPL
-            const bool full = lo == 0 && hi == Wi;
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
                 double pz = fabs(div_by_recip(er[j] - mu, sd, y));
                 pz = __builtin_fmin(pz, zcap);
-                double zz = z_shift - pz;
-                if (!full) zz = (b0 + j >= lo && b0 + j < hi) ? zz : fill;
-                z[j] = j < nvalid ? zz : NEG_INF; // cells past the band: -inf keeps them -inf
+                z[j] = z_shift - pz;
             }
+            if (__builtin_expect(lo != 0 || hi != Wi, 0)) { // masked start rows / band past the last event
+#pragma unroll
+                for (int j = 0; j < CPL; j++) z[j] = (b0 + j >= lo && b0 + j < hi) ? z[j] : fill;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; j++) z[j] = j < nvalid ? z[j] : NEG_INF; // past the band: stays -inf
         }
         // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401:
         // pp[j] is cell j's diagonal source and cell j-1's skip source
@@ -714,11 +718,35 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, const DevParams *
                 int band_pos = (int)bp64;
                 const unsigned char *row = s_mv + (rr - lo) * rowb;
 #define MVL(b_) ({ int bb_ = (b_) < 0 ? (b_) + Wi : (b_); (int)((row[bb_ >> 2] >> (2 * (bb_ & 3))) & 3); })
-                int m = MVL(band_pos);
-                while (m == 0) {
-                    band_pos--;
-                    if (band_pos < -Wi) { rc = TBA_INTERNAL; break; }
-                    m = MVL(band_pos);
+                int m;
+                {
+                    // fast path: one 64-bit window of 2-bit codes ending at band_pos (two aligned
+                    // dword reads); the highest non-zero field at or below band_pos ends the run of
+                    // stays.  Falls back to the cell-by-cell walk at the row start / wrap-around.
+                    const u32 *row32 = (const u32 *)row;
+                    const int wi = band_pos >> 4;
+                    bool done = false;
+                    m = 0;
+                    if (band_pos >= 0 && wi >= 1) {
+                        const u64 x0 = ((u64)row32[wi] << 32) | row32[wi - 1];
+                        const int p = 32 + 2 * (band_pos & 15);
+                        const u64 x = p + 2 >= 64 ? x0 : (x0 & ((1ull << (p + 2)) - 1ull));
+                        const u64 nz = (x | (x >> 1)) & 0x5555555555555555ull;
+                        if (nz != 0) {
+                            const int f = (63 - __clzll((long long)nz)) >> 1;
+                            m = (int)((x >> (2 * f)) & 3);
+                            band_pos = 16 * (wi - 1) + f;
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+                        m = MVL(band_pos);
+                        while (m == 0) {
+                            band_pos--;
+                            if (band_pos < -Wi) { rc = TBA_INTERNAL; break; }
+                            m = MVL(band_pos);
+                        }
+                    }
                 }
                 if (rc != TBA_OK) break;
                 if (m == 2) band_pos--;
