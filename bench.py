@@ -164,6 +164,16 @@ def main():
         i_dp = _native.STAGE_NAMES.index('main_dp')
         dp_ms = float(stage[i_dp])
         achieved = algo_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+        # HBM traffic of that kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes
+        # (profiles/r01b_pmc_hbm_traffic.json, bytes per read), scaled to this launch
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01b_pmc_hbm_traffic.json')) as fp:
+                pmc = json.load(fp)
+            if a.bases == 10000 and a.bandwidth == 500:
+                traffic = float(pmc['k_dp_bytes_per_read']) * a.reads
+        except (IOError, KeyError, ValueError):
+            pass
         res = {
             'metric': 'resquiggle reads/s (10 kb DNA, bw=500)', 'value': round(value, 2),
             'unit': 'reads/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -180,7 +190,7 @@ def main():
                                     zip(_native.STAGE_NAMES, stage[:16]) if v > 0}},
             'roofline': {'bound': 'hbm', 'kernel': 'k_dp (main adaptive banded forward pass)',
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'algorithmic_bytes_per_launch': algo_bytes,
                          'kernel_ms': round(dp_ms, 3),
                          'dp_cell_updates_per_s': round(dp_cells / (dp_ms * 1e-3), 1)

@@ -648,18 +648,41 @@ __global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *ban
     r.moves_off = (r.B + 1) * (i64)mv_bpl(cpl_class(bw)) * 64;
 }
 
-// exclusive scan of the per-read moves sizes into arena offsets (single thread; N is small)
-__global__ void k_scan_moves(ReadState *rs, i64 n_reads, i64 arena_bytes)
+// exclusive scan of per-read arena sizes (held in `field`) into arena offsets: one workgroup,
+// every thread scans a contiguous chunk of reads.  A read that does not fit the arena gets
+// TBA_UNSUPPORTED (its space is still counted, so later reads may fail with it).
+template <int WHICH> // 0: moves_off (also clears path on failure), 1: skip_off
+__global__ __launch_bounds__(256) void k_scan_arena(ReadState *rs, i64 n_reads, i64 arena)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ i64 s_sum[256];
+    const int tid = threadIdx.x;
+    const i64 chunk = (n_reads + 255) / 256;
+    const i64 a = (i64)tid * chunk, b = a + chunk < n_reads ? a + chunk : n_reads;
     i64 acc = 0;
-    for (i64 i = 0; i < n_reads; i++) {
+    for (i64 i = a; i < b; i++) {
         ReadState &r = rs[i];
-        i64 sz = r.moves_off;
-        if (r.status != TBA_OK || sz == 0) { r.moves_off = 0; continue; }
-        if (acc + sz > arena_bytes) { r.status = TBA_UNSUPPORTED; r.moves_off = 0; r.path = PATH_NONE; continue; }
-        r.moves_off = acc;
+        i64 sz = WHICH == 0 ? r.moves_off : r.skip_off;
+        if (r.status != TBA_OK) sz = 0;
         acc += sz;
+    }
+    s_sum[tid] = acc;
+    __syncthreads();
+    if (tid == 0) { i64 run = 0; for (int t = 0; t < 256; t++) { i64 c = s_sum[t]; s_sum[t] = run; run += c; } }
+    __syncthreads();
+    acc = s_sum[tid];
+    for (i64 i = a; i < b; i++) {
+        ReadState &r = rs[i];
+        i64 sz = WHICH == 0 ? r.moves_off : r.skip_off;
+        if (r.status != TBA_OK) sz = 0;
+        i64 off = acc;
+        acc += sz;
+        if (sz != 0 && off + sz > arena) {
+            r.status = TBA_UNSUPPORTED;
+            if (WHICH == 0) r.path = PATH_NONE;
+            off = 0;
+        }
+        if (sz == 0) off = 0;
+        if (WHICH == 0) r.moves_off = off; else r.skip_off = off;
     }
 }
 

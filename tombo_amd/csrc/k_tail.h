@@ -195,21 +195,6 @@ __global__ void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp, con
     r.skip_off = acc;
 }
 
-// exclusive scan of the per-read scratch needs into arena offsets (single thread)
-__global__ void k_scan_skip(ReadState *rs, i64 n_reads, i64 arena_units)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    i64 acc = 0;
-    for (i64 i = 0; i < n_reads; i++) {
-        ReadState &r = rs[i];
-        i64 sz = r.skip_off;
-        if (r.status != TBA_OK || sz == 0) { r.skip_off = 0; continue; }
-        if (acc + sz > arena_units) { r.status = TBA_UNSUPPORTED; r.skip_off = 0; continue; }
-        r.skip_off = acc;
-        acc += sz;
-    }
-}
-
 // rq.resolve_skipped_bases_with_raw window loop + final checks (resquiggle.py:500-538).
 // One wavefront per read, one window per lane at a time (windows own disjoint boundary ranges).
 __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *dp,

@@ -339,7 +339,7 @@ extern "C" int tba_batch_enqueue(tba_engine *e)
     k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_RETRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
     MARK(); // 8 prep
     k_prep<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_bst.as<i64>(), e->d_lo.as<i32>(), e->d_hi.as<i32>());
-    k_scan_moves<<<1, 64, 0, s>>>(rs, n, e->moves_arena);
+    k_scan_arena<0><<<1, 256, 0, s>>>(rs, n, e->moves_arena);
     MARK(); // 9 main dp
     {
         const int cls[] = {4, 8, 12, 16, 24, 32, 48};
@@ -349,7 +349,7 @@ extern "C" int tba_batch_enqueue(tba_engine *e)
     k_main_tb<<<nb, 64, 0, s>>>(rs, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
     MARK(); // 11 skip resolve
     k_skip_plan<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
-    k_scan_skip<<<1, 64, 0, s>>>(rs, n, e->skip_arena);
+    k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
     k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
     MARK(); // 12 theil-sen
     k_base_means<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_bm.as<double>());
