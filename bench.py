@@ -153,6 +153,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     out = eng.download(want_norm=False)
+    if os.environ.get('TBA_DBG_PHASES'):
+        d = eng.get(99)
+        print('phase cycles median', ' '.join(str(int(x)) for x in np.median(d, axis=0)), file=sys.stderr)
     n_ok = int((out['status'] == 0).sum())
     stage /= max(a.steps, 1)
 

@@ -222,6 +222,7 @@ class Engine(object):
             GET_SEG_SV: (np.float64, (n, 4)), GET_START: (np.float64, (n, 4)),
             GET_THEIL_SEN: (np.float64, (n, 4)), GET_PATH: (np.int32, (n, 4)),
             GET_LAST_ROW: (np.float64, (n, MAX_BAND)), GET_KERNEL_MS: (np.float32, 32),
+            99: (np.int64, (n, 8)),
             GET_SEG_NORM: (np.float64, self.n_raw_total),
             GET_BAND_STARTS: (np.int64, int(self.ref_off[-1])),
             GET_READ_TB: (np.int64, int(self.seg_off[-1])),

@@ -164,12 +164,97 @@ __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const
 // positions by exact selection.  Priority = (score, index) descending -- identical to
 // np.argsort(score)[::-1] for tie-free scores; ties fall to the higher index.
 // One workgroup per read.  state: 0 undecided, 1 taken, 2 suppressed.
-#define PK_CORE 3072
-#define PK_HALO 64
-#define PK_SPAN (PK_CORE + 2 * PK_HALO)
 __device__ __forceinline__ bool prio_before(double sp, i64 p, double sq, i64 q)
 {
     return sp > sq || (sp == sq && p > q);
+}
+
+// The greedy inside LDS tiles, one tile per WAVEFRONT at a time (no workgroup barriers: the
+// waves of a workgroup walk different tiles).  Exclusion radius R = min_base_obs - 1 is a
+// compile-time constant.  Every lane owns PKW_SLOTS strided tile slots; which neighbours
+// outrank a slot is fixed, so it is computed once per tile into a bit mask; a round then only
+// reads the 2R neighbour states (issued together, no branches) and updates the slot.  Decisions
+// are only ever taken from decided neighbours, so whatever is decided here is final; slots whose
+// dependency chain leaves the tile stay 0 and are finished by the global rounds of k_peaks.
+// Returns this lane's count of core positions left undecided.
+#define PKW_CORE 448
+#define PKW_HALO 32
+#define PKW_SPAN (PKW_CORE + 2 * PKW_HALO)   // 512 slots = 8 per lane
+#define PKW_SLOTS (PKW_SPAN / 64)
+template <int R>
+__device__ i64 peaks_tiles(const double *s, unsigned char *st, i64 ns, double *ts_all,
+                           unsigned char *tst_all)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *ts = ts_all + wave * PKW_SPAN;
+    unsigned char *tst = tst_all + wave * PKW_SPAN;
+    i64 left = 0;
+    const i64 n_tiles = (ns + PKW_CORE - 1) / PKW_CORE;
+    for (i64 tile = wave; tile < n_tiles; tile += SEL_NT / 64) {
+        const i64 t0 = tile * PKW_CORE;
+        const i64 g0 = t0 - PKW_HALO; // global index of tile slot 0
+#pragma unroll
+        for (int i = 0; i < PKW_SLOTS; i++) {
+            const int k = lane + 64 * i;
+            const i64 p = g0 + k;
+            const bool in = p >= 0 && p < ns;
+            const double v = s[p < 0 ? 0 : (p >= ns ? ns - 1 : p)];
+            ts[k] = in ? v : -1.0;   // scores are >= 0
+            tst[k] = in ? 0 : 2;     // slots outside the signal constrain nobody
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32 himask[PKW_SLOTS]; // bit d: neighbour at offset d - R (d != R) outranks me
+        unsigned char mine[PKW_SLOTS];
+#pragma unroll
+        for (int i = 0; i < PKW_SLOTS; i++) {
+            const int k = lane + 64 * i;
+            const double sk = ts[k];
+            // the outermost R slots of a tile that have neighbours outside the loaded span
+            const bool edge = (k < R && g0 > 0) || (k >= PKW_SPAN - R && g0 + PKW_SPAN < ns);
+            u32 hm = 0;
+#pragma unroll
+            for (int d = 0; d <= 2 * R; d++) {
+                if (d == R) continue;
+                const int q = k + d - R;
+                const int qc = q < 0 ? 0 : (q >= PKW_SPAN ? PKW_SPAN - 1 : q);
+                const double sq = ts[qc];
+                const bool inb = q >= 0 && q < PKW_SPAN;
+                hm |= (inb && prio_before(sq, g0 + q, sk, g0 + k)) ? (1u << d) : 0u;
+            }
+            himask[i] = hm;
+            mine[i] = edge ? 3 : tst[k]; // 3: cannot be decided in this tile
+        }
+        for (int round = 0; round < PKW_SPAN; round++) {
+            int progress = 0;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < PKW_SLOTS; i++) {
+                const int k = lane + 64 * i;
+                bool any_taken = false, any_undec = false;
+#pragma unroll
+                for (int d = 0; d <= 2 * R; d++) {
+                    if (d == R) continue;
+                    const int q = k + d - R;
+                    const unsigned char sq = tst[q < 0 ? 0 : (q >= PKW_SPAN ? PKW_SPAN - 1 : q)];
+                    const bool hi = (himask[i] >> d) & 1u;
+                    any_taken |= hi && sq == 1;
+                    any_undec |= hi && sq == 0;
+                }
+                const unsigned char nv = any_taken ? 2 : (!any_undec ? 1 : 0);
+                if (mine[i] == 0 && nv != 0) { tst[k] = nv; mine[i] = nv; progress = 1; }
+            }
+            if (__ballot(progress) == 0) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < PKW_CORE / 64; i++) {
+            const int k = lane + 64 * i;
+            const i64 p = t0 + k;
+            if (p < ns) { const unsigned char v0 = tst[k + PKW_HALO]; st[p] = v0; left += v0 == 0; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return left;
 }
 
 __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams *dp,
@@ -178,6 +263,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     __shared__ BucketSmem sm;
     __shared__ i64 s_w[SEL_NT / 64];
     __shared__ i64 s_idx_thr;
+    __shared__ unsigned char s_tst[(SEL_NT / 64) * PKW_SPAN];
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
     const int tid = threadIdx.x;
@@ -195,54 +281,21 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     // A position is only decided from neighbours that are themselves decided, so every decision
     // made here is final; positions whose dependency chain leaves the tile stay undecided (0)
     // and are finished by the global rounds below (rare: chains are a few positions long).
+    TBA_PHASE_T0();
     {
-        static_assert((PK_SPAN + PK_SPAN / 8 + 1) <= BS_NB / 2 + BS_CAP, "tile does not fit");
-        double *ts = sm.raw8;                                   // PK_SPAN scores
-        unsigned char *tst = (unsigned char *)(sm.raw8 + PK_SPAN); // PK_SPAN states
+        static_assert((SEL_NT / 64) * PKW_SPAN <= BS_NB / 2 + BS_CAP, "tiles do not fit");
+        double *ts = sm.raw8;                       // one PKW_SPAN score tile per wave
+        unsigned char *tst = s_tst;                 // and its states
         i64 left_undecided = 0;
-        for (i64 t0 = 0; t0 < ns; t0 += PK_CORE) {
-            const i64 g0 = t0 - PK_HALO;                        // global index of tile slot 0
-            for (int k = tid; k < PK_SPAN; k += SEL_NT) {
-                const i64 p = g0 + k;
-                const bool in = p >= 0 && p < ns;
-                ts[k] = in ? s[p] : -1.0;                       // scores are >= 0: -1 never wins
-                // slots outside the signal are "suppressed" (they constrain nobody); the outermost
-                // m-1 slots of a tile that do have outside neighbours can never be decided here
-                unsigned char v0 = in ? 0 : 2;
-                tst[k] = v0;
-            }
-            __syncthreads();
-            for (int round = 0; round < PK_SPAN; round++) {
-                int progress = 0;
-                for (int k = tid; k < PK_SPAN; k += SEL_NT) {
-                    if (tst[k] != 0) continue;
-                    const i64 p = g0 + k;
-                    // neighbours outside the loaded span (and inside the signal) are unknown
-                    const bool edge_lo = k < m - 1 && g0 > 0, edge_hi = k > PK_SPAN - m && g0 + PK_SPAN < ns;
-                    if (edge_lo || edge_hi) continue;
-                    const double sp_ = ts[k];
-                    bool any_taken = false, any_undecided = false;
-                    int q0 = k - (int)m + 1 < 0 ? 0 : k - (int)m + 1;
-                    int q1 = k + (int)m - 1 >= PK_SPAN ? PK_SPAN - 1 : k + (int)m - 1;
-                    for (int q = q0; q <= q1; q++) {
-                        if (q == k) continue;
-                        if (!prio_before(ts[q], g0 + q, sp_, p)) continue;
-                        const unsigned char sq = tst[q];
-                        any_taken |= sq == 1;
-                        any_undecided |= sq == 0;
-                    }
-                    if (any_taken) { tst[k] = 2; progress = 1; }
-                    else if (!any_undecided) { tst[k] = 1; progress = 1; }
-                }
-                if (!__syncthreads_or(progress)) break;
-            }
-            for (int k = tid; k < PK_CORE; k += SEL_NT) {
-                const i64 p = t0 + k;
-                if (p < ns) { const unsigned char v0 = tst[k + PK_HALO]; st[p] = v0; left_undecided += v0 == 0; }
-            }
+        if (m - 1 == 2) { left_undecided = peaks_tiles<2>(s, st, ns, ts, tst); __syncthreads(); }
+        else if (m - 1 == 5) { left_undecided = peaks_tiles<5>(s, st, ns, ts, tst); __syncthreads(); }
+        else { // unusual min_obs_per_base: everything goes through the global rounds
+            for (i64 p = tid; p < ns; p += SEL_NT) st[p] = 0;
+            left_undecided = 1;
             __syncthreads();
         }
         left_undecided = block_sum_i64(left_undecided, &sm.rad);
+        TBA_PHASE(0);
         // Phase 2: global rounds for whatever the tiles could not settle
         for (i64 round = 0; left_undecided > 0 && round <= ns; round++) {
             i64 undecided = 0;
@@ -266,6 +319,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
             left_undecided = block_sum_i64(undecided, &sm.rad);
         }
     }
+    TBA_PHASE(1);
     // taken scores -> dense array (+ their range)
     double mn = INFINITY, mx = -INFINITY;
     const i64 n_taken = block_compact(
@@ -285,10 +339,12 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
         mx = sm.redd[2 * q + 1] > mx ? sm.redd[2 * q + 1] : mx;
     }
     __syncthreads();
+    TBA_PHASE(2);
     // score of the num_cpts-th best taken position (ascending rank n_taken - num_cpts)
     const double tval = block_kth([&](i64 i) { return dn[i]; }, n_taken, n_taken - num_cpts, mn,
                                   mx, &sm);
     __syncthreads();
+    TBA_PHASE(3);
     // one pass: taken above / at the threshold, all positions above / at it, lowest taken index
     // at the threshold
     i64 c_gt = 0, c_eq = 0, a_gt = 0, a_eq = 0, min_eq = ns;
@@ -332,11 +388,13 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     // the reference raises when rank + 1 >= num_cands (cand_idx is advanced past the pick before
     // the bound check, _c_helper.pyx:116-118)
     if (num_cpts > 1 && before + 1 >= num_cands) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
+    TBA_PHASE(4);
     // ordered compaction of the picks (the .sort() of tombo_helper.py:76-82)
     block_compact(
         ns,
         [&](i64 p) { if (st[p] != 1) return false; const double v = s[p]; return v > tval || (v == tval && p >= idx_thr); },
         [&](i64 p, i64 o) { cpts[o] = p + w; }, s_w);
+    TBA_PHASE(5);
     if (tid == 0) { r.n_cpts = num_cpts; r.n_ev = num_cpts - 1; }
 }
 

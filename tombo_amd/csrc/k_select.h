@@ -4,7 +4,7 @@
 #pragma once
 #include "tba_common.h"
 
-#define SEL_NT 256 // threads per workgroup for every kernel that uses these helpers
+#define SEL_NT 512 // threads per workgroup for every kernel that uses these helpers
 
 struct SelectSmem {
     u32 hist[256];
@@ -362,21 +362,37 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
 
 // ordered stream compaction over [0, n): emit(i, out_index) for every i with pred(i), output
 // indices ascending in i.  All threads call; returns the number emitted.  s_w: >= SEL_NT/64 i64.
+// Every thread takes CB consecutive items per step (their predicate loads are issued together),
+// so a step covers CB * SEL_NT items and costs two workgroup barriers.
+#define CB 8
 template <class Pred, class Emit>
 __device__ i64 block_compact(i64 n, Pred pred, Emit emit, i64 *s_w)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     i64 run = 0;
-    for (i64 base = 0; base < n; base += SEL_NT) {
-        const i64 i = base + tid;
-        const bool flag = i < n && pred(i);
-        const u64 mask = __ballot(flag);
-        const int pre = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) s_w[w] = __popcll(mask);
+    for (i64 base = 0; base < n; base += (i64)CB * SEL_NT) {
+        const i64 i0 = base + (i64)CB * tid;
+        u32 flags = 0;
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+            const i64 i = i0 + k;
+            flags |= (i < n && pred(i)) ? (1u << k) : 0u;
+        }
+        const int c = __popc(flags);
+        int inc = c; // inclusive scan of the per-thread counts inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_w[w] = inc;
         __syncthreads();
         i64 off = 0, tot = 0;
-        for (int q = 0; q < SEL_NT / 64; q++) { i64 c = s_w[q]; off += q < w ? c : 0; tot += c; }
-        if (flag) emit(i, run + off + pre);
+        for (int q = 0; q < SEL_NT / 64; q++) { i64 cc = s_w[q]; off += q < w ? cc : 0; tot += cc; }
+        i64 o = run + off + (inc - c);
+#pragma unroll
+        for (int k = 0; k < CB; k++)
+            if (flags & (1u << k)) emit(i0 + k, o++);
         run += tot;
         __syncthreads();
     }

@@ -20,6 +20,15 @@ typedef uint32_t u32;
 #define SCALE_CHANGE_THRESH 0.1   // _default_parameters.py:170
 #define MAX_TS_POINTS 1000        // _default_parameters.py:178
 
+// optional per-phase cycle stamps into ReadState.dbg (build with -DTBA_PHASE_DEBUG)
+#ifdef TBA_PHASE_DEBUG
+#define TBA_PHASE_T0() const i64 tba_t0_ = __builtin_readcyclecounter()
+#define TBA_PHASE(i_) do { if (threadIdx.x == 0) r.dbg[i_] = __builtin_readcyclecounter() - tba_t0_; } while (0)
+#else
+#define TBA_PHASE_T0() do { } while (0)
+#define TBA_PHASE(i_) do { } while (0)
+#endif
+
 enum { PATH_NONE = 0, PATH_ADAPTIVE = 1, PATH_STATIC = 2 };
 enum { ST_NONE = 0, ST_TRY = 1, ST_OK = 2, ST_RETRY = 3, ST_STATIC = 4 };
 
@@ -42,6 +51,7 @@ struct ReadState {
     i64 read_start, norm_len, dp_read_start;
     i64 n_win, skip_off;      // deletion windows of this read, scratch arena offset
     double ts[4]; double score;
+    i64 dbg[8];               // phase cycle counters (profiling aid)
 };
 
 struct DevParams {

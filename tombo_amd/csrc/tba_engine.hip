@@ -460,6 +460,11 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
                                : (k == 0 ? rs[i].shift : k == 1 ? rs[i].scale : k == 2 ? rs[i].lower : rs[i].upper);
         return 0;
     }
+    if (what == 99) { // debug: phase cycle counters
+        if ((size_t)out_bytes < N * 64) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++) memcpy((char *)out + 64 * i, rs[i].dbg, 64);
+        return 0;
+    }
     if (what == TBA_GET_PATH) {
         if ((size_t)out_bytes < N * 16) return set_err(TBA_E_ARG, "output buffer too small");
         i32 *o = (i32 *)out;
