@@ -97,7 +97,13 @@ def main():
     ap.add_argument('--bandwidth', type=int, default=500)
     ap.add_argument('--cpu-sample', type=int, default=150)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--preset', choices=['cfg2', 'cfg3', 'cfg1'], default=None,
+                    help='BASELINE.json configs: cfg2 10kb/W=500 (default), cfg3 10kb/W=300, cfg1 2kb/W=100')
     a = ap.parse_args()
+    if a.preset == 'cfg3':
+        a.bandwidth = 300
+    elif a.preset == 'cfg1':
+        a.bases, a.bandwidth = 2000, 100
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -107,6 +113,8 @@ def main():
     samp = th.seqSampleType('DNA', False)
     model = ts.TomboModel(seq_samp_type=samp)
     params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=a.bandwidth)
+    if a.bandwidth <= 100:
+        params = params._replace(band_bound_thresh=10)  # the default 40 fails every read at W=100
     workers = max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))
     seqs, raws = make_reads(a.reads, a.bases, 1000003 * (rank + 1), workers)
     rng = np.random.RandomState(12345 + rank)

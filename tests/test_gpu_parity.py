@@ -254,3 +254,138 @@ def test_resquiggle_read_dropin_on_gpu(golden_case):
     mr2 = mr._replace(genome_seq=bad.seq, raw_signal=bad.raw)
     with pytest.raises(th.TomboError, match='extends beyond bandwidth'):
         rq.resquiggle_read(mr2, bad.model, bad.params, 5.0, seq_samp_type=bad.samp)
+
+
+def _si(nb, seed):
+    if nb <= 1000:
+        return None
+    st = np.random.get_state()
+    np.random.seed(seed)
+    si = np.random.choice(nb, 1000, replace=False)
+    np.random.set_state(st)
+    return si
+
+
+def test_full_size_reads_vs_oracle_on_gpu():
+    """BASELINE configs[1] shape: 10 kb DNA reads, bandwidth 500 -- 40 reads against the oracle"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=500)
+    reads = []
+    for seed in range(40):
+        seq, raw, _ = synth.synth_read(model, 10000, 77000 + seed, **synth.DNA_SYNTH)
+        reads.append((raw, seq, None, _si(10000, seed)))
+    eng, out, oracles = run_batch(model, params, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'cfg2')
+    assert not bad, '\n'.join(bad[:40])
+    assert all(o['status'] == 0 for o in oracles)
+
+
+def test_default_bandwidth_ragged_batch_on_gpu():
+    """BASELINE configs[2] shape: the adaptive path at Tombo's default bandwidth 300, ragged
+    lengths"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    rng = np.random.default_rng(5)
+    reads = []
+    for seed in range(32):
+        nb = int(rng.integers(400, 6000))
+        kw = dict(synth.DNA_SYNTH)
+        kw['mean_dwell'] = int(rng.integers(7, 12))
+        seq, raw, _ = synth.synth_read(model, nb, 31000 + seed, **kw)
+        reads.append((raw, seq, None, _si(nb, seed)))
+    eng, out, oracles = run_batch(model, params, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'w300')
+    assert not bad, '\n'.join(bad[:40])
+    assert sum(o['status'] == 0 for o in oracles) >= 28
+
+
+def test_rna_batch_on_gpu():
+    """BASELINE configs[3] shape: direct RNA model, t-test segmentation, stall masking, event
+    based scaling, raw_min_obs_per_base = 2 in the skipped-base DP"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('RNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    reads = []
+    for seed, nb in enumerate((3000, 1500, 800, 2200, 3000, 400, 1100, 2600)):
+        seq, raw, _ = synth.synth_read(model, nb, 88000 + seed, **synth.RNA_SYNTH)
+        if seed == 4:  # a stalled stretch in the middle of the read
+            raw = np.concatenate([raw[:40000], np.full(1500, raw[40000]) +
+                                  np.random.default_rng(1).normal(0, 3.0, 1500), raw[40000:]])
+        reads.append((raw, seq, ts.identify_stalls(raw), _si(nb, seed)))
+    assert any(len(r[2]) for r in reads), 'no stall interval exercised'
+    eng, out, oracles = run_batch(model, params, 'RNA', reads)
+    bad = compare_batch(eng, oracles, out, 'rna')
+    assert not bad, '\n'.join(bad[:40])
+    assert sum(o['status'] == 0 for o in oracles) >= 6
+
+
+def test_batch_properties_at_scale_on_gpu():
+    """size-independent properties on a larger batch (no oracle): monotone boundaries, trimmed
+    signal covered exactly, determinism across runs, independence from batch composition"""
+    import hashlib
+    from tombo_amd import _native as N, synth, tombo_stats as ts, tombo_helper as th
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=500)
+    n = 384
+    raws, seqs = [], []
+    for i in range(n):
+        seq, raw, _ = synth.synth_read(model, 4000 + 8 * (i % 50), 910000 + i, **synth.DNA_SYNTH)
+        raws.append(raw)
+        seqs.append(ts.encode_seq(seq))
+    rng = np.random.RandomState(3)
+    si = np.stack([rng.choice(4000, 1000, replace=False) for _ in range(n)])
+    eng = _engine()
+    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+    p = N.make_params(params)
+    o = N.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH['DNA'])
+
+    def run(idx):
+        eng.upload(p, o, [raws[i] for i in idx], [seqs[i] for i in idx], samp_ind=si[idx])
+        eng.run()
+        out = eng.download()
+        per = []
+        for j in range(len(idx)):
+            segs = out['segs'][eng.seg_off[j]:eng.seg_off[j + 1]]
+            nl = int(out['norm_len'][j])
+            sig = out['norm'][eng.raw_off[j]:eng.raw_off[j] + nl]
+            h = hashlib.sha256(segs.tobytes() + sig.tobytes() + out['sv'][j].tobytes()).hexdigest()
+            per.append((int(out['status'][j]), h, segs, nl, int(out['read_start'][j])))
+        return per
+
+    full = run(np.arange(n))
+    assert sum(st == 0 for st, *_ in full) >= n - 2
+    for j, (st, h, segs, nl, rs) in enumerate(full):
+        if st != 0:
+            continue
+        assert segs[0] == 0 and segs[-1] == nl and np.all(np.diff(segs) >= 1)
+        assert rs >= 0 and rs + nl <= raws[j].shape[0]
+    again = run(np.arange(n))
+    assert [h for _, h, *_ in again] == [h for _, h, *_ in full], 'not deterministic'
+    sub = np.array([5, 300, 17, 128, 64, 383, 1])
+    part = run(sub)
+    assert [h for _, h, *_ in part] == [full[i][1] for i in sub], 'depends on batch composition'
+
+
+def test_degenerate_inputs_on_gpu():
+    """too-short sequence, tiny signal, constant signal: a status, never a crash"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th, resquiggle as rq
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    good = synth.synth_map_res(model, 500, 4, **synth.DNA_SYNTH)
+    mrs = [good._replace(genome_seq='ACG'),                       # shorter than the k-mer
+           good._replace(raw_signal=good.raw_signal[:12]),        # almost no signal
+           good._replace(raw_signal=np.full(6000, 90.0)),         # constant: MAD == 0
+           good._replace(genome_seq=good.genome_seq[:200] + 'N' + good.genome_seq[201:]),
+           good]
+    res = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp)
+    assert all(isinstance(r, Exception) for r in res[:4])
+    assert isinstance(res[3], th.TomboError) and 'Invalid sequence' in str(res[3])
+    assert not isinstance(res[4], Exception) and res[4].segs.shape[0] == 501
