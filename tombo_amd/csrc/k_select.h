@@ -194,11 +194,29 @@ __device__ __forceinline__ bool bs_member(const BucketSmem *sm, int nlev, double
     return true;
 }
 
-// k-th smallest (0-based) of { val(i) }, all threads call, all return the value.
-// On return sm->next holds the (k+1)-th smallest if it could be determined cheaply
-// (sm->found & 2), i.e. when it lies in the same final bucket or equals the k-th.
+// Element enumeration for block_kth: a functor fe(visit) must call visit(value, valid) for every
+// element exactly once, with a trip count that is uniform across the workgroup's lanes (visit
+// contains wave ballots); invalid visits pad the last iterations.  flat_elems adapts an indexed
+// accessor val(i), 0 <= i < n.
 template <class F>
-__device__ double block_kth(F val, i64 n, i64 k, double lo, double hi, BucketSmem *sm)
+struct FlatElems {
+    F val; i64 n;
+    template <class V> __device__ void operator()(V visit) const
+    {
+        for (i64 base = 0; base < n; base += SEL_NT) {
+            const i64 i = base + threadIdx.x;
+            const bool ok = i < n;
+            visit(ok ? val(i) : 0.0, ok);
+        }
+    }
+};
+template <class F> __device__ FlatElems<F> flat_elems(F val, i64 n) { return FlatElems<F>{val, n}; }
+
+// k-th smallest (0-based) of the n elements enumerated by fe; all threads call, all return the
+// value.  On return sm->next holds the (k+1)-th smallest if it could be determined cheaply
+// (sm->found & 2), i.e. when it lies in the same final bucket or equals the k-th.
+template <class FE>
+__device__ double block_kth_fe(FE fe, i64 n, i64 k, double lo, double hi, BucketSmem *sm)
 {
     const int tid = threadIdx.x;
     if (tid == 0) { sm->nlev = 0; sm->k = k; sm->found = 0; sm->cnt = n; }
@@ -211,17 +229,10 @@ __device__ double block_kth(F val, i64 n, i64 k, double lo, double hi, BucketSme
         for (int b = tid; b < BS_NB; b += SEL_NT) sm->hist[b] = 0;
         __syncthreads();
         const int nlev = sm->nlev;
-        for (i64 base = 0; base < n; base += SEL_NT) {
-            i64 i = base + tid;
-            bool part = false;
-            u32 bin = 0;
-            if (i < n) {
-                double v = val(i);
-                part = bs_member(sm, nlev, v);
-                bin = (u32)bs_bucket(v, lo, scale);
-            }
-            hist_add(sm->hist, part, bin);
-        }
+        fe([&](double v, bool ok) {
+            const bool part = ok && bs_member(sm, nlev, v);
+            hist_add(sm->hist, part, (u32)bs_bucket(v, lo, scale));
+        });
         __syncthreads();
         if (tid < 64) { // wave 0: locate the bucket of rank k (BS_NB/64 bins per lane)
             const int per = BS_NB / 64;
@@ -256,10 +267,9 @@ __device__ double block_kth(F val, i64 n, i64 k, double lo, double hi, BucketSme
             // gather the bucket and pick rank k inside it by counting
             if (tid == 0) sm->n_cand = 0;
             __syncthreads();
-            for (i64 i = tid; i < n; i += SEL_NT) {
-                double v = val(i);
-                if (bs_member(sm, nl, v)) { u32 p = atomicAdd(&sm->n_cand, 1u); if (p < BS_CAP) sm->cand[p] = v; }
-            }
+            fe([&](double v, bool ok) {
+                if (ok && bs_member(sm, nl, v)) { u32 p = atomicAdd(&sm->n_cand, 1u); if (p < BS_CAP) sm->cand[p] = v; }
+            });
             __syncthreads();
             const int m = (int)cnt;
             const i64 kk = sm->k;
@@ -288,10 +298,9 @@ __device__ double block_kth(F val, i64 n, i64 k, double lo, double hi, BucketSme
         }
         // too many members: re-bucket them over their exact min / max
         double mn = INFINITY, mx = -INFINITY;
-        for (i64 i = tid; i < n; i += SEL_NT) {
-            double v = val(i);
-            if (bs_member(sm, nl, v)) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-        }
+        fe([&](double v, bool ok) {
+            if (ok && bs_member(sm, nl, v)) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        });
         for (int mm = 32; mm >= 1; mm >>= 1) {
             double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
             mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
@@ -311,23 +320,54 @@ __device__ double block_kth(F val, i64 n, i64 k, double lo, double hi, BucketSme
         }
         lo = mn; hi = mx;
     }
-    // pathological input: exact radix select on the whole set
-    block_select([&](i64 i) { return f64_key(val(i)); }, n, k, &sm->rad);
-    double res = key_f64(sm->rad.prefix);
-    if (tid == 0) { sm->result = res; sm->found = 1; }
-    __syncthreads();
-    return res;
+    // pathological input: exact radix select on the whole set (8 passes over 8-bit digits)
+    {
+        SelectSmem *rs_ = &sm->rad;
+        if (tid == 0) { rs_->prefix = 0; rs_->k = k; rs_->n_less = 0; rs_->n_eq = 0; }
+        __syncthreads();
+        for (int pass = 7; pass >= 0; pass--) {
+            rs_->hist[tid & 255] = 0;
+            __syncthreads();
+            const u64 prefix = rs_->prefix;
+            const int sh = 8 * pass;
+            const u64 himask = pass == 7 ? 0ull : (~0ull << (sh + 8));
+            fe([&](double v, bool ok) {
+                const u64 key = f64_key(v);
+                hist_add(rs_->hist, ok && (key & himask) == prefix, (u32)((key >> sh) & 255));
+            });
+            __syncthreads();
+            if (tid == 0) {
+                i64 kk = rs_->k, acc = 0;
+                for (int b2 = 0; b2 < 256; b2++) {
+                    const u32 h = rs_->hist[b2];
+                    if (kk < acc + h) { rs_->prefix = prefix | ((u64)b2 << sh); rs_->k = kk - acc; break; }
+                    acc += h;
+                }
+            }
+            __syncthreads();
+        }
+        const double res = key_f64(rs_->prefix);
+        if (tid == 0) { sm->result = res; sm->found = 1; }
+        __syncthreads();
+        return res;
+    }
+}
+
+template <class F>
+__device__ double block_kth(F val, i64 n, i64 k, double lo, double hi, BucketSmem *sm)
+{
+    return block_kth_fe(flat_elems(val, n), n, k, lo, hi, sm);
 }
 
 // np.median through block_kth: (lower middle + upper middle) / 2.  The upper middle comes for
 // free when it shares the final bucket with the lower one, else one min-greater pass.
 // Returns the median; *lo_mid / *hi_mid (if not NULL) get the two middle order statistics.
-template <class F>
-__device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSmem *sm,
-                                    double *lo_mid = nullptr, double *hi_mid = nullptr)
+template <class FE>
+__device__ double block_median_fe(FE fe, i64 n, double lo, double hi, BucketSmem *sm,
+                                  double *lo_mid = nullptr, double *hi_mid = nullptr)
 {
     const i64 k_lo = (n - 1) / 2;
-    double a = block_kth(val, n, k_lo, lo, hi, sm);
+    double a = block_kth_fe(fe, n, k_lo, lo, hi, sm);
     double b = a;
     if (!(n & 1)) {
         const int found = sm->found;
@@ -340,11 +380,10 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
             // is the smallest element above a
             i64 le = 0;
             double mn = INFINITY;
-            for (i64 i = threadIdx.x; i < n; i += SEL_NT) {
-                double v = val(i);
-                le += v <= a;
-                mn = (v > a && v < mn) ? v : mn;
-            }
+            fe([&](double v, bool ok) {
+                le += ok && v <= a;
+                mn = (ok && v > a && v < mn) ? v : mn;
+            });
             le = block_sum_i64(le, &sm->rad);
             for (int mm = 32; mm >= 1; mm >>= 1) { double t = shfl_xor_f64(mn, mm); mn = t < mn ? t : mn; }
             if ((threadIdx.x & 63) == 0) sm->redd[threadIdx.x >> 6] = mn;
@@ -358,6 +397,12 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
     if (lo_mid) *lo_mid = a;
     if (hi_mid) *hi_mid = b;
     return (n & 1) ? a : (a + b) / 2.0;
+}
+template <class F>
+__device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSmem *sm,
+                                    double *lo_mid = nullptr, double *hi_mid = nullptr)
+{
+    return block_median_fe(flat_elems(val, n), n, lo, hi, sm, lo_mid, hi_mid);
 }
 
 // ordered stream compaction over [0, n): emit(i, out_index) for every i with pred(i), output

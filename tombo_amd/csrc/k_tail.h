@@ -294,18 +294,28 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     }
     const i64 ns = n * (n - 1) / 2;
     if (ns <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
-    const u32 nn = (u32)n, full = nn * ((nn - 1) / 2); // distances 1..(n-1)/2: n pairs each
-    auto slope_val = [&](i64 idx64) {
-        const u32 idx = (u32)idx64;
-        u32 i, j;
-        if (idx < full) { u32 d = idx / nn + 1; i = idx - (d - 1) * nn; j = i + d; if (j >= nn) j -= nn; }
-        else { i = idx - full; j = i + nn / 2; }
-        const double ei = s_ev[i], ej = s_ev[j];
-        return (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) / (ei - ej);
+    // all n(n-1)/2 pairs by circular distance d: (i, (i+d) mod n) for d = 1..(n-1)/2, plus
+    // (i, i + n/2) for i < n/2 when n is even; slope(i,j) == slope(j,i) bitwise.  The loops have
+    // workgroup-uniform trip counts (the visitor ballots).
+    auto slopes = [&](auto visit) {
+        const int nn = (int)n, dmax = (nn - 1) / 2;
+        for (int d = 1; d <= dmax + ((nn & 1) ? 0 : 1); d++) {
+            const int lim = d <= dmax ? nn : nn / 2; // the antipodal distance covers half
+            for (int i0 = 0; i0 < lim; i0 += SEL_NT) {
+                const int i = i0 + tid;
+                const bool ok = i < lim;
+                const int ic = ok ? i : 0;
+                int j = ic + d;
+                j = j >= nn ? j - nn : j;
+                const double ei = s_ev[ic], ej = s_ev[j];
+                const double sl = (ei == ej) ? 1000.0 : (s_md[ic] - s_md[j]) / (ei - ej);
+                visit(sl, ok);
+            }
+        }
     };
     // slopes of a normalised read cluster around 1: [0.5, 1.5] is only the first bucket range,
     // any other distribution costs refinement passes, not correctness (k_select.h)
-    double slope = block_median_fast(slope_val, ns, 0.5, 1.5, &sm);
+    double slope = block_median_fe(slopes, ns, 0.5, 1.5, &sm);
     double inter = block_median_fast([&](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, 0.0,
                                      1.0, &sm); // n <= 1000: gathered directly
     if (tid == 0) {
