@@ -686,143 +686,142 @@ __global__ __launch_bounds__(256) void k_scan_arena(ReadState *rs, i64 n_reads, 
     }
 }
 
-// main traceback + _trim_traceback (resquiggle.py:754-764) + get_rel_raw_coords (:858-864).
-// One wavefront per read: the packed move rows are streamed through LDS in coalesced chunks
-// (the pointer chase of c_banded_traceback then runs at LDS latency instead of HBM latency, one
-// lane walking), the event -> raw coordinate gather at the end uses all lanes.
-#define TBW_BYTES 16384
-__global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, const DevParams *dp,
-    const unsigned char *moves, const i64 *band_starts, const i64 *valid_cpts, i64 *read_tb,
-    i64 *dp_segs)
+// main traceback (c_banded_traceback, pyx:281-310) + _trim_traceback (resquiggle.py:754-764).
+// One LANE per read, 64 reads per wavefront walking in lockstep.  The pointer chase is made
+// latency-tolerant by prefetching: the path stays near the same band position from row to row
+// (the band follows it), so for the next TBR rows a 64-cell window of packed moves around the
+// current band position (one 16-byte load per row) and the band starts are fetched together,
+// then the rows are walked out of registers; a position outside its window falls back to
+// direct loads.  A run of stays is resolved with clz on the 2-bit fields.
+#define TBR 16
+__device__ __forceinline__ int mv_find_le(u64 x, int top) // highest non-zero 2-bit field <= top, or -1
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_mv[TBW_BYTES];
-    __shared__ i64 s_st[TBW_BYTES / 64 + 1];
-    __shared__ i64 s_out[TBW_BYTES / 64 + 1];
-    __shared__ i64 s_state[4]; // cur_ev, status, rows done marker
-    ReadState &r = rs[blockIdx.x];
+    const u64 m = top >= 31 ? x : (x & ((1ull << (2 * top + 2)) - 1ull));
+    const u64 nz = (m | (m >> 1)) & 0x5555555555555555ull;
+    return nz ? (63 - __clzll((long long)nz)) >> 1 : -1;
+}
+__global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, const DevParams *dp,
+    const unsigned char *moves, const i64 *band_starts, i64 *read_tb)
+{
+    const i64 ri = (i64)blockIdx.x * 64 + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
     if (r.status != TBA_OK) return;
-    const int lane = threadIdx.x;
-    if (r.path == PATH_NONE) { if (lane == 0) r.status = TBA_INTERNAL; return; }
-    const i64 B = r.B, W = r.W;
-    const int Wi = (int)W;
-    const int cpl = cpl_class(W), bpl = mv_bpl(cpl);
-    const i64 rowb = (i64)64 * bpl;
-    const int chunk = (int)(TBW_BYTES / rowb);          // rows per LDS chunk (>= 21)
+    if (r.path == PATH_NONE) { r.status = TBA_INTERNAL; return; }
+    const i64 B = r.B;
+    const int Wi = (int)r.W;
+    const int rowb = 64 * mv_bpl(cpl_class(r.W));       // bytes per packed row (multiple of 64)
+    const int roww = rowb / 4;                          // dwords per row
     const unsigned char *mv = moves + r.moves_off;
     const i64 *st = band_starts + r.ref_off;
     i64 *tb = read_tb + r.seg_off;
     const bool adaptive = r.path == PATH_ADAPTIVE;
-    const i64 thresh = adaptive ? dp->p.band_bound_thresh : -1;
-    if (lane == 0) {
-        const i64 cur_ev = r.top_pos + st[B - 1];
-        tb[B] = cur_ev + 1;
-        s_state[0] = cur_ev; s_state[1] = TBA_OK;
-    }
-    __syncthreads();
-    // rows hi .. lo (inclusive), hi descending from B; row rr uses starts[rr-1]
-    for (i64 hi = B; hi >= 1; hi -= chunk) {
-        const i64 lo = hi - chunk + 1 < 1 ? 1 : hi - chunk + 1;
-        const i64 nrow = hi - lo + 1;
-        { // coalesced copy of rows lo..hi (contiguous in memory) into LDS, 16 bytes per lane
-            const i64 nbytes = nrow * rowb;
-            const uint4 *src = (const uint4 *)(mv + lo * rowb); // arena offsets / rows are 64-B multiples
-            uint4 *dst = (uint4 *)s_mv;
-            for (i64 k = lane; k < nbytes / 16; k += 64) dst[k] = src[k];
-            for (i64 k = lane; k < nrow; k += 64) s_st[k] = st[lo - 1 + k];
+    const int thresh = adaptive ? (int)dp->p.band_bound_thresh : -1;
+    i64 cur_ev = r.top_pos + st[B - 1];
+    tb[B] = cur_ev + 1;
+    int rc = TBA_OK;
+    int bp_guess = (int)r.top_pos;
+    for (i64 r0 = B; r0 >= 1 && rc == TBA_OK; r0 -= TBR) {
+        // fetch: band starts and a 4-dword window of row r0-k around the expected position
+        i64 stv[TBR];
+        uint4 win[TBR];
+        int wb = (bp_guess >> 4) - 2;                   // first dword of the window
+        wb = wb < 0 ? 0 : (wb > roww - 4 ? roww - 4 : wb);
+#pragma unroll
+        for (int k = 0; k < TBR; k++) {
+            const i64 rr = r0 - k;
+            const i64 rc_ = rr >= 1 ? rr : 1;
+            stv[k] = st[rc_ - 1];
+            win[k] = *(const uint4 *)(mv + rc_ * rowb + 4 * wb);
         }
-        __syncthreads();
-        if (lane == 0 && s_state[1] == TBA_OK) {
-            i64 cur_ev = s_state[0];
-            int rc = TBA_OK;
-            for (i64 rr = hi; rr >= lo; rr--) {
-                const i64 stv = s_st[rr - lo];
-                const i64 bp64 = cur_ev - stv;
-                if (bp64 >= W || bp64 < -W) { rc = TBA_INTERNAL; break; }
-                int band_pos = (int)bp64;
-                const unsigned char *row = s_mv + (rr - lo) * rowb;
-#define MVL(b_) ({ int bb_ = (b_) < 0 ? (b_) + Wi : (b_); (int)((row[bb_ >> 2] >> (2 * (bb_ & 3))) & 3); })
-                int m;
-                {
-                    // fast path: one 64-bit window of 2-bit codes ending at band_pos (two aligned
-                    // dword reads); the highest non-zero field at or below band_pos ends the run of
-                    // stays.  Falls back to the cell-by-cell walk at the row start / wrap-around.
-                    const u32 *row32 = (const u32 *)row;
-                    const int wi = band_pos >> 4;
-                    bool done = false;
-                    m = 0;
-                    if (band_pos >= 0 && wi >= 1) {
-                        const u64 x0 = ((u64)row32[wi] << 32) | row32[wi - 1];
-                        const int p = 32 + 2 * (band_pos & 15);
-                        const u64 x = p + 2 >= 64 ? x0 : (x0 & ((1ull << (p + 2)) - 1ull));
-                        const u64 nz = (x | (x >> 1)) & 0x5555555555555555ull;
-                        if (nz != 0) {
-                            const int f = (63 - __clzll((long long)nz)) >> 1;
-                            m = (int)((x >> (2 * f)) & 3);
-                            band_pos = 16 * (wi - 1) + f;
-                            done = true;
-                        }
-                    }
-                    if (!done) {
-                        m = MVL(band_pos);
-                        while (m == 0) {
-                            band_pos--;
-                            if (band_pos < -Wi) { rc = TBA_INTERNAL; break; }
-                            m = MVL(band_pos);
-                        }
-                    }
+#pragma unroll
+        for (int k = 0; k < TBR; k++) {
+            const i64 rr = r0 - k;
+            if (rr < 1 || rc != TBA_OK) continue;
+            const i64 bp64 = cur_ev - stv[k];
+            if (bp64 >= Wi || bp64 < -Wi) { rc = TBA_INTERNAL; continue; }
+            int bp = (int)bp64, m = 0;
+            bool done = false;
+            const int lc = bp - 16 * wb;                // position inside the window
+            if (bp >= 0 && lc >= 0 && lc < 64) {
+                const u64 lo = ((u64)win[k].y << 32) | win[k].x, hi = ((u64)win[k].w << 32) | win[k].z;
+                int f = -1;
+                if (lc >= 32) { f = mv_find_le(hi, lc - 32); if (f >= 0) f += 32; }
+                if (f < 0) f = mv_find_le(lo, lc >= 32 ? 31 : lc);
+                if (f >= 0) {
+                    const u64 wsel = f >= 32 ? hi : lo;
+                    m = (int)((wsel >> (2 * (f & 31))) & 3);
+                    bp = 16 * wb + f;
+                    done = true;
+                } else if (wb > 0) {
+                    bp = 16 * wb - 1;                   // everything in the window was a stay
+                } else {
+                    bp = -1;                            // ran off the row start: wrap-around below
                 }
-                if (rc != TBA_OK) break;
-                if (m == 2) band_pos--;
-#undef MVL
-                if (thresh >= 0) {
-                    const int a = band_pos, b2 = Wi - band_pos - 1;
-                    if ((a < b2 ? a : b2) < thresh) { rc = TBA_BEYOND_BANDWIDTH; break; }
-                }
-                cur_ev = stv + band_pos;
-                s_out[rr - lo] = cur_ev + 1;
             }
-            s_state[0] = cur_ev; s_state[1] = rc;
+            if (!done) { // cell-by-cell walk with direct loads (python wrap-around of a negative index kept)
+                const unsigned char *row = mv + rr * rowb;
+#define MVG(b_) ({ int bb_ = (b_) < 0 ? (b_) + Wi : (b_); (int)((row[bb_ >> 2] >> (2 * (bb_ & 3))) & 3); })
+                m = MVG(bp);
+                while (m == 0) {
+                    bp--;
+                    if (bp < -Wi) { rc = TBA_INTERNAL; break; }
+                    m = MVG(bp);
+                }
+#undef MVG
+                if (rc != TBA_OK) continue;
+            }
+            if (m == 2) bp--;
+            if (thresh >= 0) {
+                const int a = bp, b2 = Wi - bp - 1;
+                if ((a < b2 ? a : b2) < thresh) { rc = TBA_BEYOND_BANDWIDTH; continue; }
+            }
+            cur_ev = stv[k] + bp;
+            tb[rr - 1] = cur_ev + 1;
+            bp_guess = bp;
         }
-        __syncthreads();
-        if (s_state[1] != TBA_OK) break;
-        for (i64 k = lane; k < nrow; k += 64) tb[lo - 1 + k] = s_out[k]; // seq_poss[rr-1]
-        __syncthreads();
     }
-    if (s_state[1] != TBA_OK) { if (lane == 0) r.status = (i32)s_state[1]; return; }
-    __threadfence_block();
+    if (rc != TBA_OK) { r.status = rc; return; }
     const i64 n_ev = r.n_ev - r.clip;
-    if (lane == 0) {
-        int rc = TBA_OK;
-        if (adaptive) {
-            i64 i = 0;
-            while (tb[i] < 0) { tb[i] = 0; i++; if (i > B) { rc = TBA_INTERNAL; break; } }
-            i64 j = 1;
-            while (rc == TBA_OK && tb[B + 1 - j] > n_ev) { tb[B + 1 - j] = n_ev; j++; if (j > B + 1) { rc = TBA_INTERNAL; break; } }
-        }
-        s_state[1] = rc;
+    if (adaptive) { // _trim_traceback
+        i64 i = 0;
+        while (tb[i] < 0) { tb[i] = 0; i++; if (i > B) { r.status = TBA_INTERNAL; return; } }
+        i64 j = 1;
+        while (tb[B + 1 - j] > n_ev) { tb[B + 1 - j] = n_ev; j++; if (j > B + 1) { r.status = TBA_INTERNAL; return; } }
     }
-    __syncthreads();
-    if (s_state[1] != TBA_OK) { if (lane == 0) r.status = (i32)s_state[1]; return; }
-    const i64 *c = valid_cpts + r.ev_off + r.clip;
-    const i64 n_c = n_ev + 1;
-    i64 *sg = dp_segs + r.seg_off;
-    int bad = 0;
-    if (!adaptive)
-        for (i64 i = lane; i <= B; i += 64) bad |= tb[i] < -(n_ev + 1) || tb[i] > n_ev;
-    if (__syncthreads_or(bad)) { if (lane == 0) r.status = TBA_INTERNAL; return; }
     i64 t0 = tb[0];
-    if (t0 < 0) t0 += n_c;
-    const i64 first = c[t0];
-    for (i64 i = lane; i <= B; i += 64) {
+    if (!adaptive && (t0 < -(n_ev + 1) || t0 > n_ev)) { r.status = TBA_INTERNAL; return; }
+    if (t0 < 0) t0 += n_ev + 1;
+    r.top_pos = t0; // index of the first base's change point, consumed by k_tb_gather
+}
+
+// get_rel_raw_coords (resquiggle.py:858-864): segs[i] = valid_cpts[clip:][read_tb[i]] - first.
+// grid: (blocks, reads); the last thread block of a read also records read_start / norm_len.
+__global__ __launch_bounds__(256) void k_tb_gather(ReadState *rs, const i64 *valid_cpts,
+    const i64 *read_tb, i64 *dp_segs)
+{
+    ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const i64 B = r.B;
+    const i64 n_ev = r.n_ev - r.clip, n_c = n_ev + 1;
+    const i64 *c = valid_cpts + r.ev_off + r.clip;
+    const i64 *tb = read_tb + r.seg_off;
+    i64 *sg = dp_segs + r.seg_off;
+    const i64 first = c[r.top_pos];
+    const bool adaptive = r.path == PATH_ADAPTIVE;
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i <= B; i += (i64)gridDim.x * 256) {
         i64 t = tb[i];
+        if (!adaptive && (t < -(n_ev + 1) || t > n_ev)) { bad = true; t = 0; }
         if (t < 0) t += n_c;
-        sg[i] = c[t] - first;
+        const i64 v = c[t] - first;
+        sg[i] = v;
+        if (i == B) {
+            r.dp_read_start = first;
+            r.read_start = first;
+            r.norm_len = v;
+            if (first < 0 || v < 0 || first + v > r.n_raw) bad = true;
+        }
     }
-    __syncthreads();
-    if (lane == 0) {
-        r.dp_read_start = first;
-        r.read_start = first;
-        r.norm_len = sg[B];
-        if (first < 0 || r.norm_len < 0 || first + r.norm_len > r.n_raw) r.status = TBA_INTERNAL;
-    }
+    if (bad) r.status = TBA_INTERNAL;
 }

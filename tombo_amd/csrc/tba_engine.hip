@@ -346,7 +346,8 @@ extern "C" int tba_batch_enqueue(tba_engine *e)
         for (int c : cls) launch_dp(e, c, DP_MAIN);
     }
     MARK(); // 10 main tb
-    k_main_tb<<<nb, 64, 0, s>>>(rs, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
+    k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+    k_tb_gather<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
     MARK(); // 11 skip resolve
     k_skip_plan<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
     k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
