@@ -57,6 +57,55 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
     // admissible interval of base i: [i*m, L-(n-1-i)*m)  (pyx:56-81): same length for all
     const i64 len = L - (n - 1) * m;
     if (len <= 0) return TBA_INTERNAL;
+    if (m == 1) {
+        // DNA (raw_min_obs_per_base = 1): the last-diagonal bookkeeping is vacuous (lag is always
+        // 1, no tail), so a row is fwd[k] = z[k] + max(prev_fwd[k], fwd[k-1]) with the running
+        // value carried in a register; only the forward rows go to scratch (for the traceback)
+        double *__restrict__ fwr = scratch;
+        {
+            const double mu = means[0], sd = sds[0];
+            double acc = 0;
+            for (i64 k = 0; k < len; k++) {
+                double zv = (sig[k] - mu) / sd;
+                if (zv > 0) zv = -zv;
+                if (winsor && zv < -mh) zv = -mh;
+                acc = k == 0 ? zv : acc + zv;
+                fwr[k] = acc;
+            }
+        }
+        for (i64 i = 1; i < n; i++) {
+            const double mu = means[i], sd = sds[i];
+            const double *__restrict__ x = sig + i;
+            const double *__restrict__ pf = fwr + (i - 1) * len;
+            double *__restrict__ bf = fwr + i * len;
+            double stay = 0;
+            for (i64 k = 0; k < len; k++) {
+                double zv = (x[k] - mu) / sd;
+                if (zv > 0) zv = -zv;
+                if (winsor && zv < -mh) zv = -mh;
+                const double diag = pf[k];
+                const double best = (k == 0 || diag > stay) ? diag : stay;
+                stay = zv + best;
+                bf[k] = stay;
+            }
+        }
+        i64 sig_start = (n - 1) + len - 1; // raw_traceback / c_base_traceback, pyx:165-182
+        for (i64 b = n - 1; b >= 1; b--) {
+            const double *cf = fwr + b * len, *nf = fwr + (b - 1) * len;
+            const i64 cs = b, ns = b - 1, ne = ns + len;
+            i64 cnt = 1, found = -1;
+            for (i64 sp = sig_start; sp >= 0; sp--) {
+                cnt += 1;
+                if (cnt <= 1 || sp - 1 >= ne) continue;
+                if (sp <= cs) { found = sp; break; }
+                if (nf[sp - ns - 1] > cf[sp - cs - 1]) { found = sp; break; }
+            }
+            if (found < 0) return TBA_INTERNAL;
+            new_segs[b - 1] = found;
+            sig_start = found - 1;
+        }
+        return TBA_OK;
+    }
     double *fw = scratch, *zp = fw + n * len, *zc = zp + len, *cum = zc + len;
     i64 *pl = (i64 *)(cum + len), *bl = pl + len;
     base_z_row(sig, len, means[0], sds[0], winsor, mh, zp);
@@ -129,23 +178,35 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
 // get_deletion_windows (resquiggle.py:462-498) + per-window scratch sizing; one thread per read.
 // win[3*k..] = (start, end, scratch offset inside the read's slice); r.n_win, r.skip_off (need,
 // turned into an arena offset by k_scan_skip).
-__global__ void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp, const i64 *dp_segs,
-    i64 *win_scratch)
+__global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp,
+    const i64 *dp_segs, i64 *win_scratch)
 {
-    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ri >= n_reads) return;
-    ReadState &r = rs[ri];
-    r.n_win = 0; r.skip_off = 0;
+    (void)n_reads;
+    ReadState &r = rs[blockIdx.x];
+    const int lane = threadIdx.x;
+    if (lane == 0) { r.n_win = 0; r.skip_off = 0; }
     if (r.status != TBA_OK) return;
     const i64 m = dp->p.raw_min_obs_per_base;
     const i64 n_segs = r.B + 1;
     const i64 *ds = dp_segs + r.seg_off;
+    // skipped bases (diff(segs) == 0), found by all lanes, kept in order behind the window area
+    i64 *dels = win_scratch + 3 * r.seg_off + 2 * n_segs;
+    i64 n_del = 0;
+    for (i64 base = 0; base + 1 < n_segs; base += 64) {
+        const i64 d = base + lane;
+        const bool flag = d + 1 < n_segs && ds[d + 1] == ds[d];
+        const u64 mask = __ballot(flag);
+        if (flag) dels[n_del + __popcll(mask & ((1ull << lane) - 1ull))] = d;
+        n_del += __popcll(mask);
+    }
+    __syncthreads();
+    if (lane != 0) return;
     // windows are built in place as (s, e) pairs, then widened to (s, e, off) triples back to
     // front; capacity 3 * (B + 1) entries per read
     Win *w = (Win *)(win_scratch + 3 * r.seg_off);
     i64 nw = 0;
-    for (i64 d = 0; d + 1 < n_segs; d++) {
-        if (ds[d + 1] - ds[d] != 0) continue;
+    for (i64 q = 0; q < n_del; q++) {
+        const i64 d = dels[q];
         if (nw > 0 && d < w[nw - 1].e + DEL_FIX_WINDOW) w[nw - 1].e = d + DEL_FIX_WINDOW + 1;
         else { w[nw].s = d - DEL_FIX_WINDOW; w[nw].e = d + DEL_FIX_WINDOW + 1; nw++; }
     }

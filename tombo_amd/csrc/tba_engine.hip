@@ -349,7 +349,7 @@ extern "C" int tba_batch_enqueue(tba_engine *e)
     k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
     k_tb_gather<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
     MARK(); // 11 skip resolve
-    k_skip_plan<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
+    k_skip_plan<<<nb, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
     k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
     k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
     MARK(); // 12 theil-sen
