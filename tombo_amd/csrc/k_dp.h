@@ -69,13 +69,13 @@ __device__ __forceinline__ double dpp_mov_f64(double x)
 }
 __device__ __forceinline__ double wave_max_f64(double v)
 {
-    double t;
-    t = dpp_mov_f64<0xb1, 0xf>(v); v = t > v ? t : v;   // quad_perm:[1,0,3,2]
-    t = dpp_mov_f64<0x4e, 0xf>(v); v = t > v ? t : v;   // quad_perm:[2,3,0,1]
-    t = dpp_mov_f64<0x124, 0xf>(v); v = t > v ? t : v;  // row_ror:4
-    t = dpp_mov_f64<0x128, 0xf>(v); v = t > v ? t : v;  // row_ror:8
-    t = dpp_mov_f64<0x142, 0xa>(v); v = t > v ? t : v;  // row_bcast:15 -> rows 1,3
-    t = dpp_mov_f64<0x143, 0xc>(v); v = t > v ? t : v;  // row_bcast:31 -> rows 2,3
+    // no NaNs reach this point (a NaN row is caught by the sweep bound), so v_max_f64 == select
+    v = __builtin_fmax(v, dpp_mov_f64<0xb1, 0xf>(v));   // quad_perm:[1,0,3,2]
+    v = __builtin_fmax(v, dpp_mov_f64<0x4e, 0xf>(v));   // quad_perm:[2,3,0,1]
+    v = __builtin_fmax(v, dpp_mov_f64<0x124, 0xf>(v));  // row_ror:4
+    v = __builtin_fmax(v, dpp_mov_f64<0x128, 0xf>(v));  // row_ror:8
+    v = __builtin_fmax(v, dpp_mov_f64<0x142, 0xa>(v));  // row_bcast:15 -> rows 1,3
+    v = __builtin_fmax(v, dpp_mov_f64<0x143, 0xc>(v));  // row_bcast:31 -> rows 2,3
     int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
@@ -409,7 +409,6 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
 #pragma unroll
         for (int q = 0; q < (CPL + 15) / 16; q++) mvw[q] = 0;
         double lmax = NEG_INF;
-        int lidx = 0;
         {
             double x = in;
 #pragma unroll
@@ -418,9 +417,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 const u32 f = cv[j] > s ? ((cfw[j / 16] >> (2 * (j % 16))) & 3u) : 0u;
                 mvw[j / 16] |= f << (2 * (j % 16));
                 x = v[j];
-                const bool better = x > lmax;
-                lmax = better ? x : lmax;
-                lidx = better ? b0 + j : lidx;
+                lmax = __builtin_fmax(lmax, x);
             }
         }
         {
@@ -446,10 +443,14 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 pf_at = filled; pf = ev_load(filled + lane); pf_pending = true;
             }
         }
-        // wave argmax, first index among equal maxima
+        // wave argmax, first index among equal maxima (c_argmax, pyx:186-197): first lane that
+        // holds the maximum, first of its cells that equals it
         const double wm = wave_max_f64(lmax);
+        int lidx = CPL - 1;
+#pragma unroll
+        for (int j = CPL - 2; j >= 0; j--) lidx = v[j] == wm ? j : lidx;
         u64 eq = __ballot(lmax == wm && nvalid > 0);
-        am = uni(__shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64));
+        am = uni(__shfl(b0 + lidx, __ffsll((unsigned long long)eq) - 1, 64));
         prev_start = cur_start;
     }
     // last row + traceback start (np.argmax of the last row, resquiggle.py:728,1032)
