@@ -144,9 +144,47 @@ enum {
     TBA_GET_PATH = 11,        /* int32[n][4]: path (1 adaptive, 2 static), n_static, W, n_start_calls */
     TBA_GET_LAST_ROW = 12,    /* float64[n][TBA_MAX_BAND]: last forward-pass row */
     TBA_GET_DP_READ_START = 13, /* int64[n] */
-    TBA_GET_KERNEL_MS = 14    /* float32[32]: per-stage GPU time of the last run (events) */
+    TBA_GET_KERNEL_MS = 14,   /* float32[32]: per-stage GPU time of the last run (events) */
+    TBA_GET_REF_MEANS = 15,   /* float64, CSR by ref_off: expected levels of every base */
+    TBA_GET_REF_SDS = 16,
+    TBA_GET_SEGS = 17,        /* int64, CSR by seg_off: boundaries after skipped-base resolution */
+    TBA_GET_STATUS = 18,      /* int32[n] */
+    TBA_GET_START_FAIL = 19   /* int32[n]: status that failed the first start-discovery try (0: none) */
 };
 int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_bytes);
+/* ---- stepwise execution (the reference's public per-stage API, resquiggle.py:63-67) ---------
+ * The pipeline in stages; tba_batch_run_stages runs first..last on the uploaded batch (starting
+ * at TBA_STAGE_SEGMENT resets the per-read state).  tba_batch_put injects the inputs of a later
+ * stage so that it can run without the earlier ones:
+ *   segment_signal                 = stage SEGMENT   (get VALID_CPTS, SEG_NORM, SEG_SV)
+ *   find_seq_start_in_events       = put EVENT_MEANS/VALID_CPTS/REF_*, stage START (get START)
+ *   find_adaptive_base_assignment  = put VALID_CPTS + EVENT_MEANS, stages REF_LEVELS..ASSIGN
+ *   find_static_base_assignment    = same with put START_STATE = 4 (get READ_TB)
+ *   resolve_skipped_bases_with_raw = put NORM, REF_*, DP_SEGS, stage SKIP (get SEGS) */
+enum {
+    TBA_STAGE_SEGMENT = 0,      /* normalisation + event detection (+ stall removal) */
+    TBA_STAGE_EVENT_MEANS = 1,  /* compute_base_means over the change points */
+    TBA_STAGE_REF_LEVELS = 2,   /* get_exp_levels_from_seq */
+    TBA_STAGE_START = 3,        /* find_seq_start_in_events (+ retry) */
+    TBA_STAGE_ASSIGN = 4,       /* masked start / static fallback, adaptive DP, traceback */
+    TBA_STAGE_SKIP = 5,         /* resolve_skipped_bases_with_raw */
+    TBA_STAGE_RESCALE = 6       /* Theil-Sen rescale + final score */
+};
+enum {
+    TBA_PUT_VALID_CPTS = 1,   /* int64, CSR by ev_off; per_read[i] = count */
+    TBA_PUT_EVENT_MEANS = 2,  /* float64, CSR by ev_off */
+    TBA_PUT_NORM = 3,         /* float64, CSR by raw_off: normalised signal */
+    TBA_PUT_REF_MEANS = 4,    /* float64, CSR by ref_off */
+    TBA_PUT_REF_SDS = 5,
+    TBA_PUT_DP_SEGS = 6,      /* int64, CSR by seg_off; per_read[2i], [2i+1] = read_start, length */
+    TBA_PUT_START_STATE = 7   /* per_read[i] = 4: force the static whole-read assignment */
+};
+int tba_batch_run_stages(tba_engine *e, int first_stage, int last_stage);
+int tba_batch_put(tba_engine *e, int what, const void *data, int64_t bytes,
+                  const int64_t *per_read);
+/* per-read num_events for the NEXT tba_batch_upload (segment_signal's argument); NULL clears */
+int tba_set_num_events(tba_engine *e, const int64_t *num_events, int64_t n_reads);
+
 /* bytes of algorithmic traffic / cell updates of the last uploaded batch */
 int tba_batch_stats(tba_engine *e, double *algorithmic_bytes, double *dp_cells);
 

@@ -53,7 +53,11 @@ class Opts(C.Structure):
 # TBA_GET_* selectors
 GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START, \
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
-    GET_DP_READ_START, GET_KERNEL_MS = range(1, 15)
+    GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL = range(1, 20)
+STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, STAGE_SKIP, \
+    STAGE_RESCALE = range(7)
+PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
+    PUT_START_STATE = range(1, 8)
 MAX_BAND = 3072
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
@@ -170,6 +174,10 @@ class Engine(object):
         ne = np.maximum(n_raw // int(params.mean_obs_per_event),
                         (self.B * float(opts.min_event_to_seq_ratio)).astype(np.int64))
         ne[(self.B <= 0) | (n_raw <= 0)] = 0
+        ov = getattr(self, '_ne_override', None)
+        if ov is not None and ov.shape[0] == n:
+            ne = np.where((ov > 0) & (self.B > 0) & (n_raw > 0), ov, ne)
+        self._ne_override = None
         self.num_events = ne
         self.ev_off = np.concatenate([[0], np.cumsum(ne)]).astype(np.int64)
         svi = None if sv_in is None else np.ascontiguousarray(sv_in, dtype=np.float64)
@@ -227,6 +235,10 @@ class Engine(object):
             GET_BAND_STARTS: (np.int64, int(self.ref_off[-1])),
             GET_READ_TB: (np.int64, int(self.seg_off[-1])),
             GET_DP_SEGS: (np.int64, int(self.seg_off[-1])),
+            GET_SEGS: (np.int64, int(self.seg_off[-1])),
+            GET_REF_MEANS: (np.float64, int(self.ref_off[-1])),
+            GET_REF_SDS: (np.float64, int(self.ref_off[-1])),
+            GET_STATUS: (np.int32, n), GET_START_FAIL: (np.int32, n),
         }
         if what in (GET_VALID_CPTS, GET_EVENT_MEANS):
             out = np.zeros(max(int(self.ev_off[-1]), 1),
@@ -239,6 +251,23 @@ class Engine(object):
         self._check(self._L.tba_batch_get(self._h, C.c_int(what), out.ctypes.data_as(C.c_void_p),
                                           i64(out.nbytes)), 'tba_batch_get')
         return out
+
+    def run_stages(self, first, last):
+        self._check(self._L.tba_batch_run_stages(self._h, C.c_int(first), C.c_int(last)),
+                    'tba_batch_run_stages')
+
+    def put(self, what, data, per_read=None):
+        data = np.ascontiguousarray(data)
+        pr = None if per_read is None else np.ascontiguousarray(per_read, dtype=np.int64)
+        self._check(self._L.tba_batch_put(
+            self._h, C.c_int(what), data.ctypes.data_as(C.c_void_p), i64(data.nbytes),
+            _p(pr, i64)), 'tba_batch_put')
+
+    def set_num_events(self, num_events):
+        ne = None if num_events is None else np.ascontiguousarray(num_events, dtype=np.int64)
+        self._check(self._L.tba_set_num_events(
+            self._h, _p(ne, i64), i64(0 if ne is None else ne.shape[0])), 'tba_set_num_events')
+        self._ne_override = ne
 
     def stats(self):
         a, c = f64(0), f64(0)

@@ -545,6 +545,7 @@ __global__ void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int 
         r.n_start_calls = mode + 1;
     } else if (mode == DP_START_TRY && rc != TBA_INTERNAL) {
         // except th.TomboError: retry with the save bandwidth or fall back to the static DP
+        r.pad0 = rc; // why the first try failed (stand-alone find_seq_start_in_events reports it)
         r.start_state = r.n_ev < P.start_save_bw + nb ? ST_STATIC : ST_RETRY;
     } else {
         r.status = rc;

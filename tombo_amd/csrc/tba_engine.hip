@@ -57,6 +57,7 @@ struct tba_engine {
     i64 n_reads = 0, S_tot = 0, seq_tot = 0, B_tot = 0, E_tot = 0, max_raw = 0, max_B = 0;
     i64 start_moves_stride = 0, moves_arena = 0, skip_arena = 0;
     bool any_stall = false, have_samp = false, have_sv = false;
+    std::vector<i64> ne_override; // per-read num_events for the next upload (stepwise API)
     double algo_bytes = 0, dp_cells = 0;
     std::vector<ReadState> h_rs;
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
@@ -181,9 +182,11 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
         // ts.compute_num_events (tombo_stats.py:1558-1574) and the guard of resquiggle.py:1159
         i64 num_events = std::max(r.n_raw / p->mean_obs_per_event,
                                   (i64)((double)B * o->min_event_to_seq_ratio));
+        const bool forced = (i64)e->ne_override.size() == n && e->ne_override[(size_t)i] > 0;
+        if (forced) num_events = e->ne_override[(size_t)i]; // caller-chosen (segment_signal)
         r.num_events = num_events; // event space is reserved for every read with B > 0
         ev_acc += num_events;
-        if ((double)num_events / (double)p->bandwidth > (double)B) { r.status = TBA_TOO_MUCH_SIGNAL; continue; }
+        if (!forced && (double)num_events / (double)p->bandwidth > (double)B) { r.status = TBA_TOO_MUCH_SIGNAL; continue; }
         if (num_events <= 1 || r.n_raw < 4 * p->running_stat_width + 2) { r.status = TBA_INTERNAL; continue; }
         max_raw = std::max(max_raw, r.n_raw);
         max_B = std::max(max_B, B);
@@ -265,6 +268,15 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
         HIP_TRY(hipMemcpyAsync(e->d_stall.p, stall_ints, (size_t)stall_off[n] * 16, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     e->have_batch = true;
+    e->ne_override.clear();
+    return 0;
+}
+
+extern "C" int tba_set_num_events(tba_engine *e, const int64_t *num_events, int64_t n_reads)
+{
+    if (!e || n_reads < 0) return set_err(TBA_E_ARG, "bad arguments");
+    if (!num_events) { e->ne_override.clear(); return 0; }
+    e->ne_override.assign(num_events, num_events + n_reads);
     return 0;
 }
 
@@ -292,77 +304,162 @@ static void launch_dp(tba_engine *e, int cpl, int mode)
     }
 }
 
-extern "C" int tba_batch_enqueue(tba_engine *e)
+static int enqueue_stages(tba_engine *e, int first, int last)
 {
     if (!e || !e->have_batch) return set_err(TBA_E_STATE, "no batch uploaded");
+    if (first < 0 || last > TBA_STAGE_RESCALE || first > last) return set_err(TBA_E_ARG, "bad stage range");
+    if (first > 0 && !e->ran) return set_err(TBA_E_STATE, "stages before `first` have not been run or injected");
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const i64 n = e->n_reads;
     const tba_params &P = e->hp.p;
     ReadState *rs = e->d_rs.as<ReadState>();
     const DevParams *dp = e->d_dp.as<DevParams>();
-    // the state of a previous run of the same batch is discarded
-    HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.data(), (size_t)n * sizeof(ReadState), hipMemcpyHostToDevice, s));
+    // starting from the top discards the state of a previous run of the same batch
+    if (first == 0)
+        HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.data(), (size_t)n * sizeof(ReadState), hipMemcpyHostToDevice, s));
     const unsigned nb = (unsigned)n;
     const unsigned tpr = (unsigned)((n + 63) / 64); // blocks for thread-per-read kernels
     auto gx = [](i64 items) { i64 g = (items + 255) / 256; return (unsigned)std::min<i64>(std::max<i64>(g, 1), 128); };
     const unsigned gS = gx(e->max_raw), gB = gx(e->max_B), gE = gx(e->max_raw / std::max<i64>(P.mean_obs_per_event, 1) + 1);
     int st = 0;
 #define MARK() HIP_TRY(hipEventRecord(e->ev[st++], s))
+#define ON(stage_) ((stage_) >= first && (stage_) <= last)
     const bool rna = P.use_t_test_seg != 0;
     MARK(); // 0 normalize
-    if (!rna)
+    if (ON(TBA_STAGE_SEGMENT) && !rna)
         k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0);
     MARK(); // 1 cumsum
-    if (!rna) k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
+    if (ON(TBA_STAGE_SEGMENT) && !rna) k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
     MARK(); // 2 scores
-    if (!rna) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>());
-    else k_scores_ttest<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_score.as<double>());
-    MARK(); // 3 peaks
-    k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
-    if (e->any_stall) k_remove_stalls<<<tpr, 64, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>());
-    MARK(); // 4 event means (RNA: after event-based scaling)
-    if (rna) {
-        k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_raw.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
-        k_rna_event_scale<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_evm.as<double>());
-        k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1);
+    if (ON(TBA_STAGE_SEGMENT)) {
+        if (!rna) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>());
+        else k_scores_ttest<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_score.as<double>());
     }
-    k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+    MARK(); // 3 peaks
+    if (ON(TBA_STAGE_SEGMENT)) {
+        k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
+        if (e->any_stall) k_remove_stalls<<<tpr, 64, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>());
+        if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
+            k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_raw.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+            k_rna_event_scale<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_evm.as<double>());
+            k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1);
+        }
+    }
+    MARK(); // 4 event means
+    if (ON(TBA_STAGE_EVENT_MEANS))
+        k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
     MARK(); // 5 ref levels
-    k_ref_levels<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_seq.as<uint8_t>(), e->d_kmeans.as<double>(), e->d_ksds.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>());
-    k_path0<<<tpr, 64, 0, s>>>(rs, n, dp);
+    if (ON(TBA_STAGE_REF_LEVELS))
+        k_ref_levels<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_seq.as<uint8_t>(), e->d_kmeans.as<double>(), e->d_ksds.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>());
     MARK(); // 6 start dp (+7 start tb): find_seq_start_in_events, first try then retry
-    launch_dp(e, cpl_class(P.start_bw), DP_START_TRY);
-    k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_TRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+    if (ON(TBA_STAGE_START)) {
+        k_path0<<<tpr, 64, 0, s>>>(rs, n, dp);
+        launch_dp(e, cpl_class(P.start_bw), DP_START_TRY);
+        k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_TRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+    }
     MARK(); // 7
-    launch_dp(e, cpl_class(P.start_save_bw), DP_START_RETRY);
-    k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_RETRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+    if (ON(TBA_STAGE_START)) {
+        launch_dp(e, cpl_class(P.start_save_bw), DP_START_RETRY);
+        k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_RETRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+    }
     MARK(); // 8 prep
-    k_prep<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_bst.as<i64>(), e->d_lo.as<i32>(), e->d_hi.as<i32>());
-    k_scan_arena<0><<<1, 256, 0, s>>>(rs, n, e->moves_arena);
+    if (ON(TBA_STAGE_ASSIGN)) {
+        k_prep<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_bst.as<i64>(), e->d_lo.as<i32>(), e->d_hi.as<i32>());
+        k_scan_arena<0><<<1, 256, 0, s>>>(rs, n, e->moves_arena);
+    }
     MARK(); // 9 main dp
-    {
+    if (ON(TBA_STAGE_ASSIGN)) {
         const int cls[] = {4, 8, 12, 16, 24, 32, 48};
         for (int c : cls) launch_dp(e, c, DP_MAIN);
     }
     MARK(); // 10 main tb
-    k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
-    k_tb_gather<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
+    if (ON(TBA_STAGE_ASSIGN)) {
+        k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        k_tb_gather<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
+    }
     MARK(); // 11 skip resolve
-    k_skip_plan<<<nb, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
-    k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
-    k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
+    if (ON(TBA_STAGE_SKIP)) {
+        k_skip_plan<<<nb, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
+        k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
+        k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
+    }
     MARK(); // 12 theil-sen
-    k_base_means<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_bm.as<double>());
-    k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_bm.as<double>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr);
+    if (ON(TBA_STAGE_RESCALE)) {
+        k_base_means<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_bm.as<double>());
+        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_bm.as<double>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr);
+    }
     MARK(); // 13 rescale + score
-    k_rescale<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_norm_out.as<double>());
-    k_final_absz<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
-    k_final_score<<<tpr, 64, 0, s>>>(rs, n, e->d_absz.as<double>());
+    if (ON(TBA_STAGE_RESCALE)) {
+        k_rescale<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_norm_out.as<double>());
+        k_final_absz<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
+        k_final_score<<<tpr, 64, 0, s>>>(rs, n, e->d_absz.as<double>());
+    }
     MARK(); // 14 end
 #undef MARK
+#undef ON
     HIP_TRY(hipGetLastError());
     e->ran = true;
+    return 0;
+}
+
+extern "C" int tba_batch_enqueue(tba_engine *e) { return enqueue_stages(e, TBA_STAGE_SEGMENT, TBA_STAGE_RESCALE); }
+
+extern "C" int tba_batch_run_stages(tba_engine *e, int first_stage, int last_stage)
+{
+    int rc = enqueue_stages(e, first_stage, last_stage);
+    if (rc) return rc;
+    return tba_batch_sync(e);
+}
+
+// inject stage inputs of the uploaded batch (stepwise API): see include/tombo_amd.h
+extern "C" int tba_batch_put(tba_engine *e, int what, const void *data, int64_t bytes,
+                             const int64_t *per_read)
+{
+    if (!e || !e->have_batch || !data) return set_err(TBA_E_STATE, "no batch uploaded");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t)e->n_reads;
+    auto put = [&](DevBuf &b, size_t cap_bytes) -> int {
+        if ((size_t)bytes > cap_bytes) return set_err(TBA_E_ARG, "input larger than the batch buffer");
+        HIP_TRY(hipMemcpy(b.p, data, (size_t)bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    std::vector<ReadState> rs(N);
+    // the first injection of a fresh batch starts from the uploaded state
+    if (!e->ran) HIP_TRY(hipMemcpy(e->d_rs.p, e->h_rs.data(), N * sizeof(ReadState), hipMemcpyHostToDevice));
+    e->ran = true;
+    HIP_TRY(hipMemcpy(rs.data(), e->d_rs.p, N * sizeof(ReadState), hipMemcpyDeviceToHost));
+    int rc = 0;
+    switch (what) {
+    case TBA_PUT_VALID_CPTS: // per_read[i] = number of change points of read i
+        if (!per_read) return set_err(TBA_E_ARG, "per_read counts required");
+        rc = put(e->d_cpts, (size_t)e->E_tot * 8);
+        for (size_t i = 0; i < N && !rc; i++) {
+            if (per_read[i] > rs[i].num_events || per_read[i] < 2) return set_err(TBA_E_ARG, "change point count outside the reserved space");
+            rs[i].n_cpts = per_read[i]; rs[i].n_ev = per_read[i] - 1;
+        }
+        break;
+    case TBA_PUT_EVENT_MEANS: rc = put(e->d_evm, (size_t)e->E_tot * 8); break;
+    case TBA_PUT_NORM: rc = put(e->d_norm, (size_t)e->S_tot * 8); break;
+    case TBA_PUT_REF_MEANS: rc = put(e->d_refm, (size_t)e->B_tot * 8); break;
+    case TBA_PUT_REF_SDS: rc = put(e->d_refs, (size_t)e->B_tot * 8); break;
+    case TBA_PUT_DP_SEGS: // per_read[2i] = read_start_rel_to_raw, per_read[2i+1] = trimmed signal length
+        if (!per_read) return set_err(TBA_E_ARG, "per_read (read_start, norm_len) required");
+        rc = put(e->d_dpsegs, (size_t)(e->B_tot + e->n_reads) * 8);
+        for (size_t i = 0; i < N && !rc; i++) {
+            rs[i].read_start = rs[i].dp_read_start = per_read[2 * i];
+            rs[i].norm_len = per_read[2 * i + 1];
+            if (rs[i].read_start < 0 || rs[i].read_start + rs[i].norm_len > rs[i].n_raw) return set_err(TBA_E_ARG, "segments outside the signal");
+        }
+        break;
+    case TBA_PUT_START_STATE: // per_read[i]: 4 = force the static whole-read path
+        if (!per_read) return set_err(TBA_E_ARG, "per_read states required");
+        for (size_t i = 0; i < N; i++) rs[i].start_state = (i32)per_read[i];
+        break;
+    default: return set_err(TBA_E_ARG, "unknown TBA_PUT_* selector");
+    }
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(e->d_rs.p, rs.data(), N * sizeof(ReadState), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -438,6 +535,9 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
     case TBA_GET_READ_TB: return copy(e->d_readtb, (size_t)(e->B_tot + e->n_reads) * 8);
     case TBA_GET_DP_SEGS: return copy(e->d_dpsegs, (size_t)(e->B_tot + e->n_reads) * 8);
     case TBA_GET_LAST_ROW: return copy(e->d_lastrow, N * TBA_MAX_BAND * 8);
+    case TBA_GET_REF_MEANS: return copy(e->d_refm, (size_t)e->B_tot * 8);
+    case TBA_GET_REF_SDS: return copy(e->d_refs, (size_t)e->B_tot * 8);
+    case TBA_GET_SEGS: return copy(e->d_segs, (size_t)(e->B_tot + e->n_reads) * 8);
     case TBA_GET_KERNEL_MS:
         if ((size_t)out_bytes < sizeof(e->stage_ms)) return set_err(TBA_E_ARG, "output buffer too small");
         memcpy(out, e->stage_ms, sizeof(e->stage_ms));
@@ -445,6 +545,16 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
     default: break;
     }
     if (int rc = fetch_rs()) return rc;
+    if (what == TBA_GET_START_FAIL) {
+        if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].pad0;
+        return 0;
+    }
+    if (what == TBA_GET_STATUS) {
+        if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].status;
+        return 0;
+    }
     if (what == TBA_GET_N_CPTS || what == TBA_GET_DP_READ_START) {
         if ((size_t)out_bytes < N * 8) return set_err(TBA_E_ARG, "output buffer too small");
         for (size_t i = 0; i < N; i++)

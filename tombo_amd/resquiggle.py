@@ -17,7 +17,9 @@ from ._default_parameters import (
     MAX_RAW_CPTS, MIN_EVENT_TO_SEQ_RATIO, SIG_MATCH_THRESH, DNA_SAMP_TYPE,
     MAX_POINTS_FOR_THEIL_SEN)
 
-__all__ = ['resquiggle_read', 'resquiggle_batch', 'get_engine']
+__all__ = ['resquiggle_read', 'resquiggle_batch', 'get_engine', 'segment_signal',
+           'find_adaptive_base_assignment', 'find_seq_start_in_events',
+           'find_static_base_assignment', 'resolve_skipped_bases_with_raw']
 
 _ENGINES = {}
 
@@ -169,3 +171,175 @@ def resquiggle_read(map_res, std_ref, rsqgl_params, outlier_thresh=None, all_raw
             np.random.set_state(rng_state)
         raise res
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's public per-stage API (tombo/resquiggle.py:63-67), same names and signatures.
+# Each runs the corresponding stage(s) of the batch engine on a batch of one, injecting the
+# stage's inputs instead of recomputing the earlier stages (include/tombo_amd.h, "stepwise
+# execution").
+def _set_model(eng, std_ref):
+    if eng.kmer_width != std_ref.kmer_width or getattr(eng, '_model_id', None) != id(std_ref):
+        eng.set_model(std_ref.level_means, std_ref.level_sds, std_ref.kmer_width,
+                      std_ref.central_pos)
+        eng._model_id = id(std_ref)
+
+
+def _status_or_raise(eng):
+    st = int(eng.get(_native.GET_STATUS)[0])
+    errors.raise_for_status(st)
+
+
+class _LevelsOnly(object):
+    """stand-in model for stages that are handed expected levels instead of a sequence"""
+    # K=2: the reference's own sequence trimming needs a non-empty k-mer tail (resquiggle.py:976)
+    kmer_width, central_pos = 2, 0
+    level_means = np.zeros(16)
+    level_sds = np.ones(16)
+
+
+def segment_signal(map_res, num_events, rsqgl_params, outlier_thresh=None, const_scale=None):
+    """Normalize and segment raw signal into `num_events` events (resquiggle.py:1057-1120).
+    Returns (valid_cpts, norm_signal, scaleValues)."""
+    eng = get_engine()
+    if eng.kmer_width is None:
+        _set_model(eng, _LevelsOnly)
+    raw = np.ascontiguousarray(map_res.raw_signal, dtype=np.float64)
+    sv = map_res.scale_values
+    sv_in = sv_flags = None
+    if sv is not None:
+        has_lims = sv.lower_lim is not None and sv.upper_lim is not None
+        sv_in = np.array([[sv.shift, sv.scale, sv.lower_lim if has_lims else 0.0,
+                           sv.upper_lim if has_lims else 0.0]])
+        sv_flags = np.array([1 | (2 if has_lims else 0)], np.int32)
+    stalls = map_res.stall_ints
+    K = eng.kmer_width
+    eng.set_num_events([int(num_events)])
+    eng.upload(_native.make_params(rsqgl_params),
+               _native.make_opts(outlier_thresh=outlier_thresh, const_scale=const_scale),
+               [raw], [np.zeros(K + 1, np.uint8)], sv_in=sv_in, sv_flags=sv_flags,
+               stall_ints=[stalls] if stalls is not None and len(stalls) else None)
+    eng.run_stages(_native.STAGE_SEGMENT, _native.STAGE_SEGMENT)
+    _status_or_raise(eng)
+    n = int(eng.get(_native.GET_N_CPTS)[0])
+    cpts = eng.get(_native.GET_VALID_CPTS)[:n].copy()
+    norm = eng.get(_native.GET_SEG_NORM)[:raw.shape[0]].copy()
+    s = eng.get(_native.GET_SEG_SV)[0]
+    use_sv = sv is not None or (bool(rsqgl_params.use_t_test_seg) and const_scale is None)
+    have_lims = (sv is None and (outlier_thresh is not None)) or \
+        (sv is not None and sv.lower_lim is not None and sv.upper_lim is not None)
+    return cpts, norm, th.scaleValues(
+        float(s[0]), float(s[1]), float(s[2]) if have_lims else None,
+        float(s[3]) if have_lims else None, None if use_sv else outlier_thresh)
+
+
+def _upload_events(eng, rsqgl_params, opts, valid_cpts, event_means, seq_codes):
+    valid_cpts = np.ascontiguousarray(valid_cpts, dtype=np.int64)
+    event_means = np.ascontiguousarray(event_means, dtype=np.float64)
+    n_cpts = event_means.shape[0] + 1
+    if valid_cpts.shape[0] != n_cpts:
+        raise ValueError('valid_cpts must have one more entry than event_means')
+    w = int(rsqgl_params.running_stat_width)
+    n_raw = max(int(valid_cpts[-1]) + 1, 4 * w + 2)
+    eng.set_num_events([n_cpts])
+    eng.upload(_native.make_params(rsqgl_params), opts, [np.zeros(n_raw)], [seq_codes])
+    eng.put(_native.PUT_VALID_CPTS, valid_cpts, per_read=[n_cpts])
+    eng.put(_native.PUT_EVENT_MEANS, event_means)
+
+
+def find_adaptive_base_assignment(
+        valid_cpts, event_means, rsqgl_params, std_ref, genome_seq, start_clip_bases=None,
+        start_clip_params=None, seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False),
+        reg_id=None):
+    """Align expected signal levels to observed events with the adaptive banded DP
+    (resquiggle.py:866-1050).  Returns :class:`dpResults`."""
+    if start_clip_bases is not None:
+        raise NotImplementedError('start-clip based start discovery (USE_START_CLIP_BASES) is '
+                                  'off in the reference and not part of this engine')
+    eng = get_engine()
+    _set_model(eng, std_ref)
+    opts = _native.make_opts(
+        sig_match_thresh=None if seq_samp_type is None else SIG_MATCH_THRESH[seq_samp_type.name])
+    _upload_events(eng, rsqgl_params, opts, valid_cpts, event_means, ts.encode_seq(genome_seq))
+    eng.run_stages(_native.STAGE_REF_LEVELS, _native.STAGE_ASSIGN)
+    _status_or_raise(eng)
+    K, cp = std_ref.kmer_width, std_ref.central_pos
+    return th.dpResults(
+        read_start_rel_to_raw=int(eng.get(_native.GET_DP_READ_START)[0]),
+        segs=eng.get(_native.GET_DP_SEGS).copy(), ref_means=eng.get(_native.GET_REF_MEANS).copy(),
+        ref_sds=eng.get(_native.GET_REF_SDS).copy(),
+        genome_seq=genome_seq[cp:len(genome_seq) - (K - cp - 1)])
+
+
+def _upload_levels(eng, rsqgl_params, opts, event_means, r_ref_means, r_ref_sds):
+    _set_model(eng, _LevelsOnly)
+    event_means = np.ascontiguousarray(event_means, dtype=np.float64)
+    n_ev = event_means.shape[0]
+    B = len(r_ref_means)
+    _upload_events(eng, rsqgl_params, opts, np.arange(n_ev + 1, dtype=np.int64), event_means,
+                   np.zeros(B + 1, np.uint8))
+    eng.put(_native.PUT_REF_MEANS, np.ascontiguousarray(r_ref_means, dtype=np.float64))
+    eng.put(_native.PUT_REF_SDS, np.ascontiguousarray(r_ref_sds, dtype=np.float64))
+
+
+def find_seq_start_in_events(event_means, r_ref_means, r_ref_sds, rsqgl_params, num_bases,
+                             num_events, seq_samp_type=None, reg_id=None):
+    """Most probable start of the expected levels within the events (resquiggle.py:685-752).
+    Returns (start_loc, events_per_base)."""
+    if event_means.shape[0] < num_events + num_bases:
+        raise th.TomboError(errors.MESSAGES[3])
+    if r_ref_means.shape[0] < num_bases:
+        raise th.TomboError(errors.MESSAGES[4])
+    eng = get_engine()
+    p = rsqgl_params._replace(start_n_bases=int(num_bases), start_bw=int(num_events),
+                              start_save_bw=int(num_events))
+    opts = _native.make_opts(
+        sig_match_thresh=None if seq_samp_type is None else SIG_MATCH_THRESH[seq_samp_type.name])
+    _upload_levels(eng, p, opts, event_means, r_ref_means, r_ref_sds)
+    eng.run_stages(_native.STAGE_START, _native.STAGE_START)
+    _status_or_raise(eng)
+    fail = int(eng.get(_native.GET_START_FAIL)[0])
+    if fail != 0:
+        # the first try failed (poor score / invalid path); inside resquiggle_read the engine
+        # goes on to the retry or the static fallback, stand-alone it is the reference's exception
+        raise th.TomboError(errors.MESSAGES[fail])
+    start = eng.get(_native.GET_START)[0]
+    return int(start[0]), float(start[1])
+
+
+def find_static_base_assignment(event_means, r_ref_means, r_ref_sds, rsqgl_params, reg_id=None):
+    """Whole-read static-band assignment for short reads (resquiggle.py:547-600).  Returns the
+    event index of every base start (`read_tb`)."""
+    eng = get_engine()
+    _upload_levels(eng, rsqgl_params, _native.make_opts(), event_means, r_ref_means, r_ref_sds)
+    eng.put(_native.PUT_START_STATE, np.zeros(1), per_read=[4])
+    eng.run_stages(_native.STAGE_ASSIGN, _native.STAGE_ASSIGN)
+    _status_or_raise(eng)
+    return eng.get(_native.GET_READ_TB).copy()
+
+
+def resolve_skipped_bases_with_raw(dp_res, norm_signal, rsqgl_params, max_raw_cpts=MAX_RAW_CPTS,
+                                   del_fix_window=None, max_del_fix_window=None,
+                                   extra_sig_factor=None):
+    """Raw-signal DP over the windows around skipped bases (resquiggle.py:402-540).  Returns
+    the resolved segment boundaries."""
+    if (del_fix_window, max_del_fix_window, extra_sig_factor) != (None, None, None):
+        raise NotImplementedError('the window constants are compiled into the engine '
+                                  '(DEL_FIX_WINDOW=2, MAX_DEL_FIX_WINDOW=10, EXTRA_SIG_FACTOR=1.1)')
+    eng = get_engine()
+    _set_model(eng, _LevelsOnly)
+    norm = np.ascontiguousarray(norm_signal, dtype=np.float64)
+    segs = np.ascontiguousarray(dp_res.segs, dtype=np.int64)
+    B = segs.shape[0] - 1
+    w = int(rsqgl_params.running_stat_width)
+    pad = max(0, 4 * w + 2 - norm.shape[0])
+    eng.set_num_events([2])
+    eng.upload(_native.make_params(rsqgl_params), _native.make_opts(max_raw_cpts=max_raw_cpts),
+               [np.concatenate([norm, np.zeros(pad)])], [np.zeros(B + 1, np.uint8)])
+    eng.put(_native.PUT_NORM, np.concatenate([norm, np.zeros(pad)]))
+    eng.put(_native.PUT_REF_MEANS, np.ascontiguousarray(dp_res.ref_means, dtype=np.float64))
+    eng.put(_native.PUT_REF_SDS, np.ascontiguousarray(dp_res.ref_sds, dtype=np.float64))
+    eng.put(_native.PUT_DP_SEGS, segs, per_read=[0, norm.shape[0]])
+    eng.run_stages(_native.STAGE_SKIP, _native.STAGE_SKIP)
+    _status_or_raise(eng)
+    return eng.get(_native.GET_SEGS).copy()
