@@ -222,6 +222,37 @@ int tba_c_valid_cpts_w_cap(tba_engine *e, const double *sig, int64_t n, int64_t 
 int tba_c_valid_cpts_w_cap_t_test(tba_engine *e, const double *sig, int64_t n,
     int64_t min_base_obs, int64_t running_stat_width, int64_t num_cpts, int64_t *cpts);
 
+/* c_new_mean_stds, _c_helper.pyx:38-57: segment means and population standard deviations */
+int tba_c_new_mean_stds(tba_engine *e, const double *norm_signal, int64_t n_sig,
+    const int64_t *new_segs, int64_t n_segs, double *means, double *stds);
+/* c_compute_slopes, _c_helper.pyx:362-377: all i<j slopes in itertools.combinations order;
+ * slopes[n*(n-1)/2] */
+int tba_c_compute_slopes(tba_engine *e, const double *r_event_means,
+    const double *r_model_means, int64_t n, double max_slope, double *slopes);
+/* c_reg_z_scores, _c_dynamic_programming.pyx:34-97: per base of [reg_start, reg_end) the
+ * admissible signal interval and the negative half z-scores over it.  r_b_starts has
+ * n_b_starts entries (indices up to reg_end are read).  bounds[2*i..] = (start, end) relative
+ * to r_b_starts[reg_start]; z_off[reg_len+1] = offsets of each base's scores inside z (capacity
+ * z_cap doubles; TBA_E_ARG if too small -- reg_len * (r_b_starts[reg_end] -
+ * r_b_starts[reg_start]) always suffices). */
+int tba_c_reg_z_scores(tba_engine *e, const double *r_sig, int64_t n_sig,
+    const double *r_ref_means, const double *r_ref_sds, int64_t n_bases,
+    const int64_t *r_b_starts, int64_t n_b_starts, int64_t reg_start, int64_t reg_end,
+    int64_t max_base_shift, int64_t min_obs_per_base, int do_winsorize_z,
+    double max_half_z_score, int64_t *bounds, int64_t *z_off, double *z, int64_t z_cap);
+/* c_base_forward_pass, _c_dynamic_programming.pyx:99-163: b_data has b_end - b_start entries,
+ * the prev_* arrays prev_b_end - prev_b_start; outputs b_fwd_data / b_last_diag of b_end -
+ * b_start entries.  TBA_INTERNAL where the reference raises IndexError. */
+int tba_c_base_forward_pass(tba_engine *e, const double *b_data, int64_t b_start, int64_t b_end,
+    const double *prev_b_data, int64_t prev_b_start, int64_t prev_b_end,
+    const double *prev_b_fwd_data, const int64_t *prev_b_last_diag, int64_t min_obs_per_base,
+    double *b_fwd_data, int64_t *b_last_diag);
+/* c_base_traceback, _c_dynamic_programming.pyx:165-182: *sig_pos = the new base boundary, or
+ * -1 where the reference returns None */
+int tba_c_base_traceback(tba_engine *e, const double *curr_b_data, int64_t curr_len,
+    int64_t curr_start, const double *next_b_data, int64_t next_len, int64_t next_start,
+    int64_t next_end, int64_t sig_start, int64_t min_obs_per_base, int64_t *sig_pos);
+
 /* self-test: out[i] = the row-constant division used inside the DP kernel (reciprocal + two
  * residual corrections) for a[i] / b[i]; must equal the IEEE quotient bit for bit */
 int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,

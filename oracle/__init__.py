@@ -235,3 +235,55 @@ def valid_cpts(sig, min_base_obs, width, num_cpts, ttest=False):
     rc = fn(_p(sig), i64(sig.shape[0]), i64(min_base_obs), i64(width), i64(num_cpts),
             _p(out, C.c_int64))
     return rc, out
+
+
+def new_mean_stds(sig, segs):
+    sig, segs = _c(sig, np.float64), _c(segs, np.int64)
+    m, s = np.empty(segs.shape[0] - 1), np.empty(segs.shape[0] - 1)
+    lib().orc_new_mean_stds(_p(sig), _p(segs, C.c_int64), i64(segs.shape[0] - 1), _p(m), _p(s))
+    return m, s
+
+
+def compute_slopes(ev, model, max_slope=1000.0):
+    ev, model = _c(ev, np.float64), _c(model, np.float64)
+    n = ev.shape[0]
+    out = np.empty(n * (n - 1) // 2)
+    lib().orc_compute_slopes(_p(ev), _p(model), i64(n), f64(max_slope), _p(out))
+    return out
+
+
+def reg_z_scores(r_sig, r_ref_means, r_ref_sds, r_b_starts, reg_start, reg_end, max_base_shift,
+                 min_obs_per_base, max_half_z_score=None):
+    """list of (z_scores, (rel_start, rel_end)) like c_reg_z_scores"""
+    r_sig, r_b_starts = _c(r_sig, np.float64), _c(r_b_starts, np.int64)
+    n = reg_end - reg_start
+    ss, se = np.empty(n, np.int64), np.empty(n, np.int64)
+    lib().orc_reg_z_bounds(_p(r_b_starts, C.c_int64), i64(reg_start), i64(reg_end),
+                           i64(max_base_shift), i64(min_obs_per_base), _p(ss, C.c_int64),
+                           _p(se, C.c_int64))
+    base = int(r_b_starts[reg_start])
+    return [(base_z_scores(r_sig[ss[i]:se[i]], r_ref_means[reg_start + i],
+                           r_ref_sds[reg_start + i], max_half_z_score is not None,
+                           max_half_z_score if max_half_z_score is not None else 0.0),
+             (int(ss[i]) - base, int(se[i]) - base)) for i in range(n)]
+
+
+def base_forward_pass(b_data, b_start, b_end, prev_b_data, prev_b_start, prev_b_end,
+                      prev_b_fwd_data, prev_b_last_diag, min_obs_per_base):
+    b_data, prev_b_data = _c(b_data, np.float64), _c(prev_b_data, np.float64)
+    pf, pl = _c(prev_b_fwd_data, np.float64), _c(prev_b_last_diag, np.int64)
+    fwd, ld = np.empty(b_end - b_start), np.empty(b_end - b_start, np.int64)
+    lib().orc_base_forward_pass.restype = C.c_int
+    rc = lib().orc_base_forward_pass(
+        _p(b_data), i64(b_start), i64(b_end), _p(prev_b_data), i64(prev_b_start),
+        i64(prev_b_end), _p(pf), _p(pl, C.c_int64), i64(min_obs_per_base), _p(fwd),
+        _p(ld, C.c_int64))
+    return rc, fwd, ld
+
+
+def base_traceback(curr_b_data, curr_start, next_b_data, next_start, next_end, sig_start,
+                   min_obs_per_base):
+    cur, nxt = _c(curr_b_data, np.float64), _c(next_b_data, np.float64)
+    lib().orc_base_traceback.restype = C.c_int64
+    return int(lib().orc_base_traceback(_p(cur), i64(curr_start), _p(nxt), i64(next_start),
+                                        i64(next_end), i64(sig_start), i64(min_obs_per_base)))

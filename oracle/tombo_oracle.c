@@ -880,6 +880,108 @@ static int orc_raw_window_dp(const double *sig, i64 L, const double *means, cons
     return rc;
 }
 
+/* ---- stand-alone forms of the raw-signal DP kernels (the Cython call signatures) -------- */
+
+/* c_reg_z_scores, _c_dynamic_programming.pyx:34-97: admissible signal interval of every base
+ * of [reg_start, reg_end) (absolute positions in r_sig).  The z-scores themselves are
+ * orc_base_z_scores over r_sig[sig_starts[i]:sig_ends[i]]; the reference returns the bounds
+ * relative to r_b_starts[reg_start]. */
+void orc_reg_z_bounds(const i64 *r_b_starts, i64 reg_start, i64 reg_end, i64 max_base_shift,
+                      i64 min_obs_per_base, i64 *sig_starts, i64 *sig_ends)
+{
+    const i64 reg_len = reg_end - reg_start;
+    i64 prev = 0;
+    for (i64 idx = 0; idx < reg_len; idx++) {
+        const i64 base_i = reg_start + idx;
+        i64 b = r_b_starts[imax(reg_start, base_i - max_base_shift)];
+        if (idx > 0 && b < prev + min_obs_per_base) b = prev + min_obs_per_base;
+        sig_starts[idx] = b;
+        prev = b;
+    }
+    for (i64 idx = 0; idx < reg_len; idx++) {
+        const i64 base_i = reg_start + (reg_len - idx - 1);
+        i64 b = r_b_starts[imin(reg_end, base_i + max_base_shift + 1)];
+        if (idx > 0 && b > prev - min_obs_per_base) b = prev - min_obs_per_base;
+        sig_ends[reg_len - idx - 1] = b;
+        prev = b;
+    }
+}
+
+/* c_base_forward_pass, _c_dynamic_programming.pyx:99-163.  Negative indices wrap like the
+ * (bounds-checked, wraparound) Cython buffer accesses; anything else out of range is the
+ * IndexError the reference would raise (ORC_INTERNAL). */
+int orc_base_forward_pass(const double *b_data, i64 b_start, i64 b_end, const double *prev_b_data,
+                          i64 prev_b_start, i64 prev_b_end, const double *prev_b_fwd_data,
+                          const i64 *prev_b_last_diag, i64 min_obs_per_base, double *b_fwd_data,
+                          i64 *b_last_diag)
+{
+    const i64 b_len = b_end - b_start, plen = prev_b_end - prev_b_start;
+    if (b_len <= 0 || plen <= 0) return ORC_INTERNAL;
+    double *cum = (double *)malloc(sizeof(double) * (size_t)plen);
+    { double acc = 0; for (i64 k = 0; k < plen; k++) { acc = k == 0 ? prev_b_data[k] : acc + prev_b_data[k]; cum[k] = acc; } }
+    int rc = ORC_OK;
+    i64 i0 = b_start - prev_b_start - 1;
+    if (i0 < 0) i0 += plen;
+    if (i0 < 0 || i0 >= plen) { free(cum); return ORC_INTERNAL; }
+    b_fwd_data[0] = b_data[0] + prev_b_fwd_data[i0];
+    b_last_diag[0] = 1;
+    for (i64 pos = b_start + 1; pos < prev_b_end + 1 && rc == ORC_OK; pos++) {
+        if (pos - b_start >= b_len) { rc = ORC_INTERNAL; break; }
+        i64 lag = 1;
+        while (1) {
+            i64 idx = pos - prev_b_start - lag;
+            if (idx < 0) idx += plen;
+            if (idx < 0 || idx >= plen) { rc = ORC_INTERNAL; break; }
+            if (prev_b_last_diag[idx] + lag <= min_obs_per_base) lag++;
+            else break;
+        }
+        if (rc != ORC_OK) break;
+        i64 di = pos - prev_b_start - lag;
+        if (di < 0) di += plen;
+        double diag = prev_b_fwd_data[di];
+        if (lag > 1) diag += cum[pos - prev_b_start - 1] - cum[di];
+        const double stay = b_fwd_data[pos - b_start - 1];
+        double best;
+        i64 dv;
+        if (diag > stay) { best = diag; dv = 1; }
+        else { best = stay; dv = b_last_diag[pos - b_start - 1] + 1; }
+        b_fwd_data[pos - b_start] = b_data[pos - b_start] + best;
+        b_last_diag[pos - b_start] = dv;
+    }
+    if (rc == ORC_OK && b_end > prev_b_end + 1) {
+        i64 at = prev_b_end - b_start;
+        if (at < 0) at += b_len;
+        if (at < 0 || at >= b_len) rc = ORC_INTERNAL;
+        else {
+            double fv = b_fwd_data[at];
+            i64 cl = b_last_diag[at];
+            for (i64 k = 0; k < b_end - prev_b_end - 1; k++) {
+                fv += b_data[k + prev_b_end - b_start + 1];
+                cl += 1;
+                b_fwd_data[k + prev_b_end - b_start + 1] = fv;
+                b_last_diag[k + prev_b_end - b_start + 1] = cl;
+            }
+        }
+    }
+    free(cum);
+    return rc;
+}
+
+/* c_base_traceback, _c_dynamic_programming.pyx:165-182; -1 where the reference falls off the
+ * loop and returns None. */
+i64 orc_base_traceback(const double *curr_b_data, i64 curr_start, const double *next_b_data,
+                       i64 next_start, i64 next_end, i64 sig_start, i64 min_obs_per_base)
+{
+    i64 cnt = 1;
+    for (i64 sp = sig_start; sp >= 0; sp--) {
+        cnt += 1;
+        if (cnt <= min_obs_per_base || sp - 1 >= next_end) continue;
+        if (sp <= curr_start) return sp;
+        if (next_b_data[sp - next_start - 1] > curr_b_data[sp - curr_start - 1]) return sp;
+    }
+    return -1;
+}
+
 typedef struct { i64 s, e; } win_t;
 
 static i64 merge_windows(win_t *w, i64 n)

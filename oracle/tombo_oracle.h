@@ -116,6 +116,13 @@ void orc_new_mean_stds(const double *sig, const i64 *segs, i64 n_segs, double *m
 void orc_apply_outlier_thresh(const double *sig, i64 n, double lo, double hi, double *out);
 void orc_compute_slopes(const double *ev, const double *model, i64 n, double max_slope,
                         double *slopes);
+void orc_reg_z_bounds(const i64 *r_b_starts, i64 reg_start, i64 reg_end, i64 max_base_shift,
+    i64 min_obs_per_base, i64 *sig_starts, i64 *sig_ends);
+int orc_base_forward_pass(const double *b_data, i64 b_start, i64 b_end, const double *prev_b_data,
+    i64 prev_b_start, i64 prev_b_end, const double *prev_b_fwd_data,
+    const i64 *prev_b_last_diag, i64 min_obs_per_base, double *b_fwd_data, i64 *b_last_diag);
+i64 orc_base_traceback(const double *curr_b_data, i64 curr_start, const double *next_b_data,
+    i64 next_start, i64 next_end, i64 sig_start, i64 min_obs_per_base);
 double orc_median(const double *x, i64 n);
 double orc_np_sum(const double *a, i64 n);
 void orc_linspace(double start, double stop, i64 num, double *out);

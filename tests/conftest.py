@@ -23,7 +23,9 @@ def sha(a):
 
 
 def golden_names():
-    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+    # read-level cases; kernels_*.npz hold stand-alone kernel vectors (test_oracle_kernels_golden)
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))
+                  if not os.path.basename(f).startswith('kernels_'))
 
 
 class GoldenCase(object):

@@ -162,3 +162,103 @@ def test_row_constant_division_is_ieee():
     want = a / b
     bad = np.flatnonzero(out != want)
     assert bad.size == 0, (bad[:5], a[bad[:5]], b[bad[:5]], out[bad[:5]], want[bad[:5]])
+
+
+# ---- raw-signal DP kernels and the remaining helpers (K7-K9, H4, H6) -----------------------
+def _kt():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                'kernels_tail.npz'))
+
+
+def _rag(g, key, i):
+    o = g[key + '_off']
+    return g[key][o[i]:o[i + 1]]
+
+
+def test_reg_z_forward_traceback_match_reference_vectors():
+    """c_reg_z_scores -> c_base_forward_pass -> c_base_traceback chained like raw_forward_pass /
+    raw_traceback (resquiggle.py:345-400), every call against the recorded reference output"""
+    from tombo_amd._c_dynamic_programming import (
+        c_reg_z_scores, c_base_forward_pass, c_base_traceback)
+    g = _kt()
+    for name in g['rz_names']:
+        p = 'rz_%s_' % name
+        rs, re_, mbs, m = (int(x) for x in g[p + 'args'])
+        mh = float(g[p + 'mh'][0])
+        res = c_reg_z_scores(g[p + 'sig'], g[p + 'means'], g[p + 'sds'], g[p + 'starts'], rs, re_,
+                             mbs, m, max_half_z_score=None if np.isnan(mh) else mh)
+        assert len(res) == re_ - rs
+        for i, (z, b) in enumerate(res):
+            assert b == tuple(g[p + 'bounds'][i])
+            np.testing.assert_array_equal(z, _rag(g, p + 'z', i))
+        # forward pass as raw_forward_pass drives it
+        prev_data, (ps, pe) = res[0]
+        fwd = np.cumsum(prev_data)
+        ld = np.ones(pe - ps, dtype=np.int64) * m
+        rows = [(fwd, (ps, pe))]
+        for k, (b_data, (bs, be)) in enumerate(res[1:]):
+            fwd, ld = c_base_forward_pass(b_data, bs, be, prev_data, ps, pe, fwd, ld, m)
+            np.testing.assert_array_equal(fwd, _rag(g, p + 'fp_fwd', k))
+            np.testing.assert_array_equal(ld, _rag(g, p + 'fp_last_diag', k))
+            rows.append((fwd, (bs, be)))
+            prev_data, ps, pe = b_data, bs, be
+        # traceback as raw_traceback drives it
+        new_segs = np.empty(len(rows) - 1, dtype=np.int64)
+        sig_start = rows[-1][1][1] - 1
+        for b in range(len(rows) - 1, 0, -1):
+            cur, (cs, _) = rows[b]
+            nxt, (ns, ne) = rows[b - 1]
+            new_segs[b - 1] = c_base_traceback(cur, cs, nxt, ns, ne, sig_start, m)
+            sig_start = new_segs[b - 1] - 1
+        np.testing.assert_array_equal(new_segs, g[p + 'new_segs'])
+
+
+def test_raw_dp_kernels_random_vs_oracle():
+    import oracle
+    from tombo_amd._c_dynamic_programming import (
+        c_reg_z_scores, c_base_forward_pass, c_base_traceback)
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n, m = int(rng.integers(2, 11)), int(rng.integers(1, 4))
+        L = int(rng.integers(n * m + 3, 200))
+        starts = np.linspace(0, L, n + 1).astype(np.int64)
+        sig, mu, sd = rng.normal(0, 1, L), rng.normal(0, 1, n), rng.uniform(0.1, 0.5, n)
+        mh = None if trial % 2 else 4.0
+        got = c_reg_z_scores(sig, mu, sd, starts, 0, n, n, m, max_half_z_score=mh)
+        want = oracle.reg_z_scores(sig, mu, sd, starts, 0, n, n, m, mh)
+        for (gz, gb), (wz, wb) in zip(got, want):
+            assert gb == wb
+            np.testing.assert_array_equal(gz, wz)
+        prev, (ps, pe) = got[0]
+        fwd, ld = np.cumsum(prev), np.full(pe - ps, m, np.int64)
+        for b_data, (bs, be) in got[1:]:
+            f2, l2 = c_base_forward_pass(b_data, bs, be, prev, ps, pe, fwd, ld, m)
+            rc, of, ol = oracle.base_forward_pass(b_data, bs, be, prev, ps, pe, fwd, ld, m)
+            assert rc == 0
+            np.testing.assert_array_equal(f2, of)
+            np.testing.assert_array_equal(l2, ol)
+            tb = c_base_traceback(f2, bs, fwd, ps, pe, be - 1, m)
+            assert (-1 if tb is None else tb) == oracle.base_traceback(f2, bs, fwd, ps, pe,
+                                                                        be - 1, m)
+            prev, ps, pe, fwd, ld = b_data, bs, be, f2, l2
+    # running off the scan returns None like the Cython function
+    assert c_base_traceback(np.zeros(3), 5, np.zeros(3), 9, 12, 2, 10) is None
+
+
+def test_slopes_and_mean_stds_match_reference_vectors():
+    import oracle
+    from tombo_amd._c_helper import c_compute_slopes, c_new_mean_stds
+    g = _kt()
+    np.testing.assert_array_equal(c_compute_slopes(g['sl_ev'], g['sl_md']), g['sl_out'])
+    np.testing.assert_array_equal(c_compute_slopes(g['sl_ev'], g['sl_md'], 5.0), g['sl_out_max5'])
+    m, s = c_new_mean_stds(g['ms_sig'], g['ms_segs'])
+    np.testing.assert_array_equal(m, g['ms_means'])
+    np.testing.assert_array_equal(s, g['ms_stds'])
+    # the size the Theil-Sen fit uses (1000 sampled bases -> 499 500 slopes)
+    rng = np.random.default_rng(2)
+    ev, md = rng.normal(0, 1, 1000), rng.normal(0, 1, 1000)
+    ev[17] = ev[400]
+    got = c_compute_slopes(ev, md)
+    np.testing.assert_array_equal(got, oracle.compute_slopes(ev, md))
+    assert got.shape[0] == 499500 and (got == 1000.0).sum() == 1

@@ -7,6 +7,9 @@ tombo_amd.h).  Same names, argument meaning, in-place behaviour and error type
   c_banded_forward_pass           :240-279
   c_banded_traceback              :281-310
   c_adaptive_banded_forward_pass  :314-412
+  c_reg_z_scores                  :34-97
+  c_base_forward_pass             :99-163
+  c_base_traceback                :165-182
 """
 import ctypes as C
 
@@ -108,3 +111,73 @@ def c_adaptive_banded_forward_pass(
         C.c_int64(int(start_seq_pos)), C.c_double(mask_fill_z_score),
         C.c_int(bool(do_winsorize_z)), C.c_double(max_half_z_score)), eng)
     return None
+
+
+def _raise_index(rc, eng):
+    # the bounds-checked Cython buffers raise IndexError where these kernels report TBA_INTERNAL
+    if rc == 100:
+        raise IndexError('Out of bounds on buffer access (axis 0)')
+    _raise(rc, eng)
+
+
+def c_reg_z_scores(r_sig, r_ref_means, r_ref_sds, r_b_starts, reg_start, reg_end,
+                   max_base_shift, min_obs_per_base, max_half_z_score=None):
+    """_c_dynamic_programming.pyx:34-97: list of (z_scores, (start, end)) per base of the region"""
+    r_sig, mu, sd = _f8(r_sig, 'r_sig'), _f8(r_ref_means, 'r_ref_means'), _f8(r_ref_sds, 'r_ref_sds')
+    starts = _i8(r_b_starts, 'r_b_starts')
+    reg_start, reg_end = int(reg_start), int(reg_end)
+    n = reg_end - reg_start
+    if n <= 0:
+        return []
+    if reg_start < 0 or reg_end >= starts.shape[0] or reg_end > mu.shape[0]:
+        raise IndexError('Out of bounds on buffer access (axis 0)')
+    cap = max(1, n * int(starts[reg_end] - starts[reg_start]))
+    bounds, off = np.empty((n, 2), np.int64), np.empty(n + 1, np.int64)
+    z = np.empty(cap, np.float64)
+    eng = _engine()
+    _raise_index(eng._L.tba_c_reg_z_scores(
+        eng._h, r_sig.ctypes.data_as(_pd), C.c_int64(r_sig.shape[0]), mu.ctypes.data_as(_pd),
+        sd.ctypes.data_as(_pd), C.c_int64(min(mu.shape[0], sd.shape[0])),
+        starts.ctypes.data_as(_pi), C.c_int64(starts.shape[0]), C.c_int64(reg_start),
+        C.c_int64(reg_end), C.c_int64(int(max_base_shift)), C.c_int64(int(min_obs_per_base)),
+        C.c_int(max_half_z_score is not None),
+        C.c_double(0.0 if max_half_z_score is None else max_half_z_score),
+        bounds.ctypes.data_as(_pi), off.ctypes.data_as(_pi), z.ctypes.data_as(_pd),
+        C.c_int64(cap)), eng)
+    return [(z[off[i]:off[i + 1]].copy(), (int(bounds[i, 0]), int(bounds[i, 1])))
+            for i in range(n)]
+
+
+def c_base_forward_pass(b_data, b_start, b_end, prev_b_data, prev_b_start, prev_b_end,
+                        prev_b_fwd_data, prev_b_last_diag, min_obs_per_base):
+    """_c_dynamic_programming.pyx:99-163: returns (b_fwd_data, b_last_diag)"""
+    b, pb = _f8(b_data, 'b_data'), _f8(prev_b_data, 'prev_b_data')
+    pf, pl = _f8(prev_b_fwd_data, 'prev_b_fwd_data'), _i8(prev_b_last_diag, 'prev_b_last_diag')
+    b_start, b_end, prev_b_start, prev_b_end = (int(x) for x in (
+        b_start, b_end, prev_b_start, prev_b_end))
+    b_len, plen = b_end - b_start, prev_b_end - prev_b_start
+    if b_len <= 0 or plen <= 0 or b.shape[0] < b_len or min(
+            pb.shape[0], pf.shape[0], pl.shape[0]) < plen:
+        raise IndexError('Out of bounds on buffer access (axis 0)')
+    fwd, ld = np.empty(b_len, np.float64), np.empty(b_len, np.int64)
+    eng = _engine()
+    _raise_index(eng._L.tba_c_base_forward_pass(
+        eng._h, b.ctypes.data_as(_pd), C.c_int64(b_start), C.c_int64(b_end),
+        pb.ctypes.data_as(_pd), C.c_int64(prev_b_start), C.c_int64(prev_b_end),
+        pf.ctypes.data_as(_pd), pl.ctypes.data_as(_pi), C.c_int64(int(min_obs_per_base)),
+        fwd.ctypes.data_as(_pd), ld.ctypes.data_as(_pi)), eng)
+    return fwd, ld
+
+
+def c_base_traceback(curr_b_data, curr_start, next_b_data, next_start, next_end, sig_start,
+                     min_obs_per_base):
+    """_c_dynamic_programming.pyx:165-182: the new boundary, or None when the scan runs out"""
+    cur, nxt = _f8(curr_b_data, 'curr_b_data'), _f8(next_b_data, 'next_b_data')
+    out = C.c_int64(-1)
+    eng = _engine()
+    _raise_index(eng._L.tba_c_base_traceback(
+        eng._h, cur.ctypes.data_as(_pd), C.c_int64(cur.shape[0]), C.c_int64(int(curr_start)),
+        nxt.ctypes.data_as(_pd), C.c_int64(nxt.shape[0]), C.c_int64(int(next_start)),
+        C.c_int64(int(next_end)), C.c_int64(int(sig_start)), C.c_int64(int(min_obs_per_base)),
+        C.byref(out)), eng)
+    return None if out.value < 0 else int(out.value)

@@ -7,6 +7,8 @@ the per-kernel C ABI (tba_c_*):
                                         sorts -- this one returns them sorted already, which
                                         the wrapper's .sort() leaves unchanged)
   c_valid_cpts_w_cap_t_test  :144-202
+  c_new_mean_stds            :38-57
+  c_compute_slopes           :362-377
 """
 import ctypes as C
 
@@ -54,3 +56,28 @@ def c_valid_cpts_w_cap(raw_signal, min_base_obs, running_stat_width, num_cpts):
 def c_valid_cpts_w_cap_t_test(raw_signal, min_base_obs, running_stat_width, num_cpts):
     return _cpts('tba_c_valid_cpts_w_cap_t_test', raw_signal, min_base_obs, running_stat_width,
                  num_cpts)
+
+
+def c_new_mean_stds(norm_signal, new_segs):
+    """_c_helper.pyx:38-57: (means, population sds) of the segments"""
+    sig, segs = _f8(norm_signal, 'norm_signal'), _i8(new_segs, 'new_segs')
+    n = segs.shape[0] - 1
+    means, stds = np.empty(n, dtype=np.float64), np.empty(n, dtype=np.float64)
+    eng = _engine()
+    _raise(eng._L.tba_c_new_mean_stds(
+        eng._h, sig.ctypes.data_as(_pd), C.c_int64(sig.shape[0]), segs.ctypes.data_as(_pi),
+        C.c_int64(n), means.ctypes.data_as(_pd), stds.ctypes.data_as(_pd)), eng)
+    return means, stds
+
+
+def c_compute_slopes(r_event_means, r_model_means, max_slope=1000.0):
+    """_c_helper.pyx:362-377: all pairwise slopes in itertools.combinations order"""
+    ev, md = _f8(r_event_means, 'r_event_means'), _f8(r_model_means, 'r_model_means')
+    n = ev.shape[0]
+    assert md.shape[0] == n
+    out = np.empty(n * (n - 1) // 2, dtype=np.float64)
+    eng = _engine()
+    _raise(eng._L.tba_c_compute_slopes(
+        eng._h, ev.ctypes.data_as(_pd), md.ctypes.data_as(_pd), C.c_int64(n),
+        C.c_double(max_slope), out.ctypes.data_as(_pd)), eng)
+    return out

@@ -53,3 +53,158 @@ __global__ void k_c_div_check(const double *a, const double *b, i64 n, double *o
         out[i] = div_by_recip(a[i], b[i], y);
     }
 }
+
+// c_new_mean_stds, _c_helper.pyx:38-57 (population sd around the segment mean)
+__global__ void k_c_new_mean_stds(const double *sig, const i64 *segs, i64 n_segs, double *means,
+                                  double *stds)
+{
+    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < n_segs; s += (i64)gridDim.x * blockDim.x) {
+        const double len = (double)(segs[s + 1] - segs[s]);
+        double acc = 0;
+        for (i64 j = segs[s]; j < segs[s + 1]; j++) acc += sig[j];
+        const double m = acc / len;
+        means[s] = m;
+        double v = 0;
+        for (i64 j = segs[s]; j < segs[s + 1]; j++) { const double d = sig[j] - m; v += d * d; }
+        stds[s] = sqrt(v / len);
+    }
+}
+
+// c_compute_slopes, _c_helper.pyx:362-377: itertools.combinations order, row i of the upper
+// triangle starts at i*(2n-i-1)/2.  grid.x = n rows.
+__global__ void k_c_compute_slopes(const double *ev, const double *md, i64 n, double max_slope,
+                                   double *slopes)
+{
+    const i64 i = blockIdx.x;
+    const double ei = ev[i], mi = md[i];
+    double *row = slopes + i * (2 * n - i - 1) / 2 - (i + 1);
+    for (i64 j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+        const double ej = ev[j];
+        row[j] = ei == ej ? max_slope : (mi - md[j]) / (ei - ej);
+    }
+}
+
+// c_reg_z_scores, _c_dynamic_programming.pyx:34-97, bounds part (a serial clip chain in both
+// directions): absolute [start, end) of each base of the region and the z-score offsets.
+__global__ void k_c_reg_bounds(const i64 *r_b_starts, i64 reg_start, i64 reg_end,
+    i64 max_base_shift, i64 m, i64 *sig_starts, i64 *sig_ends, i64 *z_off)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const i64 reg_len = reg_end - reg_start;
+    i64 prev = 0;
+    for (i64 idx = 0; idx < reg_len; idx++) {
+        const i64 base_i = reg_start + idx;
+        const i64 lo = base_i - max_base_shift;
+        i64 b = r_b_starts[lo > reg_start ? lo : reg_start];
+        if (idx > 0 && b < prev + m) b = prev + m;
+        sig_starts[idx] = b;
+        prev = b;
+    }
+    for (i64 idx = 0; idx < reg_len; idx++) {
+        const i64 base_i = reg_start + (reg_len - idx - 1);
+        const i64 hi = base_i + max_base_shift + 1;
+        i64 b = r_b_starts[hi < reg_end ? hi : reg_end];
+        if (idx > 0 && b > prev - m) b = prev - m;
+        sig_ends[reg_len - idx - 1] = b;
+        prev = b;
+    }
+    i64 acc = 0;
+    for (i64 idx = 0; idx < reg_len; idx++) {
+        z_off[idx] = acc;
+        const i64 l = sig_ends[idx] - sig_starts[idx];
+        acc += l > 0 ? l : 0;
+    }
+    z_off[reg_len] = acc;
+}
+
+// z-score part: block b = base reg_start + b over r_sig[sig_starts[b]:sig_ends[b]]
+__global__ void k_c_reg_z(const double *r_sig, i64 n_sig, const double *means, const double *sds,
+    i64 reg_start, const i64 *sig_starts, const i64 *sig_ends, const i64 *z_off, i64 z_cap,
+    int winsor, double mh, double *z, i32 *status)
+{
+    const i64 b = blockIdx.x;
+    const i64 s = sig_starts[b], e = sig_ends[b];
+    if (e <= s) return;
+    if (s < 0 || e > n_sig || z_off[b] + (e - s) > z_cap) { if (threadIdx.x == 0) *status = TBA_INTERNAL; return; }
+    const double mu = means[reg_start + b], sd = sds[reg_start + b];
+    double *out = z + z_off[b];
+    for (i64 k = threadIdx.x; k < e - s; k += blockDim.x) {
+        double v = (r_sig[s + k] - mu) / sd;
+        if (v > 0) v = -v;
+        if (winsor && v < -mh) v = -mh;
+        out[k] = v;
+    }
+}
+
+// c_base_forward_pass, _c_dynamic_programming.pyx:99-163 (one serial chain; one thread).
+// Negative indices wrap like the Cython buffer accesses, other out-of-range accesses are the
+// reference's IndexError (TBA_INTERNAL).
+__global__ void k_c_base_forward_pass(const double *b_data, i64 b_start, i64 b_end,
+    const double *prev_b_data, i64 prev_b_start, i64 prev_b_end, const double *prev_fwd,
+    const i64 *prev_last_diag, i64 m, double *cum, double *b_fwd, i64 *b_last_diag, i32 *status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const i64 b_len = b_end - b_start, plen = prev_b_end - prev_b_start;
+    { double acc = 0; for (i64 k = 0; k < plen; k++) { acc = k == 0 ? prev_b_data[k] : acc + prev_b_data[k]; cum[k] = acc; } }
+    i64 i0 = b_start - prev_b_start - 1;
+    if (i0 < 0) i0 += plen;
+    if (i0 < 0 || i0 >= plen) { *status = TBA_INTERNAL; return; }
+    b_fwd[0] = b_data[0] + prev_fwd[i0];
+    b_last_diag[0] = 1;
+    for (i64 pos = b_start + 1; pos < prev_b_end + 1; pos++) {
+        if (pos - b_start >= b_len) { *status = TBA_INTERNAL; return; }
+        i64 lag = 1;
+        for (;;) {
+            i64 idx = pos - prev_b_start - lag;
+            if (idx < 0) idx += plen;
+            if (idx < 0 || idx >= plen) { *status = TBA_INTERNAL; return; }
+            if (prev_last_diag[idx] + lag <= m) lag++;
+            else break;
+        }
+        i64 di = pos - prev_b_start - lag;
+        if (di < 0) di += plen;
+        double diag = prev_fwd[di];
+        if (lag > 1) diag += cum[pos - prev_b_start - 1] - cum[di];
+        const double stay = b_fwd[pos - b_start - 1];
+        double best;
+        i64 dv;
+        if (diag > stay) { best = diag; dv = 1; }
+        else { best = stay; dv = b_last_diag[pos - b_start - 1] + 1; }
+        b_fwd[pos - b_start] = b_data[pos - b_start] + best;
+        b_last_diag[pos - b_start] = dv;
+    }
+    if (b_end > prev_b_end + 1) {
+        i64 at = prev_b_end - b_start;
+        if (at < 0) at += b_len;
+        if (at < 0 || at >= b_len) { *status = TBA_INTERNAL; return; }
+        double fv = b_fwd[at];
+        i64 cl = b_last_diag[at];
+        for (i64 k = 0; k < b_end - prev_b_end - 1; k++) {
+            fv += b_data[k + prev_b_end - b_start + 1];
+            cl += 1;
+            b_fwd[k + prev_b_end - b_start + 1] = fv;
+            b_last_diag[k + prev_b_end - b_start + 1] = cl;
+        }
+    }
+}
+
+// c_base_traceback, _c_dynamic_programming.pyx:165-182; *out = -1 where the reference runs off
+// the loop (returns None)
+__global__ void k_c_base_traceback(const double *curr, i64 curr_len, i64 curr_start,
+    const double *next, i64 next_len, i64 next_start, i64 next_end, i64 sig_start, i64 m,
+    i64 *out, i32 *status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    i64 cnt = 1;
+    *out = -1;
+    for (i64 sp = sig_start; sp >= 0; sp--) {
+        cnt += 1;
+        if (cnt <= m || sp - 1 >= next_end) continue;
+        if (sp <= curr_start) { *out = sp; return; }
+        i64 ni = sp - next_start - 1, ci = sp - curr_start - 1;
+        if (ni < 0) ni += next_len;
+        if (ci < 0) ci += curr_len;
+        if (ni < 0 || ni >= next_len || ci < 0 || ci >= curr_len) { *status = TBA_INTERNAL; return; }
+        if (next[ni] > curr[ci]) { *out = sp; return; }
+    }
+}

@@ -865,6 +865,162 @@ extern "C" int tba_c_valid_cpts_w_cap_t_test(tba_engine *e, const double *sig, i
     return c_valid_cpts(e, sig, n, min_base_obs, running_stat_width, num_cpts, cpts, 1);
 }
 
+extern "C" int tba_c_new_mean_stds(tba_engine *e, const double *norm_signal, int64_t n_sig,
+    const int64_t *new_segs, int64_t n_segs, double *means, double *stds)
+{
+    if (!e || !norm_signal || !new_segs || !means || !stds || n_segs < 0 || n_sig < 0)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (n_segs == 0) return TBA_OK;
+    for (i64 i = 0; i <= n_segs; i++)
+        if (new_segs[i] < 0 || new_segs[i] > n_sig || (i > 0 && new_segs[i] < new_segs[i - 1]))
+            return set_err(TBA_E_ARG, "segment boundaries outside the signal");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_sig, d_segs, d_m, d_s;
+    if (d_sig.alloc((size_t)n_sig * 8) || d_segs.alloc((size_t)(n_segs + 1) * 8) ||
+        d_m.alloc((size_t)n_segs * 8) || d_s.alloc((size_t)n_segs * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_sig.p, norm_signal, (size_t)n_sig * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_segs.p, new_segs, (size_t)(n_segs + 1) * 8, hipMemcpyHostToDevice));
+    k_c_new_mean_stds<<<grid_for(n_segs), 256, 0, e->stream>>>(d_sig.as<double>(),
+        d_segs.as<i64>(), n_segs, d_m.as<double>(), d_s.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(means, d_m.p, (size_t)n_segs * 8, hipMemcpyDeviceToHost));
+    C_TRY(hipMemcpy(stds, d_s.p, (size_t)n_segs * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+extern "C" int tba_c_compute_slopes(tba_engine *e, const double *r_event_means,
+    const double *r_model_means, int64_t n, double max_slope, double *slopes)
+{
+    if (!e || !r_event_means || !r_model_means || !slopes || n < 0)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (n < 2) return TBA_OK;
+    if (n > 65535) return set_err(TBA_E_ARG, "too many points");
+    const size_t ns = (size_t)n * (size_t)(n - 1) / 2;
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_ev, d_md, d_out;
+    if (d_ev.alloc((size_t)n * 8) || d_md.alloc((size_t)n * 8) || d_out.alloc(ns * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_ev.p, r_event_means, (size_t)n * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_md.p, r_model_means, (size_t)n * 8, hipMemcpyHostToDevice));
+    k_c_compute_slopes<<<dim3((unsigned)(n - 1)), 256, 0, e->stream>>>(d_ev.as<double>(),
+        d_md.as<double>(), n, max_slope, d_out.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(slopes, d_out.p, ns * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+extern "C" int tba_c_reg_z_scores(tba_engine *e, const double *r_sig, int64_t n_sig,
+    const double *r_ref_means, const double *r_ref_sds, int64_t n_bases,
+    const int64_t *r_b_starts, int64_t n_b_starts, int64_t reg_start, int64_t reg_end,
+    int64_t max_base_shift, int64_t min_obs_per_base, int do_winsorize_z,
+    double max_half_z_score, int64_t *bounds, int64_t *z_off, double *z, int64_t z_cap)
+{
+    if (!e || !r_sig || !r_ref_means || !r_ref_sds || !r_b_starts || !bounds || !z_off || !z ||
+        n_sig < 0 || z_cap < 0)
+        return set_err(TBA_E_ARG, "bad arguments");
+    const i64 reg_len = reg_end - reg_start;
+    if (reg_start < 0 || reg_len <= 0 || reg_end > n_bases || reg_end >= n_b_starts ||
+        max_base_shift < 0)
+        return set_err(TBA_E_ARG, "region outside the bases / base starts");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_sig, d_mu, d_sd, d_bs, d_ss, d_se, d_off, d_z, d_st;
+    if (d_sig.alloc((size_t)n_sig * 8) || d_mu.alloc((size_t)n_bases * 8) ||
+        d_sd.alloc((size_t)n_bases * 8) || d_bs.alloc((size_t)n_b_starts * 8) ||
+        d_ss.alloc((size_t)reg_len * 8) || d_se.alloc((size_t)reg_len * 8) ||
+        d_off.alloc((size_t)(reg_len + 1) * 8) || d_z.alloc((size_t)z_cap * 8) || d_st.alloc(4))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_sig.p, r_sig, (size_t)n_sig * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_mu.p, r_ref_means, (size_t)n_bases * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_sd.p, r_ref_sds, (size_t)n_bases * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_bs.p, r_b_starts, (size_t)n_b_starts * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemsetAsync(d_st.p, 0, 4, e->stream));
+    k_c_reg_bounds<<<1, 64, 0, e->stream>>>(d_bs.as<i64>(), reg_start, reg_end, max_base_shift,
+        min_obs_per_base, d_ss.as<i64>(), d_se.as<i64>(), d_off.as<i64>());
+    k_c_reg_z<<<dim3((unsigned)reg_len), 64, 0, e->stream>>>(d_sig.as<double>(), n_sig,
+        d_mu.as<double>(), d_sd.as<double>(), reg_start, d_ss.as<i64>(), d_se.as<i64>(),
+        d_off.as<i64>(), z_cap, do_winsorize_z, max_half_z_score, d_z.as<double>(),
+        d_st.as<i32>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    std::vector<i64> ss(reg_len), se(reg_len);
+    i32 st = 0;
+    C_TRY(hipMemcpy(&st, d_st.p, 4, hipMemcpyDeviceToHost));
+    C_TRY(hipMemcpy(ss.data(), d_ss.p, (size_t)reg_len * 8, hipMemcpyDeviceToHost));
+    C_TRY(hipMemcpy(se.data(), d_se.p, (size_t)reg_len * 8, hipMemcpyDeviceToHost));
+    C_TRY(hipMemcpy(z_off, d_off.p, (size_t)(reg_len + 1) * 8, hipMemcpyDeviceToHost));
+    if (z_off[reg_len] > z_cap) return set_err(TBA_E_ARG, "z-score buffer too small");
+    if (st != 0) return set_err(TBA_E_ARG, "base intervals outside the signal");
+    const i64 base = r_b_starts[reg_start];
+    for (i64 i = 0; i < reg_len; i++) { bounds[2 * i] = ss[i] - base; bounds[2 * i + 1] = se[i] - base; }
+    if (z_off[reg_len] > 0)
+        C_TRY(hipMemcpy(z, d_z.p, (size_t)z_off[reg_len] * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+extern "C" int tba_c_base_forward_pass(tba_engine *e, const double *b_data, int64_t b_start,
+    int64_t b_end, const double *prev_b_data, int64_t prev_b_start, int64_t prev_b_end,
+    const double *prev_b_fwd_data, const int64_t *prev_b_last_diag, int64_t min_obs_per_base,
+    double *b_fwd_data, int64_t *b_last_diag)
+{
+    if (!e || !b_data || !prev_b_data || !prev_b_fwd_data || !prev_b_last_diag || !b_fwd_data ||
+        !b_last_diag)
+        return set_err(TBA_E_ARG, "bad arguments");
+    const i64 b_len = b_end - b_start, plen = prev_b_end - prev_b_start;
+    if (b_len <= 0 || plen <= 0) return set_err(TBA_E_ARG, "empty base interval");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_b, d_pb, d_pf, d_pl, d_cum, d_f, d_l, d_st;
+    if (d_b.alloc((size_t)b_len * 8) || d_pb.alloc((size_t)plen * 8) ||
+        d_pf.alloc((size_t)plen * 8) || d_pl.alloc((size_t)plen * 8) ||
+        d_cum.alloc((size_t)plen * 8) || d_f.alloc((size_t)b_len * 8) ||
+        d_l.alloc((size_t)b_len * 8) || d_st.alloc(4))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_b.p, b_data, (size_t)b_len * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_pb.p, prev_b_data, (size_t)plen * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_pf.p, prev_b_fwd_data, (size_t)plen * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_pl.p, prev_b_last_diag, (size_t)plen * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemsetAsync(d_st.p, 0, 4, e->stream));
+    k_c_base_forward_pass<<<1, 64, 0, e->stream>>>(d_b.as<double>(), b_start, b_end,
+        d_pb.as<double>(), prev_b_start, prev_b_end, d_pf.as<double>(), d_pl.as<i64>(),
+        min_obs_per_base, d_cum.as<double>(), d_f.as<double>(), d_l.as<i64>(), d_st.as<i32>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    i32 st = 0;
+    C_TRY(hipMemcpy(&st, d_st.p, 4, hipMemcpyDeviceToHost));
+    if (st != 0) return st;
+    C_TRY(hipMemcpy(b_fwd_data, d_f.p, (size_t)b_len * 8, hipMemcpyDeviceToHost));
+    C_TRY(hipMemcpy(b_last_diag, d_l.p, (size_t)b_len * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+extern "C" int tba_c_base_traceback(tba_engine *e, const double *curr_b_data, int64_t curr_len,
+    int64_t curr_start, const double *next_b_data, int64_t next_len, int64_t next_start,
+    int64_t next_end, int64_t sig_start, int64_t min_obs_per_base, int64_t *sig_pos)
+{
+    if (!e || !curr_b_data || !next_b_data || !sig_pos || curr_len <= 0 || next_len <= 0)
+        return set_err(TBA_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_c, d_n, d_out, d_st;
+    if (d_c.alloc((size_t)curr_len * 8) || d_n.alloc((size_t)next_len * 8) || d_out.alloc(8) ||
+        d_st.alloc(4))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_c.p, curr_b_data, (size_t)curr_len * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_n.p, next_b_data, (size_t)next_len * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemsetAsync(d_st.p, 0, 4, e->stream));
+    k_c_base_traceback<<<1, 64, 0, e->stream>>>(d_c.as<double>(), curr_len, curr_start,
+        d_n.as<double>(), next_len, next_start, next_end, sig_start, min_obs_per_base,
+        d_out.as<i64>(), d_st.as<i32>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    i32 st = 0;
+    C_TRY(hipMemcpy(&st, d_st.p, 4, hipMemcpyDeviceToHost));
+    if (st != 0) return st;
+    C_TRY(hipMemcpy(sig_pos, d_out.p, 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
 extern "C" int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,
                                      double *out)
 {
