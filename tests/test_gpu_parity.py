@@ -89,7 +89,8 @@ def compare_batch(eng, oracles, out, label=''):
             else:
                 chk(i, 'static_W', path[i, 2], len(d['fwd_last_row']))
             chk(i, 'band_starts', bst[r0:r1], d['band_event_starts'])
-            chk(i, 'last_row', lastrow[i, :len(d['fwd_last_row'])], d['fwd_last_row'])
+            if len(d['fwd_last_row']) <= lastrow.shape[1]:  # not kept for the wide static DP
+                chk(i, 'last_row', lastrow[i, :len(d['fwd_last_row'])], d['fwd_last_row'])
             chk(i, 'read_tb', rtb[s0:s1], d['read_tb'])
             chk(i, 'dp_segs', dps[s0:s1], d['dp_segs'])
             chk(i, 'dp_read_start', dprs[i], d['dp_read_start'])
@@ -389,3 +390,26 @@ def test_degenerate_inputs_on_gpu():
     assert all(isinstance(r, Exception) for r in res[:4])
     assert isinstance(res[3], th.TomboError) and 'Invalid sequence' in str(res[3])
     assert not isinstance(res[4], Exception) and res[4].segs.shape[0] == 501
+
+
+def test_wide_static_band_matches_oracle():
+    """short reads with a lot of signal: find_static_base_assignment's band is n_events -
+    mask_len cells wide (resquiggle.py:566-570), far beyond the register band classes ->
+    k_dp_wide.  Reached in practice through the save-bandwidth retry (resquiggle.py:1587)."""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    save = ts.load_resquiggle_parameters(samp, use_save_bandwidth=True)
+    reads = []
+    for nb, seed, kw in [(20, 9, dict(lead=60000)), (100, 31, dict(mean_dwell=300)),
+                         (249, 32, dict(lead=30000)), (180, 33, {}), (1200, 34, {})]:
+        seq, raw, _ = synth.synth_read(model, nb, seed, **kw)
+        reads.append((raw, seq, None, _si(nb, seed)))
+    eng, out, oracles = run_batch(model, save, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'wide')
+    assert not bad, '\n'.join(bad[:20])
+    from tombo_amd import _native as N
+    path = eng.get(N.GET_PATH)
+    assert (path[:3, 0] == 2).all() and (path[:3, 2] > 3072).all(), path   # wide static bands
+    assert path[3, 2] <= 3072 and path[4, 0] == 1
+    assert sum(o['status'] == 0 for o in oracles) >= 4

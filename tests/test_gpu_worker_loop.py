@@ -1,0 +1,116 @@
+"""GPU: the caller's loop around resquiggle_read (`_resquiggle_worker.run_rsqgl_iters` and the
+save-parameter retry, resquiggle.py:1492-1504,1578-1589) over the batch engine, against the same
+loop driven through the oracle read by read."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_pass(model, params, mr, samp_name, outlier_thresh, samp_ind, scale_values=None,
+                 const_scale=None, skip_seq_scaling=False):
+    import oracle
+    from tombo_amd import tombo_stats as ts
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=outlier_thresh,
+                         const_scale=const_scale, scale_values=scale_values,
+                         skip_seq_scaling=skip_seq_scaling,
+                         sig_match_thresh=SIG_MATCH_THRESH[samp_name])
+    return oracle.resquiggle_read(mr.raw_signal, ts.encode_seq(mr.genome_seq), model.level_means,
+                                  model.level_sds, oracle.make_params(params), o,
+                                  stall_ints=mr.stall_ints, samp_ind=samp_ind)
+
+
+def _oracle_loop(model, map_results, idx, params, samp_name, outlier_thresh, max_iters, passes):
+    """round-major emulation: every read of a round longer than 1000 bases draws its Theil-Sen
+    subsample from the global RNG in read order, exactly like resquiggle_batch"""
+    from tombo_amd import tombo_helper as th
+    K = model.kmer_width
+
+    def draw(i):
+        b = len(map_results[i].genome_seq) - K + 1
+        return np.random.choice(b, 1000, replace=False) if b > 1000 else None
+    res = {}
+    si = [draw(i) for i in idx]
+    for i, s in zip(idx, si):
+        res[i] = _oracle_pass(model, params, map_results[i], samp_name, outlier_thresh, s)
+        passes[i] += 1
+    it = 1
+    while it < max_iters:
+        again = [i for i in idx if res[i]['status'] == 0 and res[i]['norm_params_changed']]
+        if not again:
+            break
+        si = [draw(i) for i in again]
+        for i, s in zip(again, si):
+            sv = res[i]['scale_values']
+            res[i] = _oracle_pass(model, params, map_results[i], samp_name, outlier_thresh, s,
+                                  scale_values=th.scaleValues(sv[0], sv[1], sv[2], sv[3],
+                                                              outlier_thresh))
+            passes[i] += 1
+        it += 1
+    return res
+
+
+def test_worker_loop_matches_oracle_loop():
+    from tombo_amd import resquiggle as rq, synth, tombo_stats as ts, tombo_helper as th
+    from tombo_amd import errors
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    # narrow main band so that some reads need the save-bandwidth retry
+    aln = (4.2, 4.2, 100, 1500, 20.0, 40, 750, 2500, 250)
+    params = ts.load_resquiggle_parameters(samp, sig_aln_params=aln)
+    save = ts.load_resquiggle_parameters(samp, sig_aln_params=aln, use_save_bandwidth=True)
+    assert params.bandwidth == 100 and save.bandwidth == 1500
+    mrs = [synth.synth_map_res(model, 600, 1), synth.synth_map_res(model, 1200, 2),
+           synth.synth_map_res(model, 2000, 0), synth.synth_map_res(model, 1500, 6, lead=5000),
+           synth.synth_map_res(model, 20, 9, lead=60000),
+           synth.synth_map_res(model, 900, 3, scale=15.0, offset=40.0),
+           synth.synth_map_res(model, 300, 5), synth.synth_map_res(model, 3, 10, lead=60000)]
+    mrs = [rq.adjust_map_res(m, samp) for m in mrs]
+    np.random.seed(3)
+    got, passes = rq.resquiggle_batch_iters(mrs, model, params, save, outlier_thresh=5.0,
+                                            seq_samp_type=samp, return_passes=True)
+    # the same loop through the oracle
+    np.random.seed(3)
+    want_p = [0] * len(mrs)
+    want = _oracle_loop(model, mrs, list(range(len(mrs))), params, 'DNA', 5.0, 3, want_p)
+    failed = [i for i in range(len(mrs)) if want[i]['status'] != 0]
+    if failed:
+        want.update(_oracle_loop(model, mrs, failed, save, 'DNA', 5.0, 3, want_p))
+    assert passes == want_p
+    assert failed, 'the narrow band should send at least one read to the save-parameter retry'
+    assert max(passes) >= 2
+    n_ok = 0
+    for i in range(len(mrs)):
+        w = want[i]
+        if w['status'] != 0:
+            assert isinstance(got[i], th.TomboError) and str(got[i]) == errors.MESSAGES[w['status']]
+            continue
+        n_ok += 1
+        g = got[i]
+        np.testing.assert_array_equal(g.segs, w['segs'])
+        assert g.read_start_rel_to_raw == w['read_start_rel_to_raw']
+        np.testing.assert_array_equal(g.raw_signal, w['norm_signal'])
+        assert g.sig_match_score == w['sig_match_score']
+        assert g.norm_params_changed == bool(w['norm_params_changed'])
+        assert (g.scale_values.shift, g.scale_values.scale) == tuple(w['scale_values'][:2])
+    # 3 bases under a 60k-sample leader fail with both parameter sets; 20 bases pass with the
+    # save bandwidth (through the wide static band)
+    assert n_ok == len(mrs) - 1 and isinstance(got[-1], th.TomboError)
+
+
+def test_adjust_map_res_rna_flips_and_finds_stalls():
+    from tombo_amd import resquiggle as rq, synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('RNA', True)
+    model = ts.TomboModel(seq_samp_type=samp)
+    mr = synth.synth_map_res(model, 300, 4, **synth.RNA_SYNTH)
+    # the worker receives 3'->5' signal; adjust_map_res flips it (resquiggle.py:1516)
+    flipped = mr._replace(raw_signal=mr.raw_signal[::-1].copy())
+    adj = rq.adjust_map_res(flipped, samp)
+    np.testing.assert_array_equal(adj.raw_signal, mr.raw_signal)
+    want = ts.identify_stalls(mr.raw_signal)
+    assert len(adj.stall_ints) == len(want)
+    params = ts.load_resquiggle_parameters(samp)
+    res = rq.resquiggle_batch_iters([adj], model, params, None, outlier_thresh=5.0,
+                                    seq_samp_type=samp)
+    assert not isinstance(res[0], Exception) and res[0].segs.shape[0] == 301

@@ -98,6 +98,13 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
 // bytes of packed 2-bit moves per lane per row: 4 cells per byte, so a row is plainly linear
 // (cell b -> byte b/4, bits 2*(b%4)) and 16*CPL bytes long
 __host__ __device__ constexpr int mv_bpl(int cpl) { return cpl / 4; }
+// bytes of one packed 2-bit move row of a W-cell band: the band class' row (64 lanes x cpl/4
+// bytes) or, for bands wider than every class (k_dp_wide), W rounded up to 256 cells
+__host__ __device__ inline i64 mv_row_bytes(i64 W)
+{
+    const int c = cpl_class(W);
+    return c ? (i64)64 * mv_bpl(c) : ((W + 255) / 256) * 64;
+}
 
 // wave-uniform values the compiler cannot prove uniform (they come from vector loads or
 // shuffles) are moved to scalar registers explicitly, so that control flow on them is scalar
@@ -464,6 +471,99 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     }
 }
 
+// Static whole-read DP (find_static_base_assignment, resquiggle.py:547-600 over
+// c_banded_forward_pass, pyx:240-279) for bands wider than the widest register class: a short
+// read with a lot of signal gets a band of n_events - mask_len cells.  Rare and small in rows
+// (< start_n_bases bases, or a failed start discovery), so: one wavefront per read, the two
+// forward rows in a global scratch slice, 64 cells per step with the stay chain resolved by
+// monotone sweeps (cell = max(non-stay candidate, (left - stay_pen) + z), iterated until no
+// lane changes; the carry crosses steps through lane 63).  Same cell arithmetic, tie rules and
+// packed 2-bit move rows as k_dp.  Blocks pick reads grid-strided; scratch = 2 * wide_w
+// doubles per block.
+__global__ __launch_bounds__(64) void k_dp_wide(ReadState *rs, i64 n_reads, const DevParams *dp,
+    const double *event_means, const double *ref_means, const double *ref_sds,
+    const i64 *band_starts, unsigned char *moves, double *scratch, i64 wide_w)
+{
+    const int lane = threadIdx.x;
+    const tba_params &P = dp->p;
+    const double stay_pen = P.stay_pen, skip_pen = P.skip_pen, z_shift = P.z_shift;
+    const double zcap = P.do_winsorize_z ? P.max_half_z_score : INFINITY;
+    const double NEG_INF = -INFINITY;
+    double *rowA = scratch + (i64)blockIdx.x * 2 * wide_w, *rowB = rowA + wide_w;
+    for (i64 ri = blockIdx.x; ri < n_reads; ri += gridDim.x) {
+        ReadState &r = rs[ri];
+        if (r.status != TBA_OK || r.path != PATH_STATIC || cpl_class(r.W) != 0) continue;
+        const i64 W = r.W, n_rows = r.B;
+        if (W > wide_w) { if (lane == 0) r.status = TBA_UNSUPPORTED; continue; }
+        const double *ev = event_means + r.ev_off + r.clip;
+        const double *rmu = ref_means + r.ref_off, *rsd = ref_sds + r.ref_off;
+        const i64 *bst = band_starts + r.ref_off;
+        unsigned char *mv = moves + r.moves_off;
+        const i64 rowb = mv_row_bytes(W);
+        double *prev = rowA, *cur = rowB;
+        for (i64 b = lane; b < W; b += 64) prev[b] = 0.0; // row 0: zeros
+        __threadfence();
+        double best_v = NEG_INF; i64 best_i = 0;
+        for (i64 row = 0; row < n_rows; row++) {
+            const i64 st = bst[row];
+            const i64 diff = row > 0 ? st - bst[row - 1] : 0;
+            const double mu = rmu[row], sd = rsd[row];
+            const bool last = row == n_rows - 1;
+            unsigned char *mrow = mv + (row + 1) * rowb;
+            double carry = NEG_INF; // value of the cell left of this step's first cell
+            best_v = NEG_INF; best_i = 0;
+            for (i64 b0 = 0; b0 < W; b0 += 64) {
+                const i64 b = b0 + lane;
+                const bool in = b < W;
+                const i64 bc = in ? b : W - 1;
+                double pz = fabs((ev[st + bc] - mu) / sd);
+                pz = __builtin_fmin(pz, zcap);
+                const double z = z_shift - pz;
+                // non-stay candidate and its move: diag (2) wins ties against skip (1)
+                const i64 pb = bc + diff;
+                double v0; int m0;
+                if (bc == 0) { // first cell, pyx:259-270
+                    if (row == 0 || diff == 0) { v0 = prev[0] - skip_pen; m0 = 1; }
+                    else { v0 = prev[diff - 1] + z; m0 = 2; }
+                } else {
+                    const double d = pb - 1 < W ? prev[pb - 1] + z : NEG_INF;
+                    const double sk = pb < W ? prev[pb] - skip_pen : NEG_INF;
+                    v0 = sk > d ? sk : d;
+                    m0 = sk > d ? 1 : 2;
+                }
+                v0 = in ? v0 : NEG_INF;
+                // stay chain: monotone sweeps to the fixed point
+                double v = v0, sv = NEG_INF;
+                for (;;) {
+                    double left = __shfl_up(v, 1, 64);
+                    left = lane == 0 ? carry : left;
+                    sv = bc == 0 ? NEG_INF : (left - stay_pen) + z;
+                    const double nv = (in && sv > v) ? sv : v;
+                    const bool ch = nv != v;
+                    v = nv;
+                    if (!__any(ch)) break;
+                }
+                // a stay is replaced only by a strictly better candidate (pyx:213-234)
+                const int m = (bc != 0 && !(v0 > sv)) ? 0 : m0;
+                carry = __shfl(v, 63, 64);
+                if (in) cur[b] = v;
+                // pack four cells per byte
+                int mm = in ? m : 0;
+                const int m1 = __shfl_down(mm, 1, 64), m2 = __shfl_down(mm, 2, 64), m3 = __shfl_down(mm, 3, 64);
+                if ((lane & 3) == 0 && in) mrow[b >> 2] = (unsigned char)(mm | (m1 << 2) | (m2 << 4) | (m3 << 6));
+                if (last && in && v > best_v) { best_v = v; best_i = b; } // first max per lane
+            }
+            __threadfence(); // the next row reads this one across lanes
+            double *t = prev; prev = cur; cur = t;
+        }
+        // np.argmax of the last row: first index of the maximum
+        const double wm = wave_max_f64(best_v);
+        i64 cand = best_v == wm ? best_i : (i64)0x7fffffffffffffffll;
+        for (int o = 32; o >= 1; o >>= 1) { const i64 t = __shfl_xor(cand, o, 64); cand = t < cand ? t : cand; }
+        if (lane == 0) r.top_pos = cand;
+    }
+}
+
 // one 2-bit move code out of the packed rows written by k_dp
 __device__ __forceinline__ int mv_get(const unsigned char *mv, i64 row, int cpl, int bpl, i64 b)
 {
@@ -598,7 +698,6 @@ __global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *ban
         const i64 mask_len = (seq_len < n_ev ? seq_len : n_ev) / 4;
         const i64 Ws = n_ev - mask_len;
         if (Ws <= 0 || seq_len - 2 * mask_len < 0) { r.status = TBA_INTERNAL; return; }
-        if (cpl_class(Ws) == 0) { r.status = TBA_UNSUPPORTED; return; }
         const i64 nz = seq_len - 2 * mask_len;
         for (i64 i = 0; i < seq_len; i++) {
             i64 s = 0;
@@ -606,7 +705,7 @@ __global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *ban
             bst[i] = s; lo_a[i] = 0; hi_a[i] = (i32)Ws;
         }
         r.path = PATH_STATIC; r.clip = 0; r.offset = 0; r.W = Ws; r.n_static = seq_len;
-        r.moves_off = (seq_len + 1) * (i64)mv_bpl(cpl_class(Ws)) * 64;
+        r.moves_off = (seq_len + 1) * mv_row_bytes(Ws); // wider than every band class: k_dp_wide
         return;
     }
     // _get_masked_start_fwd_pass on event_means[clip:]
@@ -712,7 +811,7 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, cons
     if (r.path == PATH_NONE) { r.status = TBA_INTERNAL; return; }
     const i64 B = r.B;
     const int Wi = (int)r.W;
-    const int rowb = 64 * mv_bpl(cpl_class(r.W));       // bytes per packed row (multiple of 64)
+    const int rowb = (int)mv_row_bytes(r.W);            // bytes per packed row (multiple of 64)
     const int roww = rowb / 4;                          // dwords per row
     const unsigned char *mv = moves + r.moves_off;
     const i64 *st = band_starts + r.ref_off;

@@ -47,6 +47,7 @@ static const char *STAGE_NAMES[N_STAGE] = {
     "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen", "rescale_score",
     "rna_scale", "total"};
 
+#define WIDE_BLOCKS 64 // workgroups of k_dp_wide (each owns two scratch rows)
 struct tba_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -55,7 +56,7 @@ struct tba_engine {
     bool have_model = false, have_batch = false, ran = false;
     DevParams hp;
     i64 n_reads = 0, S_tot = 0, seq_tot = 0, B_tot = 0, E_tot = 0, max_raw = 0, max_B = 0;
-    i64 start_moves_stride = 0, moves_arena = 0, skip_arena = 0;
+    i64 start_moves_stride = 0, moves_arena = 0, skip_arena = 0, wide_w = 0;
     bool any_stall = false, have_samp = false, have_sv = false;
     std::vector<i64> ne_override; // per-read num_events for the next upload (stepwise API)
     double algo_bytes = 0, dp_cells = 0;
@@ -63,14 +64,14 @@ struct tba_engine {
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_bm, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
-        d_moves, d_dscr;
+        d_moves, d_dscr, d_wide;
     void release_all()
     {
         DevBuf *all[] = {&d_rs, &d_dp, &d_kmeans, &d_ksds, &d_raw, &d_norm, &d_norm_out, &d_csum,
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_bm, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr};
+                         &d_moves, &d_dscr, &d_wide};
         for (DevBuf *b : all) b->release();
     }
 };
@@ -157,7 +158,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     e->h_rs.assign((size_t)n, ReadState());
     i64 ref_acc = 0, ev_acc = 0, max_raw = 0, max_B = 0;
     double algo_bytes = 0, cells = 0;
-    i64 moves_need = 0;
+    i64 moves_need = 0, max_nev = 0;
     const int cpl_main = cpl_class(p->bandwidth);
     for (i64 i = 0; i < n; i++) {
         ReadState &r = e->h_rs[(size_t)i];
@@ -192,9 +193,12 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
         max_B = std::max(max_B, B);
         const i64 n_ev = num_events - 1;
         const bool short_read = n_ev < p->start_bw + p->start_n_bases || B < p->start_n_bases;
-        int cpl = cpl_main;
-        if (short_read) cpl = std::max(cpl, cpl_class(std::min<i64>(n_ev, TBA_MAX_BAND)));
-        moves_need += (B + 1) * 64 * (i64)mv_bpl(cpl > 0 ? cpl : 48);
+        // packed move rows: the adaptive band, or the whole-read static band of a short read
+        // (n_ev - mask_len cells, any width: k_dp_wide beyond the widest class)
+        i64 row_bytes = mv_row_bytes(p->bandwidth);
+        if (short_read) row_bytes = std::max(row_bytes, mv_row_bytes(n_ev));
+        moves_need += (B + 1) * row_bytes;
+        max_nev = std::max(max_nev, n_ev);
         // algorithmic traffic: raw in + seq + norm out + segs + band starts +
         // 2-bit moves + scalars
         algo_bytes += 8.0 * r.n_raw + (double)r.seq_len + 8.0 * r.n_raw + 8.0 * (B + 1) + 8.0 * B +
@@ -207,6 +211,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     e->E_tot = ev_acc;
     e->max_raw = max_raw;
     e->max_B = max_B;
+    e->wide_w = max_nev > TBA_MAX_BAND ? ((max_nev + 63) / 64) * 64 : 0;
     e->algo_bytes = algo_bytes;
     e->dp_cells = cells;
     e->any_stall = stall_off != nullptr && stall_off[n] > 0;
@@ -253,6 +258,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     // do not fit the arena get TBA_UNSUPPORTED
     e->skip_arena = (i64)N * 32768 + (32ll << 20);
     rc |= e->d_dscr.ensure((size_t)e->skip_arena * 8);
+    if (e->wide_w) rc |= e->d_wide.ensure((size_t)WIDE_BLOCKS * 2 * (size_t)e->wide_w * 8);
     if (e->any_stall) rc |= e->d_stall.ensure((size_t)stall_off[n] * 16);
     if (rc) return TBA_E_NOMEM;
 
@@ -372,6 +378,8 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     if (ON(TBA_STAGE_ASSIGN)) {
         const int cls[] = {4, 8, 12, 16, 24, 32, 48};
         for (int c : cls) launch_dp(e, c, DP_MAIN);
+        if (e->wide_w) // a static band wider than every class is possible in this batch
+            k_dp_wide<<<WIDE_BLOCKS, 64, 0, s>>>(rs, n, dp, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), e->d_moves.as<unsigned char>(), e->d_wide.as<double>(), e->wide_w);
     }
     MARK(); // 10 main tb
     if (ON(TBA_STAGE_ASSIGN)) {

@@ -14,10 +14,11 @@ from . import tombo_stats as ts
 from . import errors
 from . import _native
 from ._default_parameters import (
-    MAX_RAW_CPTS, MIN_EVENT_TO_SEQ_RATIO, SIG_MATCH_THRESH, DNA_SAMP_TYPE,
+    MAX_RAW_CPTS, MIN_EVENT_TO_SEQ_RATIO, SIG_MATCH_THRESH, DNA_SAMP_TYPE, RNA_SAMP_TYPE,
     MAX_POINTS_FOR_THEIL_SEN)
 
-__all__ = ['resquiggle_read', 'resquiggle_batch', 'get_engine', 'segment_signal',
+__all__ = ['resquiggle_read', 'resquiggle_batch', 'resquiggle_batch_iters', 'adjust_map_res',
+           'get_engine', 'segment_signal',
            'find_adaptive_base_assignment', 'find_seq_start_in_events',
            'find_static_base_assignment', 'resolve_skipped_bases_with_raw']
 
@@ -343,3 +344,78 @@ def resolve_skipped_bases_with_raw(dp_res, norm_signal, rsqgl_params, max_raw_cp
     eng.run_stages(_native.STAGE_SKIP, _native.STAGE_SKIP)
     _status_or_raise(eng)
     return eng.get(_native.GET_SEGS).copy()
+
+
+# ---- the caller's loop: _resquiggle_worker, resquiggle.py:1488-1602 ------
+def adjust_map_res(map_res, seq_samp_type):
+    """What `_resquiggle_worker.adjust_map_res` (resquiggle.py:1506-1530) does to a mapped read
+    before resquiggling: RNA signal is flipped into 5'->3' order and stall intervals are
+    detected on it (`COLLAPSE_RNA_STALLS`); DNA is passed through (`COLLAPSE_DNA_STALLS` and
+    `USE_START_CLIP_BASES` are off in the reference, `TRIM_RNA_ADAPTER` too)."""
+    from ._default_parameters import COLLAPSE_RNA_STALLS, COLLAPSE_DNA_STALLS
+    if seq_samp_type.name == RNA_SAMP_TYPE:
+        map_res = map_res._replace(raw_signal=map_res.raw_signal[::-1])
+    if (COLLAPSE_RNA_STALLS and seq_samp_type.name == RNA_SAMP_TYPE) or \
+            (COLLAPSE_DNA_STALLS and seq_samp_type.name == DNA_SAMP_TYPE):
+        map_res = map_res._replace(stall_ints=ts.identify_stalls(map_res.raw_signal))
+    return map_res
+
+
+def _run_iters(map_results, idx, std_ref, params, outlier_thresh, const_scale, skip_seq_scaling,
+               seq_samp_type, max_scaling_iters, engine, n_passes):
+    """run_rsqgl_iters (resquiggle.py:1492-1504) for the reads `idx`, round by round"""
+    res = dict(zip(idx, resquiggle_batch(
+        [map_results[i] for i in idx], std_ref, params, outlier_thresh, const_scale=const_scale,
+        skip_seq_scaling=skip_seq_scaling, seq_samp_type=seq_samp_type, engine=engine)))
+    for i in idx:
+        n_passes[i] += 1
+    n_iters = 1
+    while n_iters < max_scaling_iters:
+        again = [i for i in idx if not isinstance(res[i], Exception) and
+                 res[i].norm_params_changed]
+        if not again:
+            break
+        # the re-runs take the fitted scale values and the un-normalised signal; const_scale /
+        # skip_seq_scaling are NOT forwarded (resquiggle.py:1499-1502)
+        sub = resquiggle_batch(
+            [map_results[i]._replace(scale_values=res[i].scale_values) for i in again], std_ref,
+            params, outlier_thresh, all_raw_signals=[map_results[i].raw_signal for i in again],
+            seq_samp_type=seq_samp_type, engine=engine)
+        for i, r in zip(again, sub):
+            res[i] = r
+            n_passes[i] += 1
+        n_iters += 1
+    return res
+
+
+def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
+                           outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
+                           seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False),
+                           max_scaling_iters=None, engine=None, return_passes=False):
+    """The per-read loop of `_resquiggle_worker` (resquiggle.py:1578-1589) over a batch.
+
+    Every read is resquiggled; while `norm_params_changed` it is re-run with the fitted
+    `scale_values` (at most `max_scaling_iters` passes, default MAX_SCALING_ITERS = 3); a read
+    that fails for any reason is started over with `save_params` (the wide "save" bandwidth,
+    `load_resquiggle_parameters(..., use_save_bandwidth=True)`).  `map_results` are what
+    `adjust_map_res` returns.  Returns per read a `resquiggleResults` or the exception of the
+    last attempt.  Reads are grouped into rounds (all first passes, then all second passes, ...),
+    so the Theil-Sen subsamples are drawn from numpy's global RNG in round-major order instead
+    of the worker's read-major order; each individual pass is the same computation as
+    `resquiggle_read` with the subsample it was handed.
+    """
+    from ._default_parameters import MAX_SCALING_ITERS
+    if max_scaling_iters is None:
+        max_scaling_iters = MAX_SCALING_ITERS
+    n = len(map_results)
+    n_passes = [0] * n
+    res = _run_iters(map_results, list(range(n)), std_ref, rsqgl_params, outlier_thresh,
+                     const_scale, skip_seq_scaling, seq_samp_type, max_scaling_iters, engine,
+                     n_passes)
+    failed = [i for i in range(n) if isinstance(res[i], Exception)]
+    if failed and save_params is not None:
+        res.update(_run_iters(map_results, failed, std_ref, save_params, outlier_thresh,
+                              const_scale, skip_seq_scaling, seq_samp_type, max_scaling_iters,
+                              engine, n_passes))
+    out = [res[i] for i in range(n)]
+    return (out, n_passes) if return_passes else out
