@@ -163,7 +163,7 @@ def main():
     out = eng.download(want_norm=False)
     if os.environ.get('TBA_DBG_PHASES'):
         d = eng.get(99)
-        print('phase cycles median', ' '.join(str(int(x)) for x in np.median(d, axis=0)), file=sys.stderr)
+        print("dbg mean", " ".join("%.1f" % x for x in d.mean(axis=0)), file=sys.stderr); print("phase cycles median", ' '.join(str(int(x)) for x in np.median(d, axis=0)), file=sys.stderr)
     n_ok = int((out['status'] == 0).sum())
     stage /= max(a.steps, 1)
 

@@ -26,7 +26,8 @@ def build(force=False):
             os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    subprocess.check_call([hipcc] + HIPCC_FLAGS + ['-o', LIB_PATH,
+    subprocess.check_call([hipcc] + HIPCC_FLAGS + os.environ.get('TBA_EXTRA_HIPCC_FLAGS', '').split() +
+                          ['-o', LIB_PATH,
                                                    os.path.join(CSRC, 'tba_engine.hip')])
     return LIB_PATH
 

@@ -118,6 +118,13 @@ __device__ __forceinline__ i64 uni(i64 x)
 template <class T> __device__ __forceinline__ T *uni(T *p) { return (T *)uni((i64)p); }
 __device__ __forceinline__ double uni(double x) { return __longlong_as_double((long long)uni((i64)__double_as_longlong(x))); }
 __device__ __forceinline__ bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
+// lane `sel` (wave-uniform) of a double, as a scalar
+__device__ __forceinline__ double readlane_f64(double x, int sel)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), sel);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), sel);
+    return __hiloint2double(hi, lo);
+}
 
 // Previous-row access without memory: every lane keeps its CPL cells of the previous row in
 // registers; the cells a row needs are that row shifted by the (wave-uniform) band offset, i.e. a
@@ -133,6 +140,34 @@ __device__ __forceinline__ void shifted_row(const double (&Q)[CPL], double left,
         else if (idx < CPL) A[k] = Q[idx];
         else A[k] = wave_shl1_f64(Q[idx - CPL], -INFINITY);
     }
+}
+// diag / skip candidates of one row for band offset D (pyx:220-231, first cell pyx:392-401):
+// A[j] is cell j's diagonal source and cell j-1's skip source.  Instantiated per offset so the
+// previous row is read straight out of its registers (no renaming moves).  tk bit j: skip taken.
+template <int CPL, int D>
+__device__ __forceinline__ void cand_row(const double (&Q)[CPL], double left,
+    const double (&z)[CPL], double skip_pen, bool first_is_skip, bool lane0, double (&cv)[CPL],
+    bool (&tk)[CPL])
+{
+    double A[CPL + 1];
+    shifted_row<CPL, D>(Q, left, A);
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        const double d = A[j] + z[j];
+        const double s = A[j + 1] - skip_pen;
+        bool take_s = s > d;
+        if (j == 0) take_s = lane0 ? first_is_skip : take_s; // band cell 0: skip xor diag
+        cv[j] = take_s ? s : d;
+        tk[j] = take_s;
+    }
+}
+// v_max_f64 without the canonicalising self-max the fmax builtin puts in front of it (both
+// operands are results of adds / maxes here, never signalling NaNs)
+__device__ __forceinline__ double max_f64_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 // Q <- Q shifted by S cells (S <= CPL); returns the cell just left of the new Q[0]
 template <int CPL, int S>
@@ -232,6 +267,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     int nvalid = Wi - b0;        // how many of my cells are inside the band
     nvalid = nvalid < 0 ? 0 : (nvalid > CPL ? CPL : nvalid);
     const double zcap = winsor ? max_half_z : INFINITY; // no winsorising: clamp at +inf
+    const int Lw = Wi / CPL, jw = Wi - Lw * CPL;       // lane / slot of the first cell past the band
 
     double v[CPL]; // my cells of the previous row (cells past the band: -inf for good)
     i64 prev_start = 0;
@@ -288,11 +324,19 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     }
     __syncthreads();
 
-    double mu_n = 0, sd_n = 1;
+    // expected level, sd and its reciprocal of 64 rows at a time: lane l holds row blk0 + l
+    // (one coalesced load and one true division per 64 rows), a row reads its lane
+    double mu_v = 0, sd_v = 1, y_v = 1;
+    auto load_levels = [&](i64 first) {
+        i64 rc = first + lane;
+        rc = rc < n_rows ? rc : n_rows - 1;
+        mu_v = rmu[rc]; sd_v = rsd[rc];
+        y_v = 1.0 / sd_v;
+    };
+    if (!use_z) load_levels(row0);
     i64 st_n = 0; int lo_n = 0, hi_n = Wi;
-    auto fetch_row = [&](i64 rr) { // per-row inputs, fetched one row ahead
+    auto fetch_row = [&](i64 rr) { // per-row band geometry of the static rows, one row ahead
         const i64 rc = rr < n_rows ? rr : n_rows - 1;
-        if (!use_z) { mu_n = rmu[rc]; sd_n = rsd[rc]; }
         if (rc < n_static) {
             if (identity) { st_n = rc; lo_n = 0; hi_n = Wi; }
             else if (DIRECT) { st_n = bst[rc]; lo_n = 0; hi_n = Wi; }
@@ -301,8 +345,16 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     };
     fetch_row(row0);
 
+#ifdef TBA_SWEEP_STATS
+    i64 sw_total = 0, sw_lanes = 0, sw_depth[4] = {0, 0, 0, 0};
+#endif
     for (i64 row = row0; row < n_rows; row++) {
-        const double mu = mu_n, sd = sd_n;
+        double mu = 0, sd = 1, y = 1;
+        if (!use_z) {
+            const int sel = (int)((row - row0) & 63);
+            if (sel == 0 && row != row0) load_levels(row);
+            mu = readlane_f64(mu_v, sel); sd = readlane_f64(sd_v, sel); y = readlane_f64(y_v, sel);
+        }
         i64 cur_start;
         int lo, hi;
         double fill;
@@ -343,7 +395,6 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 if (pf_pending) { ring_store(pf_at + lane, pf); filled = pf_at + 64; pf_pending = false; }
                 while (cur_start + 64 * CPL > filled) { ring_store(filled + lane, ev_load(filled + lane)); filled += 64; }
             }
-            const double y = 1.0 / sd;
             const double *er = ring + (int)((cur_start + RING + b0) & (RING - 1)); // + j < RING + CPL
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
@@ -356,40 +407,36 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 for (int j = 0; j < CPL; j++) z[j] = (b0 + j >= lo && b0 + j < hi) ? z[j] : fill;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // past the band: cell W gets z = -inf, which makes its value -inf (diag and stay add
+            // z, its skip source is already -inf); every cell right of it then stays -inf on its
+            // own (its sources and its left neighbour are -inf), so one select does for all
+            if (Lw < 64) {
+                const bool mine = lane == Lw;
 #pragma unroll
-            for (int j = 0; j < CPL; j++) z[j] = j < nvalid ? z[j] : NEG_INF; // past the band: stays -inf
+                for (int j = 0; j < CPL; j++)
+                    if (jw == j) z[j] = mine ? NEG_INF : z[j]; // jw is wave-uniform: one taken
+            }
         }
         // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401:
         // pp[j] is cell j's diagonal source and cell j-1's skip source
         double cv[CPL];
-        u32 cfw[(CPL + 15) / 16];
-#pragma unroll
-        for (int q = 0; q < (CPL + 15) / 16; q++) cfw[q] = 0;
+        bool tk[CPL];
         {
-            double pp[CPL + 1];
             int rem = diff_i;
             double left = NEG_INF;
             while (rem > S) { left = shift_cells<CPL, S>(v); rem -= S; } // rare: big band jump
+            const bool fs = diff_i == 0, l0 = lane == 0;
             switch (rem) {
             case 0: left = diff_i == 0 ? wave_shr1_f64(v[CPL - 1], NEG_INF) : left;
-                    shifted_row<CPL, 0>(v, left, pp); break;
-            case 1: shifted_row<CPL, 1>(v, left, pp); break;
-            case 2: if constexpr (S >= 2) shifted_row<CPL, 2>(v, left, pp); break;
-            case 3: if constexpr (S >= 3) shifted_row<CPL, 3>(v, left, pp); break;
-            case 4: if constexpr (S >= 4) shifted_row<CPL, 4>(v, left, pp); break;
-            case 5: if constexpr (S >= 5) shifted_row<CPL, 5>(v, left, pp); break;
-            case 6: if constexpr (S >= 6) shifted_row<CPL, 6>(v, left, pp); break;
-            case 7: if constexpr (S >= 7) shifted_row<CPL, 7>(v, left, pp); break;
-            default: if constexpr (S >= 8) shifted_row<CPL, 8>(v, left, pp); break;
-            }
-#pragma unroll
-            for (int j = 0; j < CPL; j++) {
-                const double d = pp[j] + z[j];
-                const double s = pp[j + 1] - skip_pen;
-                bool take_s = s > d;
-                if (j == 0) take_s = lane == 0 ? diff_i == 0 : take_s; // band cell 0: skip xor diag
-                cv[j] = take_s ? s : d;
-                cfw[j / 16] |= (take_s ? 1u : 2u) << (2 * (j % 16));
+                    cand_row<CPL, 0>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            case 1: cand_row<CPL, 1>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            case 2: if constexpr (S >= 2) cand_row<CPL, 2>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            case 3: if constexpr (S >= 3) cand_row<CPL, 3>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            case 4: if constexpr (S >= 4) cand_row<CPL, 4>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            case 5: if constexpr (S >= 5) cand_row<CPL, 5>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            case 6: if constexpr (S >= 6) cand_row<CPL, 6>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            case 7: if constexpr (S >= 7) cand_row<CPL, 7>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+            default: if constexpr (S >= 8) cand_row<CPL, 8>(v, left, z, skip_pen, fs, l0, cv, tk); break;
             }
         }
         // stay chain: monotone fixed-point sweeps, chunk exit values shifted one lane up
@@ -397,11 +444,23 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         bool converged = false;
         for (int it = 0; it < 66; it++) { // <= 64 sweeps by induction over lanes (NaN-proof bound)
             double x = in;
+#ifdef TBA_SWEEP_STATS
+            int depth = 0;
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
                 x = __builtin_fmax(cv[j], (x - stay_pen) + z[j]);
+                if (it > 0 && x != v[j]) depth = j + 1;
                 v[j] = x;
             }
+            if (it > 0) { int dm = depth; for (int o = 32; o >= 1; o >>= 1) { int t = __shfl_xor(dm, o, 64); dm = t > dm ? t : dm; } sw_depth[it < 4 ? it : 3] += dm; sw_lanes += __popcll(__ballot(depth > 0)); }
+            sw_total++;
+#else
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                x = max_f64_raw(cv[j], (x - stay_pen) + z[j]);
+                v[j] = x;
+            }
+#endif
             const double nin = wave_shr1_f64(x, NEG_INF);
             if (__ballot(nin != in) == 0) { converged = true; break; }
             in = nin;
@@ -421,7 +480,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
                 const double s = (x - stay_pen) + z[j];
-                const u32 f = cv[j] > s ? ((cfw[j / 16] >> (2 * (j % 16))) & 3u) : 0u;
+                const u32 f = cv[j] > s ? (tk[j] ? 1u : 2u) : 0u;
                 mvw[j / 16] |= f << (2 * (j % 16));
                 x = v[j];
                 lmax = __builtin_fmax(lmax, x);
@@ -460,6 +519,12 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         am = uni(__shfl(b0 + lidx, __ffsll((unsigned long long)eq) - 1, 64));
         prev_start = cur_start;
     }
+#ifdef TBA_SWEEP_STATS
+    if (!DIRECT && mode == DP_MAIN && lane == 0) {
+        r.dbg[0] = n_rows - row0; r.dbg[1] = sw_total; r.dbg[2] = sw_lanes;
+        r.dbg[3] = sw_depth[1]; r.dbg[4] = sw_depth[2]; r.dbg[5] = sw_depth[3];
+    }
+#endif
     // last row + traceback start (np.argmax of the last row, resquiggle.py:728,1032)
     if constexpr (DIRECT) {
         if (lane == 0) job->top_pos = am;

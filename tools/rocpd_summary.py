@@ -18,8 +18,8 @@ def main(path):
         print('%-64s %6d %14.1f %14.1f %7.2f' % (short[:64], calls, tot, avg, pct))
     try:
         rows = list(c.execute(
-            'select name, counter_name, sum(value), count(*) from counters_collection '
-            'group by name, counter_name order by sum(value) desc'))
+            'select kernel_name, counter_name, sum(value), count(*) from counters_collection '
+            'group by kernel_name, counter_name order by sum(value) desc'))
         if rows:
             print('\n%-64s %-14s %18s %8s' % ('kernel', 'counter', 'sum', 'samples'))
             for name, cn, v, k in rows:
