@@ -267,7 +267,10 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     int nvalid = Wi - b0;        // how many of my cells are inside the band
     nvalid = nvalid < 0 ? 0 : (nvalid > CPL ? CPL : nvalid);
     const double zcap = winsor ? max_half_z : INFINITY; // no winsorising: clamp at +inf
-    const int Lw = Wi / CPL, jw = Wi - Lw * CPL;       // lane / slot of the first cell past the band
+    double zs[CPL]; // z_shift per cell, -inf for the cells past the band (folds the band-end mask
+                    // into the subtraction that forms z)
+#pragma unroll
+    for (int j = 0; j < CPL; j++) zs[j] = j < nvalid ? z_shift : NEG_INF;
 
     double v[CPL]; // my cells of the previous row (cells past the band: -inf for good)
     i64 prev_start = 0;
@@ -400,21 +403,15 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             for (int j = 0; j < CPL; j++) {
                 double pz = fabs(div_by_recip(er[j] - mu, sd, y));
                 pz = __builtin_fmin(pz, zcap);
-                z[j] = z_shift - pz;
+                z[j] = zs[j] - pz; // cells past the band: -inf - pz = -inf, stays -inf for good
             }
             if (__builtin_expect(lo != 0 || hi != Wi, 0)) { // masked start rows / band past the last event
 #pragma unroll
-                for (int j = 0; j < CPL; j++) z[j] = (b0 + j >= lo && b0 + j < hi) ? z[j] : fill;
+                for (int j = 0; j < CPL; j++) {
+                    z[j] = (b0 + j >= lo && b0 + j < hi) ? z[j] : fill;
+                    z[j] = j < nvalid ? z[j] : NEG_INF;
+                }
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            // past the band: cell W gets z = -inf, which makes its value -inf (diag and stay add
-            // z, its skip source is already -inf); every cell right of it then stays -inf on its
-            // own (its sources and its left neighbour are -inf), so one select does for all
-            if (Lw < 64) {
-                const bool mine = lane == Lw;
-#pragma unroll
-                for (int j = 0; j < CPL; j++)
-                    if (jw == j) z[j] = mine ? NEG_INF : z[j]; // jw is wave-uniform: one taken
             }
         }
         // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401:
