@@ -169,90 +169,129 @@ __device__ __forceinline__ bool prio_before(double sp, i64 p, double sq, i64 q)
     return sp > sq || (sp == sq && p > q);
 }
 
-// The greedy inside LDS tiles, one tile per WAVEFRONT at a time (no workgroup barriers: the
-// waves of a workgroup walk different tiles).  Exclusion radius R = min_base_obs - 1 is a
-// compile-time constant.  Every lane owns PKW_SLOTS strided tile slots; which neighbours
-// outrank a slot is fixed, so it is computed once per tile into a bit mask; a round then only
-// reads the 2R neighbour states (issued together, no branches) and updates the slot.  Decisions
-// are only ever taken from decided neighbours, so whatever is decided here is final; slots whose
-// dependency chain leaves the tile stay 0 and are finished by the global rounds of k_peaks.
+// The greedy, bit-sliced: one tile per WAVEFRONT at a time (no workgroup barriers), 64 lanes x
+// 64 consecutive positions; lane l holds, as 64-bit words (bit i <-> position base + 64 l + i):
+//   V        position inside the signal
+//   G[d]     the neighbour at +d (d = 1..R) outranks this position (ties fall to the higher
+//            index, so that is score[p + d] >= score[p]); "this position outranks the one at
+//            -d" is the complement over valid pairs, shifted up by d
+//   T, S     taken / suppressed so far
+// The masks come from one compare + ballot per 64 positions and offset, moved into their lane
+// with v_writelane.  A round is then ~20 bit operations per offset for 4096 positions:
+// taken-by-a-higher-neighbour suppresses, no-undecided-higher-neighbour takes; the neighbour
+// words cross lanes through DPP.  Decisions are only ever taken from decided neighbours, so
+// whatever is decided here is final; the first and last lane of a tile are halo (their outside
+// neighbours count as undecided), positions whose dependency chain leaves the tile or outlasts
+// the round bound stay 0 and are finished by the global rounds of k_peaks.
 // Returns this lane's count of core positions left undecided.
-#define PKW_CORE 448
-#define PKW_HALO 32
-#define PKW_SPAN (PKW_CORE + 2 * PKW_HALO)   // 512 slots = 8 per lane
-#define PKW_SLOTS (PKW_SPAN / 64)
-template <int R>
-__device__ i64 peaks_tiles(const double *s, unsigned char *st, i64 ns, double *ts_all,
-                           unsigned char *tst_all)
+#define PKB_SPAN 4096
+#define PKB_CORE (PKB_SPAN - 128)
+#define PKB_MAX_ROUNDS 96
+struct W64 { u32 lo, hi; };
+__device__ __forceinline__ W64 w_and(W64 a, W64 b) { return {a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ W64 w_or(W64 a, W64 b) { return {a.lo | b.lo, a.hi | b.hi}; }
+__device__ __forceinline__ W64 w_andn(W64 a, W64 b) { return {a.lo & ~b.lo, a.hi & ~b.hi}; }
+// bit i <- bit i + d of the 128-bit (next:cur);  bit i <- bit i - d of (cur:prev);  0 < d < 32
+__device__ __forceinline__ W64 w_down(W64 cur, W64 next, int d)
 {
+    return {__builtin_amdgcn_alignbit(cur.hi, cur.lo, d), __builtin_amdgcn_alignbit(next.lo, cur.hi, d)};
+}
+__device__ __forceinline__ W64 w_up(W64 cur, W64 prev, int d)
+{
+    return {__builtin_amdgcn_alignbit(cur.lo, prev.hi, 32 - d), __builtin_amdgcn_alignbit(cur.hi, cur.lo, 32 - d)};
+}
+__device__ __forceinline__ W64 w_from_lane_below(W64 x, W64 lane0) // lane l <- lane l-1
+{
+    return {(u32)__builtin_amdgcn_update_dpp((int)lane0.lo, (int)x.lo, 0x138, 0xf, 0xf, false),
+            (u32)__builtin_amdgcn_update_dpp((int)lane0.hi, (int)x.hi, 0x138, 0xf, 0xf, false)};
+}
+__device__ __forceinline__ W64 w_from_lane_above(W64 x, W64 lane63) // lane l <- lane l+1
+{
+    return {(u32)__builtin_amdgcn_update_dpp((int)lane63.lo, (int)x.lo, 0x130, 0xf, 0xf, false),
+            (u32)__builtin_amdgcn_update_dpp((int)lane63.hi, (int)x.hi, 0x130, 0xf, 0xf, false)};
+}
+__device__ __forceinline__ W64 w_ballot_to_lane(W64 old, u64 m, int g) // word of lane g <- m
+{
+    u32 lo = old.lo, hi = old.hi;
+    const u32 mlo = (u32)m, mhi = (u32)(m >> 32);
+    // one SGPR operand per VALU instruction on gfx9: the lane select goes through m0
+    asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+        : "+v"(lo), "+v"(hi) : "s"(mlo), "s"(g), "s"(mhi) : "m0");
+    return {lo, hi};
+}
+template <int R>
+__device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns)
+{
+    static_assert(R >= 1 && R < 32, "exclusion radius");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *ts = ts_all + wave * PKW_SPAN;
-    unsigned char *tst = tst_all + wave * PKW_SPAN;
     i64 left = 0;
-    const i64 n_tiles = (ns + PKW_CORE - 1) / PKW_CORE;
+    const i64 n_tiles = (ns + PKB_CORE - 1) / PKB_CORE;
+    const W64 zero = {0u, 0u}, ones = {~0u, ~0u};
     for (i64 tile = wave; tile < n_tiles; tile += SEL_NT / 64) {
-        const i64 t0 = tile * PKW_CORE;
-        const i64 g0 = t0 - PKW_HALO; // global index of tile slot 0
+        const i64 g0 = tile * PKB_CORE - 64; // position of bit 0 of lane 0
+        W64 V = zero, G[R + 1];
 #pragma unroll
-        for (int i = 0; i < PKW_SLOTS; i++) {
-            const int k = lane + 64 * i;
-            const i64 p = g0 + k;
-            const bool in = p >= 0 && p < ns;
-            const double v = s[p < 0 ? 0 : (p >= ns ? ns - 1 : p)];
-            ts[k] = in ? v : -1.0;   // scores are >= 0
-            tst[k] = in ? 0 : 2;     // slots outside the signal constrain nobody
-        }
-        __builtin_amdgcn_wave_barrier();
-        u32 himask[PKW_SLOTS]; // bit d: neighbour at offset d - R (d != R) outranks me
-        unsigned char mine[PKW_SLOTS];
+        for (int d = 1; d <= R; d++) G[d] = zero;
+        // masks: group g = positions g0 + 64 g + lane
+#pragma unroll 4
+        for (int g = 0; g < 64; g++) {
+            const i64 p = g0 + 64 * g + lane;
+            const bool vp = p >= 0 && p < ns;
+            const i64 pc = p < 0 ? 0 : (p >= ns ? ns - 1 : p);
+            const double sp = s[pc];
+            V = w_ballot_to_lane(V, __ballot(vp), g);
 #pragma unroll
-        for (int i = 0; i < PKW_SLOTS; i++) {
-            const int k = lane + 64 * i;
-            const double sk = ts[k];
-            // the outermost R slots of a tile that have neighbours outside the loaded span
-            const bool edge = (k < R && g0 > 0) || (k >= PKW_SPAN - R && g0 + PKW_SPAN < ns);
-            u32 hm = 0;
-#pragma unroll
-            for (int d = 0; d <= 2 * R; d++) {
-                if (d == R) continue;
-                const int q = k + d - R;
-                const int qc = q < 0 ? 0 : (q >= PKW_SPAN ? PKW_SPAN - 1 : q);
-                const double sq = ts[qc];
-                const bool inb = q >= 0 && q < PKW_SPAN;
-                hm |= (inb && prio_before(sq, g0 + q, sk, g0 + k)) ? (1u << d) : 0u;
+            for (int d = 1; d <= R; d++) {
+                const i64 q = p + d;
+                const i64 qc = q < 0 ? 0 : (q >= ns ? ns - 1 : q);
+                const double sq = s[qc];
+                G[d] = w_ballot_to_lane(G[d], __ballot(vp && q >= 0 && q < ns && sq >= sp), g);
             }
-            himask[i] = hm;
-            mine[i] = edge ? 3 : tst[k]; // 3: cannot be decided in this tile
         }
-        for (int round = 0; round < PKW_SPAN; round++) {
-            int progress = 0;
-            __builtin_amdgcn_wave_barrier();
+        // validity of the words just outside the tile
+        const i64 after = ns - (g0 + PKB_SPAN); // positions of the signal past the tile
+        const W64 v_after = after >= 64 ? ones : (after <= 0 ? zero :
+            (after >= 32 ? W64{~0u, (1u << (after - 32)) - 1u} : W64{(1u << after) - 1u, 0u}));
+        const W64 v_before = g0 > 0 ? ones : zero;
+        const W64 Vn = w_from_lane_above(V, v_after), Vp = w_from_lane_below(V, v_before);
+        (void)Vp;
+        // Hp[d]: neighbour +d outranks me (= G[d]);  Hm[d]: neighbour -d outranks me
+        W64 Hm[R + 1];
 #pragma unroll
-            for (int i = 0; i < PKW_SLOTS; i++) {
-                const int k = lane + 64 * i;
-                bool any_taken = false, any_undec = false;
+        for (int d = 1; d <= R; d++) {
+            const W64 pv = w_and(V, w_down(V, Vn, d));            // both ends of the pair valid
+            const W64 x = w_andn(pv, G[d]);                        // pair (p, p+d): p outranks p+d
+            // below the tile nothing is known: the missing neighbours count as outranking
+            const W64 x_prev = w_from_lane_below(x, v_before);
+            Hm[d] = w_and(V, w_up(x, x_prev, d));
+        }
+        W64 T = zero, S = zero, U = V;
+        const W64 u_before = v_before, u_after = v_after;        // outside: undecided where valid
+        for (int round = 0; round < PKB_MAX_ROUNDS; round++) {
+            const W64 Tn = w_from_lane_above(T, zero), Tp = w_from_lane_below(T, zero);
+            const W64 Un = w_from_lane_above(U, u_after), Up = w_from_lane_below(U, u_before);
+            W64 at = zero, au = zero;
 #pragma unroll
-                for (int d = 0; d <= 2 * R; d++) {
-                    if (d == R) continue;
-                    const int q = k + d - R;
-                    const unsigned char sq = tst[q < 0 ? 0 : (q >= PKW_SPAN ? PKW_SPAN - 1 : q)];
-                    const bool hi = (himask[i] >> d) & 1u;
-                    any_taken |= hi && sq == 1;
-                    any_undec |= hi && sq == 0;
-                }
-                const unsigned char nv = any_taken ? 2 : (!any_undec ? 1 : 0);
-                if (mine[i] == 0 && nv != 0) { tst[k] = nv; mine[i] = nv; progress = 1; }
+            for (int d = 1; d <= R; d++) {
+                at = w_or(at, w_or(w_and(G[d], w_down(T, Tn, d)), w_and(Hm[d], w_up(T, Tp, d))));
+                au = w_or(au, w_or(w_and(G[d], w_down(U, Un, d)), w_and(Hm[d], w_up(U, Up, d))));
             }
-            if (__ballot(progress) == 0) break;
+            const W64 nS = w_and(U, at);
+            const W64 nT = w_andn(w_andn(U, at), au);
+            T = w_or(T, nT); S = w_or(S, nS);
+            U = w_andn(w_andn(U, nT), nS);
+            if (__ballot((nS.lo | nS.hi | nT.lo | nT.hi) != 0) == 0) break;
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < PKW_CORE / 64; i++) {
-            const int k = lane + 64 * i;
-            const i64 p = t0 + k;
-            if (p < ns) { const unsigned char v0 = tst[k + PKW_HALO]; st[p] = v0; left += v0 == 0; }
+        // core lanes 1..62 -> one state byte per position
+        for (int g = 1; g < 63; g++) {
+            const u32 tl = __builtin_amdgcn_readlane((int)T.lo, g), th = __builtin_amdgcn_readlane((int)T.hi, g);
+            const u32 sl = __builtin_amdgcn_readlane((int)S.lo, g), sh = __builtin_amdgcn_readlane((int)S.hi, g);
+            const i64 p = g0 + 64 * g + lane;
+            const u32 tb = lane < 32 ? (tl >> lane) & 1u : (th >> (lane - 32)) & 1u;
+            const u32 sb = lane < 32 ? (sl >> lane) & 1u : (sh >> (lane - 32)) & 1u;
+            if (p < ns) st[p] = (unsigned char)(tb | (sb << 1));
         }
-        __builtin_amdgcn_wave_barrier();
+        if (lane >= 1 && lane < 63) left += __popc(U.lo) + __popc(U.hi);
     }
     return left;
 }
@@ -263,7 +302,6 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     __shared__ BucketSmem sm;
     __shared__ i64 s_w[SEL_NT / 64];
     __shared__ i64 s_idx_thr;
-    __shared__ unsigned char s_tst[(SEL_NT / 64) * PKW_SPAN];
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
     const int tid = threadIdx.x;
@@ -283,12 +321,9 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     // and are finished by the global rounds below (rare: chains are a few positions long).
     TBA_PHASE_T0();
     {
-        static_assert((SEL_NT / 64) * PKW_SPAN <= BS_NB / 2 + BS_CAP, "tiles do not fit");
-        double *ts = sm.raw8;                       // one PKW_SPAN score tile per wave
-        unsigned char *tst = s_tst;                 // and its states
         i64 left_undecided = 0;
-        if (m - 1 == 2) { left_undecided = peaks_tiles<2>(s, st, ns, ts, tst); __syncthreads(); }
-        else if (m - 1 == 5) { left_undecided = peaks_tiles<5>(s, st, ns, ts, tst); __syncthreads(); }
+        if (m - 1 == 2) { left_undecided = peaks_bits<2>(s, st, ns); __syncthreads(); }
+        else if (m - 1 == 5) { left_undecided = peaks_bits<5>(s, st, ns); __syncthreads(); }
         else { // unusual min_obs_per_base: everything goes through the global rounds
             for (i64 p = tid; p < ns; p += SEL_NT) st[p] = 0;
             left_undecided = 1;
