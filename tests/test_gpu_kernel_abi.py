@@ -58,6 +58,39 @@ def test_change_point_kernels(read):
     assert rc == 2
 
 
+def test_change_points_with_exact_score_ties_and_tile_edges():
+    """quantised (integer) signal: many exactly equal scores, also at the threshold score ->
+    priority falls to the higher index (DESIGN.md tie rule) like the oracle's ordering; lengths
+    around the 3968-position tiles of the bit-sliced greedy; both exclusion radii"""
+    import oracle
+    from tombo_amd import _c_helper as ch
+    rng = np.random.default_rng(17)
+    for n in (64, 700, 3968 + 10, 3968 + 74, 2 * 3968 + 9, 4096, 8192, 20011):
+        sig = rng.integers(-3, 4, size=n).astype(np.float64)
+        for frac in (0.02, 0.1, 0.19):
+            k = max(2, int(n * frac))
+            rc, want = oracle.valid_cpts(sig, 3, 5, k)
+            if rc == 0:
+                np.testing.assert_array_equal(ch.c_valid_cpts_w_cap(sig, 3, 5, k), want,
+                                              err_msg='n=%d k=%d' % (n, k))
+            else:
+                with pytest.raises(NotImplementedError, match='Fewer changepoints'):
+                    ch.c_valid_cpts_w_cap(sig, 3, 5, k)
+        if n >= 700:
+            k = max(2, n // 40)
+            rc, want = oracle.valid_cpts(sig, 6, 12, k, ttest=True)
+            if rc == 0:
+                np.testing.assert_array_equal(ch.c_valid_cpts_w_cap_t_test(sig, 6, 12, k), want,
+                                              err_msg='ttest n=%d k=%d' % (n, k))
+    # continuous input around the tile edges
+    for n in (3968 + 64 + 10 + 1, 3 * 3968 + 11):
+        sig = rng.normal(0, 1, n)
+        k = n // 6
+        rc, want = oracle.valid_cpts(sig, 3, 5, k)
+        assert rc == 0
+        np.testing.assert_array_equal(ch.c_valid_cpts_w_cap(sig, 3, 5, k), want)
+
+
 def test_forward_pass_and_traceback_kernels(read):
     import oracle
     from tombo_amd import _c_dynamic_programming as cdp

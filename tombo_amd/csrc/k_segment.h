@@ -380,55 +380,50 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
                                   mx, &sm);
     __syncthreads();
     TBA_PHASE(3);
-    // one pass: taken above / at the threshold, all positions above / at it, lowest taken index
-    // at the threshold
-    i64 c_gt = 0, c_eq = 0, a_gt = 0, a_eq = 0, min_eq = ns;
-    for (i64 p = tid; p < ns; p += SEL_NT) {
-        const double v = s[p];
-        const bool tk = st[p] == 1;
-        a_gt += v > tval; a_eq += v == tval;
-        c_gt += tk && v > tval;
-        if (tk && v == tval) { c_eq++; min_eq = p < min_eq ? p : min_eq; }
-    }
+    // one pass: ordered compaction of the picks (the .sort() of tombo_helper.py:76-82), taking
+    // every taken position at or above the threshold score, and on the way the counts that tell
+    // whether that was right: taken above / at the threshold, all positions above / at it
+    i64 c_gt = 0, c_eq = 0, a_gt = 0, a_eq = 0;
+    block_compact(
+        ns,
+        [&](i64 p) {
+            const double v = s[p];
+            const bool tk = st[p] == 1;
+            a_gt += v > tval; a_eq += v == tval;
+            c_gt += tk && v > tval; c_eq += tk && v == tval;
+            return tk && v >= tval;
+        },
+        [&](i64 p, i64 o) { if (o < num_cpts) cpts[o] = p + w; }, s_w);
     c_gt = block_sum_i64(c_gt, &sm.rad);
     c_eq = block_sum_i64(c_eq, &sm.rad);
     a_gt = block_sum_i64(a_gt, &sm.rad);
     a_eq = block_sum_i64(a_eq, &sm.rad);
-    for (int mm = 32; mm >= 1; mm >>= 1) { i64 t = shfl_i64(min_eq, (tid & 63) ^ mm); min_eq = t < min_eq ? t : min_eq; }
-    if ((tid & 63) == 0) s_w[tid >> 6] = min_eq;
-    __syncthreads();
-    min_eq = s_w[0];
-    for (int q = 1; q < SEL_NT / 64; q++) min_eq = s_w[q] < min_eq ? s_w[q] : min_eq;
-    __syncthreads();
     const i64 need_eq = num_cpts - c_gt;
-    i64 idx_thr = min_eq; // take every taken position at the threshold score
     i64 before = a_gt;    // rank of the last pick in the argsort order
     if (need_eq < c_eq || a_eq > 1) {
         // exact ties on the threshold score (never with continuous input): priority falls to
-        // the higher index; resolve sequentially, then recount
-        if (need_eq < c_eq) {
-            if (tid == 0) {
-                i64 thr = 0, left = need_eq;
-                for (i64 p = ns - 1; p >= 0; p--)
-                    if (st[p] == 1 && s[p] == tval) { if (--left == 0) { thr = p; break; } }
-                s_idx_thr = thr;
-            }
-            __syncthreads();
-            idx_thr = s_idx_thr;
+        // the higher index; resolve sequentially, recount, and redo the compaction
+        if (tid == 0) {
+            i64 thr = 0, left = need_eq;
+            for (i64 p = ns - 1; p >= 0; p--)
+                if (st[p] == 1 && s[p] == tval) { thr = p; if (--left == 0) break; }
+            s_idx_thr = thr;
         }
+        __syncthreads();
+        const i64 idx_thr = s_idx_thr; // lowest-index pick at the threshold score
         i64 extra = 0;
         for (i64 p = tid; p < ns; p += SEL_NT) extra += s[p] == tval && p > idx_thr;
         before = a_gt + block_sum_i64(extra, &sm.rad);
+        if (need_eq < c_eq)
+            block_compact(
+                ns,
+                [&](i64 p) { if (st[p] != 1) return false; const double v = s[p]; return v > tval || (v == tval && p >= idx_thr); },
+                [&](i64 p, i64 o) { if (o < num_cpts) cpts[o] = p + w; }, s_w);
     }
     // the reference raises when rank + 1 >= num_cands (cand_idx is advanced past the pick before
     // the bound check, _c_helper.pyx:116-118)
     if (num_cpts > 1 && before + 1 >= num_cands) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
     TBA_PHASE(4);
-    // ordered compaction of the picks (the .sort() of tombo_helper.py:76-82)
-    block_compact(
-        ns,
-        [&](i64 p) { if (st[p] != 1) return false; const double v = s[p]; return v > tval || (v == tval && p >= idx_thr); },
-        [&](i64 p, i64 o) { cpts[o] = p + w; }, s_w);
     TBA_PHASE(5);
     if (tid == 0) { r.n_cpts = num_cpts; r.n_ev = num_cpts - 1; }
 }
