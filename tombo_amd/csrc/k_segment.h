@@ -30,21 +30,26 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         use_sv = true; // get_scale_values_from_events result, tombo_stats.py:217-233
         shift = r.shift; scale = r.scale; have_lims = true; lo = r.lower; hi = r.upper;
     } else {
-        // range of the raw signal (one pass), then bucket-select medians (k_select.h)
-        mn = INFINITY; mx = -INFINITY;
-        for (i64 i = tid; i < n; i += SEL_NT) { double v = x[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        // Bucket-select medians (k_select.h).  Their first bucket range is only a guess -- the
+        // select clamps outside values into the end buckets and refines -- so it comes from 512
+        // samples instead of a min / max pass over the signal.
+        double smn = INFINITY, smx = -INFINITY;
+        { const double v = x[(n * (i64)tid) / SEL_NT]; smn = v; smx = v; }
         for (int mm = 32; mm >= 1; mm >>= 1) {
-            double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
-            mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
+            double a = shfl_xor_f64(smn, mm), b2 = shfl_xor_f64(smx, mm);
+            smn = a < smn ? a : smn; smx = b2 > smx ? b2 : smx;
         }
-        if ((tid & 63) == 0) { sm.redd[2 * (tid >> 6)] = mn; sm.redd[2 * (tid >> 6) + 1] = mx; }
+        if ((tid & 63) == 0) { sm.redd[2 * (tid >> 6)] = smn; sm.redd[2 * (tid >> 6) + 1] = smx; }
         __syncthreads();
-        mn = sm.redd[0]; mx = sm.redd[1];
+        smn = sm.redd[0]; smx = sm.redd[1];
         for (int w = 1; w < SEL_NT / 64; w++) {
-            mn = sm.redd[2 * w] < mn ? sm.redd[2 * w] : mn;
-            mx = sm.redd[2 * w + 1] > mx ? sm.redd[2 * w + 1] : mx;
+            smn = sm.redd[2 * w] < smn ? sm.redd[2 * w] : smn;
+            smx = sm.redd[2 * w + 1] > smx ? sm.redd[2 * w + 1] : smx;
         }
         __syncthreads();
+        double span = smx - smn;
+        span = span > 0 ? span : 1.0;
+        mn = smn - span; mx = smx + span;
         shift = block_median_fast([&](i64 i) { return x[i]; }, n, mn, mx, &sm, &xlo, &xhi);
         if (o.has_const_scale) scale = o.const_scale;
         else {
@@ -53,8 +58,8 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
                                       a > b2 ? a : b2, &sm);
         }
     }
-    for (i64 i = tid; i < n; i += SEL_NT) y[i] = (x[i] - shift) / scale;
-    __syncthreads();
+    // The normalised signal is written once, at the end: the passes in between recompute
+    // (x - shift) / scale on the fly (same operation, same bits).
     // RNA with scale_values=None and no event scaling normalises without an outlier threshold
     bool thresh = !use_sv && o.has_outlier_thresh && !(mode == 1 && !o.has_const_scale);
     if (thresh) {
@@ -64,8 +69,8 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         const double ylo = (xlo - shift) / scale, yhi = (xhi - shift) / scale;
         const double med = (n & 1) ? ylo : (ylo + yhi) / 2.0;
         const double e0 = fabs((mn - shift) / scale - med), e1 = fabs((mx - shift) / scale - med);
-        const double mad = block_median_fast([&](i64 i) { return fabs(y[i] - med); }, n, 0.0,
-                                             e0 > e1 ? e0 : e1, &sm);
+        const double mad = block_median_fast(
+            [&](i64 i) { return fabs((x[i] - shift) / scale - med); }, n, 0.0, e0 > e1 ? e0 : e1, &sm);
         lo = med - (mad * o.outlier_thresh);
         hi = med + (mad * o.outlier_thresh);
         have_lims = true;
@@ -73,9 +78,11 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
     if (have_lims) {
         // c_apply_outlier_thresh, _c_helper.pyx:73-87
         for (i64 i = tid; i < n; i += SEL_NT) {
-            double v = y[i];
+            const double v = (x[i] - shift) / scale;
             y[i] = v > hi ? hi : (v < lo ? lo : v);
         }
+    } else {
+        for (i64 i = tid; i < n; i += SEL_NT) y[i] = (x[i] - shift) / scale;
     }
     if (tid == 0) {
         r.shift = shift; r.scale = scale; r.lower = lo; r.upper = hi;
