@@ -230,8 +230,8 @@ __device__ double block_kth_fe(FE fe, i64 n, i64 k, double lo, double hi, Bucket
         __syncthreads();
         const int nlev = sm->nlev;
         fe([&](double v, bool ok) {
-            const bool part = ok && bs_member(sm, nlev, v);
-            hist_add(sm->hist, part, (u32)bs_bucket(v, lo, scale));
+            // 4096 fine buckets: lanes rarely share one, plain LDS atomics beat leader aggregation
+            if (ok && bs_member(sm, nlev, v)) atomicAdd(&sm->hist[bs_bucket(v, lo, scale)], 1u);
         });
         __syncthreads();
         if (tid < 64) { // wave 0: locate the bucket of rank k (BS_NB/64 bins per lane)
