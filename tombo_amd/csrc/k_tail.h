@@ -359,18 +359,30 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     // (i, i + n/2) for i < n/2 when n is even; slope(i,j) == slope(j,i) bitwise.  The loops have
     // workgroup-uniform trip counts (the visitor ballots).
     auto slopes = [&](auto visit) {
-        const int nn = (int)n, dmax = (nn - 1) / 2;
-        for (int d = 1; d <= dmax + ((nn & 1) ? 0 : 1); d++) {
-            const int lim = d <= dmax ? nn : nn / 2; // the antipodal distance covers half
-            for (int i0 = 0; i0 < lim; i0 += SEL_NT) {
-                const int i = i0 + tid;
-                const bool ok = i < lim;
-                const int ic = ok ? i : 0;
-                int j = ic + d;
-                j = j >= nn ? j - nn : j;
-                const double ei = s_ev[ic], ej = s_ev[j];
-                const double sl = (ei == ej) ? 1000.0 : (s_md[ic] - s_md[j]) / (ei - ej);
-                visit(sl, ok);
+        // a thread keeps point i and walks the distances four at a time (their LDS loads go out
+        // together); dtop = dmax, plus the antipodal distance n/2 for even n (first half of the
+        // points only)
+        const int nn = (int)n, dmax = (nn - 1) / 2, dtop = dmax + ((nn & 1) ? 0 : 1);
+        for (int i0 = 0; i0 < nn; i0 += SEL_NT) {
+            const int i = i0 + tid;
+            const bool okr = i < nn;
+            const int ic = okr ? i : 0;
+            const double ei = s_ev[ic], mi = s_md[ic];
+            const int dlim = okr ? ((nn & 1) || i >= nn / 2 ? dmax : dtop) : 0; // my last distance
+            for (int d0 = 1; d0 <= dtop; d0 += 4) {
+                double ej[4], mj[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int j = ic + d0 + u;
+                    j = j >= nn ? j - nn : j;
+                    j = j >= nn ? 0 : j; // d0 + u past dtop (never used)
+                    ej[u] = s_ev[j]; mj[u] = s_md[j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double sl = (ei == ej[u]) ? 1000.0 : (mi - mj[u]) / (ei - ej[u]);
+                    visit(sl, d0 + u <= dlim);
+                }
             }
         }
     };
