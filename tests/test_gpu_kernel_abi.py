@@ -82,6 +82,14 @@ def test_change_points_with_exact_score_ties_and_tile_edges():
             if rc == 0:
                 np.testing.assert_array_equal(ch.c_valid_cpts_w_cap_t_test(sig, 6, 12, k), want,
                                               err_msg='ttest n=%d k=%d' % (n, k))
+    # window widths on both sides of the fused cumsum + score kernel's limit (2w <= 64), and
+    # lengths around its 64-sample chunks
+    for n, w in ((20011, 32), (20011, 33), (5000, 1), (64 * 7 + 1, 5), (64 * 7, 5), (64 * 7 - 1, 7)):
+        sig = rng.normal(0, 1, n)
+        k = max(2, n // 100)
+        rc, want = oracle.valid_cpts(sig, 3, w, k)
+        assert rc == 0
+        np.testing.assert_array_equal(ch.c_valid_cpts_w_cap(sig, 3, w, k), want, err_msg='w=%d' % w)
     # continuous input around the tile edges
     for n in (3968 + 64 + 10 + 1, 3 * 3968 + 11):
         sig = rng.normal(0, 1, n)

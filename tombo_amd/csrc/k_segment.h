@@ -136,6 +136,127 @@ __global__ __launch_bounds__(256) void k_scores_dna(const ReadState *rs, const D
         s[k] = fabs(((2 * c[k + w]) - c[k]) - c[k + 2 * w]);
 }
 
+// k_cumsum + k_scores_dna in one pass (2 * running_stat_width <= 64): the cumulative sum never
+// goes to memory.  Its left-to-right accumulation needs one LANE per read, and a lane per read
+// would touch 64 different cache lines per global access, so the signal is transposed through
+// LDS and the parts of a step are pipelined: a workgroup (4 waves) owns CS_READS reads and three
+// CS_READS x CS_CHUNK tiles (rows padded by one to spread the banks); in step i waves 1..3 (a)
+// drop the samples they fetched during step i-1 into tile (i+1) % 3, (b) fetch chunk i+2 into
+// registers, (c) turn tile (i-1) % 3 -- scanned during step i-1 -- into scores (the 2w sums
+// before the tile come from a per-row halo) and write them out, all as coalesced half rows,
+// while wave 0 walks tile i % 3 column-wise (lane = read).  One barrier per step; a step costs
+// about one memory round trip, 32 reads x 128 samples per workgroup keep enough of them in
+// flight (measured against 64 x 64 tiles, an LDS-only barrier and separate load / store waves:
+// all slower).
+#define CS_READS 32
+#define CS_CHUNK 128
+#define CS_STRIDE (CS_CHUNK + 1)
+#define CS_UNITS 22 // half rows per loader wave: 3 x 22 >= 2 x CS_READS, even so halves pair up
+__global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 n_reads,
+    const DevParams *dp, const double *__restrict__ norm, double *__restrict__ score)
+{
+    __shared__ double tile[3][CS_READS * CS_STRIDE];
+    __shared__ double halo[CS_READS * 64]; // row q: the 2w sums before the tile being stored
+    __shared__ i64 s_off[CS_READS], s_n[CS_READS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 r0 = (i64)blockIdx.x * CS_READS;
+    const int w = (int)dp->p.running_stat_width, w2 = 2 * w;
+    if (tid < CS_READS) {
+        const i64 ri = r0 + tid;
+        const bool live = ri < n_reads && rs[ri].status == TBA_OK;
+        s_off[tid] = live ? rs[ri].raw_off : 0;
+        s_n[tid] = live ? rs[ri].n_raw : 0;
+    }
+    for (int k = tid; k < CS_READS * 64; k += 256) halo[k] = 0.0; // c[0] = 0, nothing before it
+    __syncthreads();
+    i64 n_max = 0;
+    for (int q = 0; q < CS_READS; q++) n_max = s_n[q] > n_max ? s_n[q] : n_max;
+    const i64 n_steps = (n_max + CS_CHUNK - 1) / CS_CHUNK;
+    // loader waves: unit u is half `x & 1` of row `x >> 1`, x = (wave - 1) * CS_UNITS + u
+    i64 uoff[CS_UNITS]; // raw_off of the unit's read
+    i64 un[CS_UNITS];   // its length (0: no such unit)
+    int ucol[CS_UNITS];
+    double pre[CS_UNITS]; // the chunk fetched during the previous step
+    if (wave > 0) {
+#pragma unroll
+        for (int u = 0; u < CS_UNITS; u++) {
+            const int x = (wave - 1) * CS_UNITS + u, q = x >> 1;
+            const bool have = x < 2 * CS_READS;
+            ucol[u] = (x & 1) * 64 + lane;
+            un[u] = have ? s_n[have ? q : 0] : 0;
+            uoff[u] = s_off[have ? q : 0];
+        }
+    }
+    auto fetch = [&](i64 chunk) {
+#pragma unroll
+        for (int u = 0; u < CS_UNITS; u++) {
+            const i64 k = chunk * CS_CHUNK + ucol[u];
+            pre[u] = k < un[u] ? norm[uoff[u] + k] : 0.0;
+        }
+    };
+    auto drop = [&](double *t) {
+#pragma unroll
+        for (int u = 0; u < CS_UNITS; u++) {
+            const int x = (wave - 1) * CS_UNITS + u;
+            if (x < 2 * CS_READS) t[(x >> 1) * CS_STRIDE + ucol[u]] = pre[u];
+        }
+    };
+    if (wave > 0) { fetch(0); drop(tile[0]); if (n_steps > 1) fetch(1); }
+    __syncthreads();
+    const i64 my_n = lane < CS_READS ? s_n[lane < CS_READS ? lane : 0] : 0;
+    double acc = 0.0; // wave 0: running sum of read r0 + lane
+    for (i64 i = 0; i <= n_steps; i++) { // one extra step turns the last tile into scores
+        if (wave == 0) {
+            if (i < n_steps && lane < CS_READS) {
+                double *row = tile[i % 3] + lane * CS_STRIDE;
+                const i64 left = my_n - i * CS_CHUNK;
+                if (left >= CS_CHUNK) {
+#pragma unroll 16
+                    for (int k = 0; k < CS_CHUNK; k++) { acc = acc + row[k]; row[k] = acc; }
+                } else {
+                    for (int k = 0; k < CS_CHUNK; k++)
+                        if (k < left) { acc = acc + row[k]; row[k] = acc; }
+                }
+            }
+        } else {
+            if (i + 1 < n_steps) drop(tile[(i + 1) % 3]);
+            if (i + 2 < n_steps) fetch(i + 2);
+            if (i >= 1) {
+                // tile j = i - 1 holds c[jC + 1 .. jC + C] (column t <-> c index jC + 1 + t);
+                // halo row q holds c[jC + 1 - 2w .. jC].  Column t closes the window of position
+                // k = jC + 1 + t - 2w: score[k] = |2 c[k + w] - c[k] - c[k + 2w]| (pyx:94-98)
+                const double *t = tile[(i - 1) % 3];
+                const i64 m0 = (i - 1) * CS_CHUNK + 1; // c index of column 0
+                double ca[CS_UNITS], cb[CS_UNITS], cc[CS_UNITS];
+#pragma unroll
+                for (int u = 0; u < CS_UNITS; u++) { // all LDS reads first
+                    const int x = (wave - 1) * CS_UNITS + u, q = x < 2 * CS_READS ? x >> 1 : 0;
+                    const double *row = t + q * CS_STRIDE, *hr = halo + q * 64;
+                    const int c = ucol[u];
+                    cc[u] = row[c];
+                    // c[k] sits 2w columns to the left, c[k + w] w columns: tile or halo
+                    ca[u] = c >= w2 ? row[c - w2] : hr[c];
+                    cb[u] = c >= w ? row[c - w] : hr[c + w];
+                }
+#pragma unroll
+                for (int u = 0; u < CS_UNITS; u++) {
+                    const i64 k = m0 + ucol[u] - w2;
+                    if (k >= 0 && k < un[u] + 1 - w2) score[uoff[u] + k] = fabs(((2 * cb[u]) - ca[u]) - cc[u]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // next halo: the last 2w columns of this tile (second half of each row)
+#pragma unroll
+                for (int u = 0; u < CS_UNITS; u++) {
+                    const int x = (wave - 1) * CS_UNITS + u;
+                    if (x < 2 * CS_READS && (x & 1) && lane >= 64 - w2)
+                        halo[(x >> 1) * 64 + lane - (64 - w2)] = cc[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // c_valid_cpts_w_cap_t_test scores, _c_helper.pyx:152-183 (sequential sums inside each window)
 __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const DevParams *dp,
     const double *raw, double *score)

@@ -336,10 +336,14 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     if (ON(TBA_STAGE_SEGMENT) && !rna)
         k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0);
     MARK(); // 1 cumsum
-    if (ON(TBA_STAGE_SEGMENT) && !rna) k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
+    const bool fused_scores = 2 * P.running_stat_width <= 64; // cumsum + scores in one kernel
+    if (ON(TBA_STAGE_SEGMENT) && !rna) {
+        if (fused_scores) k_cumsum_scores<<<(unsigned)((n + CS_READS - 1) / CS_READS), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
+        else k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
+    }
     MARK(); // 2 scores
     if (ON(TBA_STAGE_SEGMENT)) {
-        if (!rna) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>());
+        if (!rna) { if (!fused_scores) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>()); }
         else k_scores_ttest<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_score.as<double>());
     }
     MARK(); // 3 peaks
@@ -846,7 +850,9 @@ static int c_valid_cpts(tba_engine *e, const double *sig, int64_t n, int64_t min
     C_TRY(hipMemcpy(d_dp.p, &dp, sizeof(dp), hipMemcpyHostToDevice));
     hipStream_t s = e->stream;
     const unsigned g = grid_for(n) > 128 ? 128 : grid_for(n);
-    if (!ttest) {
+    if (!ttest && 2 * width <= 64) { // the batch pipeline's fused form
+        k_cumsum_scores<<<1, 256, 0, s>>>(d_rs.as<ReadState>(), 1, d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
+    } else if (!ttest) {
         k_cumsum<<<1, 64, 0, s>>>(d_rs.as<ReadState>(), 1, d_sig.as<double>(), d_csum.as<double>());
         k_scores_dna<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_csum.as<double>(), d_score.as<double>());
     } else {
