@@ -594,11 +594,10 @@ __global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const 
     double *em = event_means + r.ev_off;
     i64 n = r.n_cpts - 1;
     (void)from_raw_limit;
-    for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < n; e += (i64)gridDim.x * 256) {
-        double s = 0;
-        for (i64 j = c[e]; j < c[e + 1]; j++) s += x[j];
-        em[e] = s / (double)(c[e + 1] - c[e]);
-    }
+    __shared__ double s_seg[4 * SEGW_CAP];
+    const int wave = threadIdx.x >> 6;
+    wave_segment_sums(x, c, n, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * SEGW_CAP,
+                      [&](i64 e, double s, i64 len) { em[e] = s / (double)len; });
 }
 
 // ts.get_scale_values_from_events (tombo_stats.py:217-233): median / MAD of the first

@@ -405,6 +405,41 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
     return block_median_fe(flat_elems(val, n), n, lo, hi, sm, lo_mid, hi_mid);
 }
 
+
+// c_new_means-style segment means, wave-cooperative: a wavefront takes 64 consecutive segments,
+// pulls the samples they span (one contiguous range) into its LDS slice with coalesced loads, and
+// every lane then sums its own segment out of LDS -- sequentially, in sample order, like the
+// reference.  A thread-per-segment loop over global memory touches 64 different cache lines per
+// load instead.  Spans longer than SEGW_CAP samples (long dwell, RNA) take the direct loop.
+// seg has n_segs + 1 ascending boundaries; emit(i, sum, length) per segment.
+#define SEGW_CAP 1024
+template <class Emit>
+__device__ __forceinline__ void wave_segment_sums(const double *__restrict__ x,
+    const i64 *__restrict__ seg, i64 n_segs, i64 first_group, i64 group_stride, double *lds,
+    Emit emit)
+{
+    const int lane = threadIdx.x & 63;
+    for (i64 g = first_group; g * 64 < n_segs; g += group_stride) {
+        const i64 i = g * 64 + lane;
+        const bool ok = i < n_segs;
+        const i64 a = seg[ok ? i : n_segs], b = seg[ok ? i + 1 : n_segs];
+        const i64 lo = shfl_i64(a, 0);
+        const i64 i_last = g * 64 + 63 < n_segs ? g * 64 + 64 : n_segs;
+        const i64 hi = seg[i_last];
+        const i64 span = hi - lo;
+        double s = 0;
+        if (span <= SEGW_CAP) {
+            __builtin_amdgcn_wave_barrier(); // the previous group's lanes are done with the slice
+            for (i64 k = lane; k < span; k += 64) lds[k] = x[lo + k];
+            __builtin_amdgcn_wave_barrier();
+            for (i64 j = a - lo; j < b - lo; j++) s += lds[j];
+        } else {
+            for (i64 j = a; j < b; j++) s += x[j];
+        }
+        if (ok) emit(i, s, b - a);
+    }
+}
+
 // ordered stream compaction over [0, n): emit(i, out_index) for every i with pred(i), output
 // indices ascending in i.  All threads call; returns the number emitted.  s_w: >= SEL_NT/64 i64.
 // Every thread takes CB consecutive items per step (their predicate loads are issued together),

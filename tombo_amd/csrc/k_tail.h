@@ -315,11 +315,10 @@ __global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const d
     const double *x = sig + r.raw_off + r.read_start;
     const i64 *sg = segs + r.seg_off;
     double *bm = base_means + r.ref_off;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.B; i += (i64)gridDim.x * 256) {
-        double s = 0;
-        for (i64 j = sg[i]; j < sg[i + 1]; j++) s += x[j];
-        bm[i] = s / (double)(sg[i + 1] - sg[i]);
-    }
+    __shared__ double s_seg[4 * SEGW_CAP];
+    const int wave = threadIdx.x >> 6;
+    wave_segment_sums(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * SEGW_CAP,
+                      [&](i64 i, double s, i64 len) { bm[i] = s / (double)len; });
 }
 
 // ts.calc_kmer_fitted_shift_scale(method='theil_sen') (tombo_stats.py:401-450) with
@@ -430,12 +429,13 @@ __global__ __launch_bounds__(256) void k_final_absz(const ReadState *rs, const d
     if (r.status != TBA_OK) return;
     const double *x = norm_out + r.raw_off;
     const i64 *sg = segs + r.seg_off;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.B; i += (i64)gridDim.x * 256) {
-        double s = 0;
-        for (i64 j = sg[i]; j < sg[i + 1]; j++) s += x[j];
-        double m = s / (double)(sg[i + 1] - sg[i]);
-        absz[r.ref_off + i] = fabs((m - ref_means[r.ref_off + i]) / ref_sds[r.ref_off + i]);
-    }
+    __shared__ double s_seg[4 * SEGW_CAP];
+    const int wave = threadIdx.x >> 6;
+    wave_segment_sums(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * SEGW_CAP,
+                      [&](i64 i, double s, i64 len) {
+                          const double m = s / (double)len;
+                          absz[r.ref_off + i] = fabs((m - ref_means[r.ref_off + i]) / ref_sds[r.ref_off + i]);
+                      });
 }
 
 // ts.get_read_seg_score (tombo_stats.py:2327-2338): np.mean in numpy's summation order.
