@@ -203,7 +203,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     const tba_params &P = dp->p;
     const int lane = threadIdx.x;
 
-    i64 W, n_rows, n_static, n_ev, row0 = 0;
+    // row / event indices fit 32 bits: scalar compares and adds instead of 64-bit VALU ones
+    int W, n_rows, n_static, n_ev, row0 = 0;
     bool identity;
     unsigned char *mv;
     const double *ev, *rmu, *rsd, *zmat = nullptr;
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     double stay_pen, skip_pen, z_shift, max_half_z, fill_masked;
     bool winsor;
     if constexpr (DIRECT) {
-        W = job->W; n_rows = job->n_rows; n_static = job->n_static; n_ev = job->n_ev;
-        row0 = job->row0;
+        W = (int)job->W; n_rows = (int)job->n_rows; n_static = (int)job->n_static; n_ev = (int)job->n_ev;
+        row0 = (int)job->row0;
         identity = false;
         mv = job->mv;
         ev = job->ev; rmu = job->mu; rsd = job->sd; zmat = job->zmat; bst = job->starts;
@@ -223,21 +224,21 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         i64 ev_base;
         if (mode == DP_MAIN) {
             if (r.path == PATH_NONE) return;
-            W = r.W;
+            W = (int)r.W;
             if (cpl_class(W) != CPL) return;
-            n_rows = r.B;
-            n_static = r.n_static;
+            n_rows = (int)r.B;
+            n_static = (int)r.n_static;
             ev_base = r.ev_off + r.clip;
-            n_ev = r.n_ev - r.clip;
+            n_ev = (int)(r.n_ev - r.clip);
             identity = false;
             mv = moves + uni(r.moves_off);
         } else {
             if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
-            W = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
-            n_rows = P.start_n_bases;
+            W = (int)(mode == DP_START_TRY ? P.start_bw : P.start_save_bw);
+            n_rows = (int)P.start_n_bases;
             n_static = n_rows;
             ev_base = r.ev_off;
-            n_ev = r.n_ev;
+            n_ev = (int)r.n_ev;
             identity = true;
             mv = moves + (i64)blockIdx.x * start_moves_stride;
         }
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     stay_pen = uni(stay_pen); skip_pen = uni(skip_pen); z_shift = uni(z_shift);
     max_half_z = uni(max_half_z); fill_masked = uni(fill_masked);
     const bool use_z = DIRECT && zmat != nullptr;
-    const int Wi = (int)W;
-    const i64 half_bw = W / 2; // integer division, pyx:327
+    const int Wi = W;
+    const int half_bw = W / 2; // integer division, pyx:327
     const double NEG_INF = -INFINITY;
     const i64 mv_stride = (i64)BPL * 64;
     const int b0 = lane * CPL;   // my first band cell
@@ -273,8 +274,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     for (int j = 0; j < CPL; j++) zs[j] = j < nvalid ? z_shift : NEG_INF;
 
     double v[CPL]; // my cells of the previous row (cells past the band: -inf for good)
-    i64 prev_start = 0;
-    i64 am = 0; // argmax of the previous row (row 0: all zeros -> 0)
+    int prev_start = 0;
+    int am = 0; // argmax of the previous row (row 0: all zeros -> 0)
     if (DIRECT && job->init_row != nullptr) {
         // resume from a given forward row (c_adaptive_banded_forward_pass is handed rows
         // 0..start_seq_pos): load it, take its argmax
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         const double wm = wave_max_f64(lmax);
         u64 eq = __ballot(lmax == wm && nvalid > 0);
         am = uni(__shfl(lidx, __ffsll((unsigned long long)eq) - 1, 64));
-        if (row0 > 0) prev_start = uni(bst[row0 - 1]);
+        if (row0 > 0) prev_start = uni((int)bst[row0 - 1]);
     } else {
 #pragma unroll
         for (int j = 0; j < CPL; j++) v[j] = j < nvalid ? 0.0 : NEG_INF; // row 0: zeros (pyx:253-254)
@@ -305,23 +306,23 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
 
     // event ring: absolute event index a lives at slot (a + RING) & (RING - 1) (plus a mirror of
     // slots 0..CPL-1 behind the end); filled = first absolute index not yet loaded
-    i64 filled = 0;
-    auto ring_store = [&](i64 a, double x) {
-        const int sl = (int)((a + RING) & (RING - 1));
+    int filled = 0;
+    auto ring_store = [&](int a, double x) {
+        const int sl = (a + RING) & (RING - 1);
         ring[sl] = x;
         if (sl < CPL) ring[RING + sl] = x;
     };
-    auto ev_load = [&](i64 a) { // clamped load + select
-        const i64 ac = a < 0 ? 0 : (a >= n_ev ? n_ev - 1 : a);
+    auto ev_load = [&](int a) { // clamped load + select
+        const int ac = a < 0 ? 0 : (a >= n_ev ? n_ev - 1 : a);
         const double x = ev[ac];
         return (a >= 0 && a < n_ev) ? x : 0.0;
     };
     double pf = 0.0;      // one prefetched chunk (event pf_at + lane), in flight
-    i64 pf_at = 0;
+    int pf_at = 0;
     bool pf_pending = false;
     if (!use_z) {
         // the first band start positions the ring: [start, start + RING - 128) is loaded up front
-        i64 first_start = row0 < n_static ? (identity ? row0 : uni(bst[row0])) : prev_start;
+        int first_start = row0 < n_static ? (identity ? row0 : uni((int)bst[row0])) : prev_start;
         filled = first_start;
         for (int c = 0; c < RING / 64 - 2; c++) { ring_store(filled + lane, ev_load(filled + lane)); filled += 64; }
     }
@@ -330,20 +331,20 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     // expected level, sd and its reciprocal of 64 rows at a time: lane l holds row blk0 + l
     // (one coalesced load and one true division per 64 rows), a row reads its lane
     double mu_v = 0, sd_v = 1, y_v = 1;
-    auto load_levels = [&](i64 first) {
-        i64 rc = first + lane;
+    auto load_levels = [&](int first) {
+        int rc = first + lane;
         rc = rc < n_rows ? rc : n_rows - 1;
         mu_v = rmu[rc]; sd_v = rsd[rc];
         y_v = 1.0 / sd_v;
     };
     if (!use_z) load_levels(row0);
-    i64 st_n = 0; int lo_n = 0, hi_n = Wi;
-    auto fetch_row = [&](i64 rr) { // per-row band geometry of the static rows, one row ahead
-        const i64 rc = rr < n_rows ? rr : n_rows - 1;
+    int st_n = 0, lo_n = 0, hi_n = Wi;
+    auto fetch_row = [&](int rr) { // per-row band geometry of the static rows, one row ahead
+        const int rc = rr < n_rows ? rr : n_rows - 1;
         if (rc < n_static) {
             if (identity) { st_n = rc; lo_n = 0; hi_n = Wi; }
-            else if (DIRECT) { st_n = bst[rc]; lo_n = 0; hi_n = Wi; }
-            else { st_n = bst[rc]; lo_n = lo_a[rc]; hi_n = hi_a[rc]; }
+            else if (DIRECT) { st_n = (int)bst[rc]; lo_n = 0; hi_n = Wi; }
+            else { st_n = (int)bst[rc]; lo_n = lo_a[rc]; hi_n = hi_a[rc]; }
         }
     };
     fetch_row(row0);
@@ -351,14 +352,14 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
 #ifdef TBA_SWEEP_STATS
     i64 sw_total = 0, sw_lanes = 0, sw_depth[4] = {0, 0, 0, 0};
 #endif
-    for (i64 row = row0; row < n_rows; row++) {
+    for (int row = row0; row < n_rows; row++) {
         double mu = 0, sd = 1, y = 1;
         if (!use_z) {
-            const int sel = (int)((row - row0) & 63);
+            const int sel = (row - row0) & 63;
             if (sel == 0 && row != row0) load_levels(row);
             mu = readlane_f64(mu_v, sel); sd = readlane_f64(sd_v, sel); y = readlane_f64(y_v, sel);
         }
-        i64 cur_start;
+        int cur_start;
         int lo, hi;
         double fill;
         if (row < n_static) {
@@ -377,18 +378,18 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             }
             if (lane == 0) bst[row] = cur_start;
             lo = 0;
-            hi = cur_start + W <= n_ev ? Wi : (int)(n_ev - cur_start);
+            hi = cur_start + W <= n_ev ? Wi : n_ev - cur_start;
             fill = DIRECT ? fill_masked : MASK_FILL_Z_SCORE; // literal -15, pyx:385-386
         }
         fetch_row(row + 1); // next row's inputs travel while this row computes
-        const int diff_i = (int)(row > 0 ? cur_start - prev_start : 0);
+        const int diff_i = row > 0 ? cur_start - prev_start : 0;
 
         // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720)
         double z[CPL];
         if (use_z) {
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
-                const double zz = zmat[row * W + (j < nvalid ? b0 + j : Wi - 1)];
+                const double zz = zmat[(i64)row * W + (j < nvalid ? b0 + j : Wi - 1)];
                 z[j] = j < nvalid ? zz : NEG_INF;
             }
         } else {
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 if (pf_pending) { ring_store(pf_at + lane, pf); filled = pf_at + 64; pf_pending = false; }
                 while (cur_start + 64 * CPL > filled) { ring_store(filled + lane, ev_load(filled + lane)); filled += 64; }
             }
-            const double *er = ring + (int)((cur_start + RING + b0) & (RING - 1)); // + j < RING + CPL
+            const double *er = ring + ((cur_start + RING + b0) & (RING - 1)); // + j < RING + CPL
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
                 double pz = fabs(div_by_recip(er[j] - mu, sd, y));
