@@ -326,10 +326,16 @@ __global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const d
 // intercept.  One workgroup per read; the (<= 1000) points sit in LDS, the n(n-1)/2 slopes are
 // recomputed inside every radix-select pass instead of being stored (4 MB per read otherwise).
 // Pair enumeration by circular distance: (i, (i+d) mod n); slope(i,j) == slope(j,i) bitwise.
+#define TSW_SAMPLE_DIST 64  // distances in the window sample
+#define TSW_MIN_POINTS 256  // below this the generic two-pass select is cheap anyway
+#define TSW_REL 1e-5        // guard band of the approximate classification (see below)
 __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevParams *dp,
-    const double *base_means, const double *ref_means, const i64 *samp_ind)
+    const double *base_means, const double *ref_means, const i64 *samp_ind, double *scratch)
 {
     __shared__ BucketSmem sm;
+    __shared__ u32 s_ncand;
+    __shared__ double s_win[2];
+    __shared__ int s_win_ok;
     __shared__ double s_ev[MAX_TS_POINTS], s_md[MAX_TS_POINTS];
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
@@ -385,9 +391,129 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
             }
         }
     };
-    // slopes of a normalised read cluster around 1: [0.5, 1.5] is only the first bucket range,
-    // any other distribution costs refinement passes, not correctness (k_select.h)
-    double slope = block_median_fe(slopes, ns, 0.5, 1.5, &sm);
+    // Median slope.  Generic form: two bucket-select passes over all n(n-1)/2 exact slopes
+    // (slopes of a normalised read cluster around 1: [0.5, 1.5] is only the first bucket range,
+    // any other distribution costs refinement passes, not correctness; k_select.h).
+    //
+    // Fast form (n >= TSW_MIN_POINTS), ONE pass over the pairs:
+    //  1. a sample (TSW_SAMPLE_DIST evenly spread circular distances, exact slopes) is
+    //     histogrammed; the buckets at the sample quantiles 0.5 -/+ 4 sigma give a window
+    //     [t1, t2) that holds the two middle ranks of ALL slopes with near certainty;
+    //  2. every pair is classified against the window by an approximate quotient
+    //     a * r, r = v_rcp_f64(b) refined by one Newton step (relative error far below TSW_REL):
+    //     safely below t1 -> counted; safely above t2 -> nothing; inside the window or within
+    //     the guard band of an edge -> (a, b) is appended to a list in global scratch;
+    //  3. the list (a few thousand pairs) is divided exactly, classified exactly, and the middle
+    //     ranks are selected among the exact in-window slopes.
+    // The count below t1 and the in-window multiset are exact, so the result is the reference's
+    // np.median; whenever the window misses the middle ranks or the list overflows, the generic
+    // form runs instead.
+    double slope = 0;
+    bool fast_done = false;
+    const i64 cap = r.n_raw / 2 < 12288 ? r.n_raw / 2 : 12288; // (a, b) pairs in my scratch slice
+    if (n >= TSW_MIN_POINTS && scratch != nullptr && cap >= 4096) {
+        double *cl = scratch + r.raw_off + blockIdx.x; // this read's slice of the csum buffer
+        const int nn = (int)n, dmax = (nn - 1) / 2;
+        const int ds = dmax < TSW_SAMPLE_DIST ? dmax : TSW_SAMPLE_DIST;
+        const double glo = 0.5, gsc = (double)BS_NB / 1.0;
+        for (int b = tid; b < BS_NB; b += SEL_NT) sm.hist[b] = 0;
+        if (tid == 0) { s_ncand = 0; s_win_ok = 0; }
+        __syncthreads();
+        for (int t0 = 0; t0 < ds; t0++) { // sample: distance 1 + t0 * dmax / ds
+            const int d = 1 + (int)(((i64)t0 * dmax) / ds);
+            for (int i = tid; i < nn; i += SEL_NT) {
+                int j = i + d; j = j >= nn ? j - nn : j;
+                const double ei = s_ev[i], ej = s_ev[j];
+                const double sl = (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) / (ei - ej);
+                atomicAdd(&sm.hist[bs_bucket(sl, glo, gsc)], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double m = (double)nn * ds;
+            const double dq = 4.0 * sqrt(0.25 / m) + 0.0005;
+            const i64 r1 = (i64)((0.5 - dq) * m), r2 = (i64)((0.5 + dq) * m);
+            i64 acc = 0; int b1 = -1, b2 = -1;
+            for (int b = 0; b < BS_NB; b++) {
+                const i64 nx = acc + sm.hist[b];
+                if (b1 < 0 && nx > r1) b1 = b;
+                if (b2 < 0 && nx > r2) { b2 = b; break; }
+                acc = nx;
+            }
+            if (b1 > 0 && b2 >= b1 && b2 < BS_NB - 1) {
+                s_win[0] = glo + (double)b1 / gsc;
+                s_win[1] = glo + (double)(b2 + 1) / gsc;
+                s_win_ok = 1;
+            }
+        }
+        __syncthreads();
+        if (s_win_ok) {
+            const double t1 = s_win[0], t2 = s_win[1]; // 0.5 < t1 < t2 < 1.5
+            const double A1 = t1 - t1 * TSW_REL, B2 = t2 + t2 * TSW_REL;
+            i64 c_lo = 0;
+            const int dtop = dmax + ((nn & 1) ? 0 : 1);
+            for (int i0 = 0; i0 < nn; i0 += SEL_NT) {
+                const int i = i0 + tid;
+                const bool okr = i < nn;
+                const int ic = okr ? i : 0;
+                const double ei = s_ev[ic], mi = s_md[ic];
+                const int dlim = okr ? ((nn & 1) || i >= nn / 2 ? dmax : dtop) : 0;
+                for (int d0 = 1; d0 <= dtop; d0 += 4) {
+                    double ej[4], mj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        int j = ic + d0 + u;
+                        j = j >= nn ? j - nn : j;
+                        j = j >= nn ? 0 : j;
+                        ej[u] = s_ev[j]; mj[u] = s_md[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (d0 + u > dlim) continue;
+                        const double b = ei - ej[u], a = mi - mj[u];
+                        if (b == 0) continue; // max_slope = 1000: above the window
+                        double rr = __builtin_amdgcn_rcp(b);
+                        rr = __builtin_fma(__builtin_fma(-b, rr, 1.0), rr, rr);
+                        const double q = a * rr;
+                        if (q < A1) { c_lo++; continue; }       // safely below the window
+                        if (q >= B2) continue;                   // safely above
+                        // inside, or too close to an edge to tell (NaNs land here too)
+                        const u32 pos = atomicAdd(&s_ncand, 1u);
+                        if (pos < cap) { cl[2 * (i64)pos] = a; cl[2 * (i64)pos + 1] = b; }
+                    }
+                }
+            }
+            c_lo = block_sum_i64(c_lo, &sm.rad);
+            __threadfence_block();
+            __syncthreads();
+            const i64 n_c = s_ncand;
+            if (n_c <= cap) {
+                // exact slopes of the listed pairs; in-window ones stay (in place of their a),
+                // the rest becomes +inf and the ones below t1 are counted
+                i64 lo_more = 0, inw = 0;
+                for (i64 k = tid; k < n_c; k += SEL_NT) {
+                    const double sl = cl[2 * k] / cl[2 * k + 1];
+                    const bool below = sl < t1, in = sl >= t1 && sl < t2;
+                    lo_more += below; inw += in;
+                    cl[2 * k] = in ? sl : INFINITY;
+                }
+                c_lo += block_sum_i64(lo_more, &sm.rad);
+                inw = block_sum_i64(inw, &sm.rad);
+                __threadfence_block();
+                __syncthreads();
+                const i64 k_lo = (ns - 1) / 2 - c_lo, k_hi = ns / 2 - c_lo;
+                if (k_lo >= 0 && k_hi < inw) {
+                    const double a = block_kth([&](i64 k) { return cl[2 * k]; }, n_c, k_lo, t1, t2, &sm);
+                    __syncthreads();
+                    double b = a;
+                    if (k_hi != k_lo) { b = block_kth([&](i64 k) { return cl[2 * k]; }, n_c, k_hi, t1, t2, &sm); __syncthreads(); }
+                    slope = (ns & 1) ? a : (a + b) / 2.0;
+                    fast_done = true;
+                }
+            }
+        }
+    }
+    if (!fast_done) slope = block_median_fe(slopes, ns, 0.5, 1.5, &sm);
     double inter = block_median_fast([&](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, 0.0,
                                      1.0, &sm); // n <= 1000: gathered directly
     if (tid == 0) {

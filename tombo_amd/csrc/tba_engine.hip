@@ -399,7 +399,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     MARK(); // 12 theil-sen
     if (ON(TBA_STAGE_RESCALE)) {
         k_base_means<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_bm.as<double>());
-        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_bm.as<double>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr);
+        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_bm.as<double>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr, e->d_csum.as<double>());
     }
     MARK(); // 13 rescale + score
     if (ON(TBA_STAGE_RESCALE)) {
