@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const d
 // intercept.  One workgroup per read; the (<= 1000) points sit in LDS, the n(n-1)/2 slopes are
 // recomputed inside every radix-select pass instead of being stored (4 MB per read otherwise).
 // Pair enumeration by circular distance: (i, (i+d) mod n); slope(i,j) == slope(j,i) bitwise.
-#define TSW_SAMPLE_DIST 64  // distances in the window sample
+#define TSW_SAMPLE_DIST 128 // distances in the window sample
 #define TSW_MIN_POINTS 256  // below this the generic two-pass select is cheap anyway
 #define TSW_REL 1e-5        // guard band of the approximate classification (see below)
 __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevParams *dp,
@@ -504,9 +504,14 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
                 const i64 k_lo = (ns - 1) / 2 - c_lo, k_hi = ns / 2 - c_lo;
                 if (k_lo >= 0 && k_hi < inw) {
                     const double a = block_kth([&](i64 k) { return cl[2 * k]; }, n_c, k_lo, t1, t2, &sm);
+                    const int found = sm.found;
+                    const double nxt = sm.next;
                     __syncthreads();
                     double b = a;
-                    if (k_hi != k_lo) { b = block_kth([&](i64 k) { return cl[2 * k]; }, n_c, k_hi, t1, t2, &sm); __syncthreads(); }
+                    if (k_hi != k_lo) {
+                        if (found & 2) b = nxt; // the next order statistic came with the first one
+                        else { b = block_kth([&](i64 k) { return cl[2 * k]; }, n_c, k_hi, t1, t2, &sm); __syncthreads(); }
+                    }
                     slope = (ns & 1) ? a : (a + b) / 2.0;
                     fast_done = true;
                 }
