@@ -594,9 +594,10 @@ __global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const 
     double *em = event_means + r.ev_off;
     i64 n = r.n_cpts - 1;
     (void)from_raw_limit;
-    __shared__ double s_seg[4 * SEGW_CAP];
+    constexpr int CAP = 448; // 64 events of ~5 samples
+    __shared__ double s_seg[4 * CAP];
     const int wave = threadIdx.x >> 6;
-    wave_segment_sums(x, c, n, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * SEGW_CAP,
+    wave_segment_sums<CAP>(x, c, n, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
                       [&](i64 e, double s, i64 len) { em[e] = s / (double)len; });
 }
 

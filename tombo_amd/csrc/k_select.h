@@ -410,10 +410,11 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
 // pulls the samples they span (one contiguous range) into its LDS slice with coalesced loads, and
 // every lane then sums its own segment out of LDS -- sequentially, in sample order, like the
 // reference.  A thread-per-segment loop over global memory touches 64 different cache lines per
-// load instead.  Spans longer than SEGW_CAP samples (long dwell, RNA) take the direct loop.
+// load instead.  Spans longer than SEGW_CAP samples (long dwell, RNA) take the direct loop; the
+// cap is per kernel: a smaller LDS slice lets more workgroups share a CU (these kernels are
+// bandwidth bound, occupancy is what keeps bytes in flight).
 // seg has n_segs + 1 ascending boundaries; emit(i, sum, length) per segment.
-#define SEGW_CAP 1024
-template <class Emit>
+template <int SEGW_CAP, class Emit>
 __device__ __forceinline__ void wave_segment_sums(const double *__restrict__ x,
     const i64 *__restrict__ seg, i64 n_segs, i64 first_group, i64 group_stride, double *lds,
     Emit emit)

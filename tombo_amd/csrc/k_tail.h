@@ -315,9 +315,10 @@ __global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const d
     const double *x = sig + r.raw_off + r.read_start;
     const i64 *sg = segs + r.seg_off;
     double *bm = base_means + r.ref_off;
-    __shared__ double s_seg[4 * SEGW_CAP];
+    constexpr int CAP = 768; // 64 bases of ~9 samples
+    __shared__ double s_seg[4 * CAP];
     const int wave = threadIdx.x >> 6;
-    wave_segment_sums(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * SEGW_CAP,
+    wave_segment_sums<CAP>(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
                       [&](i64 i, double s, i64 len) { bm[i] = s / (double)len; });
 }
 
@@ -560,9 +561,10 @@ __global__ __launch_bounds__(256) void k_final_absz(const ReadState *rs, const d
     if (r.status != TBA_OK) return;
     const double *x = norm_out + r.raw_off;
     const i64 *sg = segs + r.seg_off;
-    __shared__ double s_seg[4 * SEGW_CAP];
+    constexpr int CAP = 768; // 64 bases of ~9 samples
+    __shared__ double s_seg[4 * CAP];
     const int wave = threadIdx.x >> 6;
-    wave_segment_sums(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * SEGW_CAP,
+    wave_segment_sums<CAP>(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
                       [&](i64 i, double s, i64 len) {
                           const double m = s / (double)len;
                           absz[r.ref_off + i] = fabs((m - ref_means[r.ref_off + i]) / ref_sds[r.ref_off + i]);
