@@ -20,7 +20,8 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
     const tba_opts &o = dp->o;
     double shift, scale, lo = 0, hi = 0;
     double xlo = 0, xhi = 0, mn = 0, mx = 0; // middle order statistics / range of the raw signal
-    bool have_lims = false, use_sv = false;
+    bool have_lims = false, use_sv = false, have_dev = false;
+    double dlo = 0, dhi = 0; // middle order statistics of |x - shift|
     if (r.sv_flags & 1) {
         use_sv = true;
         shift = sv_in[4 * blockIdx.x + 0];
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         else {
             const double a = mx - shift, b2 = shift - mn;
             scale = block_median_fast([&](i64 i) { return fabs(x[i] - shift); }, n, 0.0,
-                                      a > b2 ? a : b2, &sm);
+                                      a > b2 ? a : b2, &sm, &dlo, &dhi);
+            have_dev = true;
         }
     }
     // The normalised signal is written once, at the end: the passes in between recompute
@@ -68,9 +70,19 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         // reference averages; for a negative const scale they swap places, the sum does not care)
         const double ylo = (xlo - shift) / scale, yhi = (xhi - shift) / scale;
         const double med = (n & 1) ? ylo : (ylo + yhi) / 2.0;
-        const double e0 = fabs((mn - shift) / scale - med), e1 = fabs((mx - shift) / scale - med);
-        const double mad = block_median_fast(
-            [&](i64 i) { return fabs((x[i] - shift) / scale - med); }, n, 0.0, e0 > e1 ? e0 : e1, &sm);
+        double mad;
+        if (have_dev && med == 0.0 && scale > 0) {
+            // |norm - 0| = RN(|x - shift| / scale) is a monotone image of the deviations the
+            // scale was just selected from, so its middle order statistics are the images of
+            // theirs: no pass over the signal (med is exactly 0 for every odd length and for the
+            // even ones whose two middle samples sit symmetrically around the shift)
+            const double m_lo = dlo / scale, m_hi = dhi / scale;
+            mad = (n & 1) ? m_lo : (m_lo + m_hi) / 2.0;
+        } else {
+            const double e0 = fabs((mn - shift) / scale - med), e1 = fabs((mx - shift) / scale - med);
+            mad = block_median_fast(
+                [&](i64 i) { return fabs((x[i] - shift) / scale - med); }, n, 0.0, e0 > e1 ? e0 : e1, &sm);
+        }
         lo = med - (mad * o.outlier_thresh);
         hi = med + (mad * o.outlier_thresh);
         have_lims = true;
