@@ -359,8 +359,11 @@ __device__ __forceinline__ W64 w_ballot_to_lane(W64 old, u64 m, int g) // word o
         : "+v"(lo), "+v"(hi) : "s"(mlo), "s"(g), "s"(mhi) : "m0");
     return {lo, hi};
 }
+// Taken scores of the core positions are appended to `dense` on the way (order is irrelevant to
+// the selection that follows): one LDS counter bump per 64 positions.
 template <int R>
-__device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns)
+__device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *dense, u32 *n_dense,
+                          double &mn, double &mx)
 {
     static_assert(R >= 1 && R < 32, "exclusion radius");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -430,6 +433,19 @@ __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns)
             const u32 tb = lane < 32 ? (tl >> lane) & 1u : (th >> (lane - 32)) & 1u;
             const u32 sb = lane < 32 ? (sl >> lane) & 1u : (sh >> (lane - 32)) & 1u;
             if (p < ns) st[p] = (unsigned char)(tb | (sb << 1));
+            const u32 cnt = __popc(tl) + __popc(th); // taken bits only ever sit on valid positions
+            if (cnt) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(n_dense, cnt);
+                base = __shfl(base, 0, 64);
+                if (tb) {
+                    const u32 below = lane < 32 ? __popc(tl & ((1u << lane) - 1u))
+                                                : __popc(tl) + __popc(th & ((1u << (lane - 32)) - 1u));
+                    const double v = s[p];
+                    dense[base + below] = v;
+                    mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+                }
+            }
         }
         if (lane >= 1 && lane < 63) left += __popc(U.lo) + __popc(U.hi);
     }
@@ -442,6 +458,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     __shared__ BucketSmem sm;
     __shared__ i64 s_w[SEL_NT / 64];
     __shared__ i64 s_idx_thr;
+    __shared__ u32 s_ndense;
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
     const int tid = threadIdx.x;
@@ -454,6 +471,8 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     double *dn = dense + r.raw_off + blockIdx.x; // scratch: taken scores, densely packed
     i64 *cpts = valid_cpts + r.ev_off;
     if (ns <= 0 || num_cpts <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
+    double mn = INFINITY, mx = -INFINITY; // range of the taken scores
+    bool fused = false, had_leftovers = false;
 
     // Phase 1: resolve the greedy inside LDS tiles (core PK_CORE positions + PK_HALO each side).
     // A position is only decided from neighbours that are themselves decided, so every decision
@@ -462,14 +481,17 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     TBA_PHASE_T0();
     {
         i64 left_undecided = 0;
-        if (m - 1 == 2) { left_undecided = peaks_bits<2>(s, st, ns); __syncthreads(); }
-        else if (m - 1 == 5) { left_undecided = peaks_bits<5>(s, st, ns); __syncthreads(); }
+        if (tid == 0) s_ndense = 0;
+        __syncthreads();
+        if (m - 1 == 2) { left_undecided = peaks_bits<2>(s, st, ns, dn, &s_ndense, mn, mx); fused = true; __syncthreads(); }
+        else if (m - 1 == 5) { left_undecided = peaks_bits<5>(s, st, ns, dn, &s_ndense, mn, mx); fused = true; __syncthreads(); }
         else { // unusual min_obs_per_base: everything goes through the global rounds
             for (i64 p = tid; p < ns; p += SEL_NT) st[p] = 0;
             left_undecided = 1;
             __syncthreads();
         }
         left_undecided = block_sum_i64(left_undecided, &sm.rad);
+        had_leftovers = left_undecided > 0;
         TBA_PHASE(0);
         // Phase 2: global rounds for whatever the tiles could not settle
         for (i64 round = 0; left_undecided > 0 && round <= ns; round++) {
@@ -495,12 +517,20 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
         }
     }
     TBA_PHASE(1);
-    // taken scores -> dense array (+ their range)
-    double mn = INFINITY, mx = -INFINITY;
-    const i64 n_taken = block_compact(
-        ns, [&](i64 p) { return st[p] == 1; },
-        [&](i64 p, i64 o) { double v = s[p]; dn[o] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; },
-        s_w);
+    // taken scores -> dense array (+ their range): done by the tiles, unless some positions had
+    // to be settled by the global rounds (then one ordered compaction pass redoes it)
+    i64 n_taken;
+    if (fused && !had_leftovers) {
+        __threadfence_block();
+        __syncthreads();
+        n_taken = s_ndense;
+    } else {
+        mn = INFINITY; mx = -INFINITY;
+        n_taken = block_compact(
+            ns, [&](i64 p) { return st[p] == 1; },
+            [&](i64 p, i64 o) { double v = s[p]; dn[o] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; },
+            s_w);
+    }
     if (n_taken < num_cpts) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
     for (int mm = 32; mm >= 1; mm >>= 1) {
         double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
