@@ -67,6 +67,21 @@ __device__ __forceinline__ double dpp_mov_f64(double x)
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    // v_max_f32 with a DPP source, in place: one instruction per ladder step (the builtin form
+    // costs a copy, a DPP move and a canonicalising self-max besides the max).  s_nop 1: a DPP
+    // read of a VGPR needs two wait states after the VALU write of it.
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ double wave_max_f64(double v)
 {
     // no NaNs reach this point (a NaN row is caught by the sweep bound), so v_max_f64 == select
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 const u32 f = cv[j] > s ? (tk[j] ? 1u : 2u) : 0u;
                 mvw[j / 16] |= f << (2 * (j % 16));
                 x = v[j];
-                lmax = __builtin_fmax(lmax, x);
+                lmax = max_f64_raw(lmax, x);
             }
         }
         {
@@ -509,12 +524,26 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         }
         // wave argmax, first index among equal maxima (c_argmax, pyx:186-197): first lane that
         // holds the maximum, first of its cells that equals it
-        const double wm = wave_max_f64(lmax);
-        int lidx = CPL - 1;
+        // The wave maximum is first located in float32 (conversion is monotone, so the lanes
+        // whose rounded maximum equals the rounded wave maximum include the true one; the DPP
+        // ladder on 32-bit values is one instruction per step instead of three); one candidate
+        // lane is the common case, several fall back to the float64 ladder.  The cell index
+        // inside the winning lane comes from one compare + ballot per cell, resolved on the
+        // scalar unit.
+        double wm;
+        {
+            const float fl = (float)lmax;
+            const float fm = wave_max_f32(fl);
+            const u64 cm = __ballot(fl == fm);
+            if (__popcll(cm) == 1) wm = readlane_f64(lmax, __ffsll((unsigned long long)cm) - 1);
+            else wm = wave_max_f64(lmax);
+        }
+        const u64 eq = __ballot(lmax == wm && nvalid > 0);
+        const int wl = __ffsll((unsigned long long)eq) - 1; // first lane holding the maximum
+        int wj = CPL - 1;
 #pragma unroll
-        for (int j = CPL - 2; j >= 0; j--) lidx = v[j] == wm ? j : lidx;
-        u64 eq = __ballot(lmax == wm && nvalid > 0);
-        am = uni(__shfl(b0 + lidx, __ffsll((unsigned long long)eq) - 1, 64));
+        for (int j = CPL - 2; j >= 0; j--) wj = ((__ballot(v[j] == wm) >> wl) & 1ull) ? j : wj;
+        am = wl * CPL + wj;
         prev_start = cur_start;
     }
 #ifdef TBA_SWEEP_STATS
