@@ -29,14 +29,20 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6300 achievabl
 
 
 def _gen(args):
-    n_bases, seed = args
+    n_bases, seed, samp_name = args
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
-    model = _gen.model if hasattr(_gen, 'model') else None
-    if model is None:
-        model = ts.TomboModel(seq_samp_type=th.seqSampleType('DNA', False))
-        _gen.model = model
+    models = _gen.models if hasattr(_gen, 'models') else {}
+    if samp_name not in models:
+        models[samp_name] = ts.TomboModel(seq_samp_type=th.seqSampleType(samp_name, samp_name == 'RNA'))
+        _gen.models = models
+    model = models[samp_name]
+    if samp_name == 'RNA':
+        # generated in 5'->3' order = what the worker passes after [::-1]; stalls as the worker
+        # finds them
+        seq, raw, _ = synth.synth_read(model, n_bases, seed, **synth.RNA_SYNTH)
+        return ts.encode_seq(seq).copy(), raw, ts.identify_stalls(raw)
     seq, raw, _ = synth.synth_read(model, n_bases, seed, **synth.DNA_SYNTH)
-    return ts.encode_seq(seq).copy(), raw
+    return ts.encode_seq(seq).copy(), raw, None
 
 
 def _under_profiler():
@@ -44,11 +50,11 @@ def _under_profiler():
     return any('rocprof' in os.environ.get(k, '').lower() for k in keys)
 
 
-def make_reads(n_reads, n_bases, base_seed, workers):
+def make_reads(n_reads, n_bases, base_seed, workers, samp_name='DNA'):
     """Synthetic reads (read i: seed base_seed + i).  Worker processes are forked before any
     HIP state exists; under rocprofv3 forked workers deadlock in the tool's signal handler, so
     threads are used there."""
-    jobs = [(n_bases, base_seed + i) for i in range(n_reads)]
+    jobs = [(n_bases, base_seed + i, samp_name) for i in range(n_reads)]
     _gen(jobs[0])
     if workers > 1 and n_reads >= 64 and not _under_profiler():
         import multiprocessing as mp
@@ -60,28 +66,29 @@ def make_reads(n_reads, n_bases, base_seed, workers):
             res = list(ex.map(_gen, jobs, chunksize=max(1, n_reads // (workers * 8))))
     else:
         res = [_gen(j) for j in jobs]
-    return [r[0] for r in res], [r[1] for r in res]
+    return [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
 
 
-def cpu_baseline(seqs, raws, params, model, n_sample, n_bases):
+def cpu_baseline(seqs, raws, params, model, n_sample, n_bases, samp_name='DNA', stalls=None):
     """the CPU restatement (oracle/, kind "port") timed single-threaded on a bounded sample of
     the same workload -- reported baseline only; the oracle is never on the measured path"""
     import oracle
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
     p = oracle.make_params(params)
     o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
-                         sig_match_thresh=SIG_MATCH_THRESH['DNA'])
+                         sig_match_thresh=SIG_MATCH_THRESH[samp_name])
     rng = np.random.RandomState(7)
     n_sample = min(n_sample, len(raws))
     si = [rng.choice(n_bases, 1000, replace=False) if n_bases > 1000 else None
           for _ in range(n_sample)]
+    st = stalls if stalls is not None else [None] * len(raws)
     oracle.resquiggle_read(raws[0], seqs[0], model.level_means, model.level_sds, p, o,
-                           samp_ind=si[0])  # page in
+                           stall_ints=st[0], samp_ind=si[0])  # page in
     t0 = time.perf_counter()
     ok = 0
     for i in range(n_sample):
         r = oracle.resquiggle_read(raws[i], seqs[i], model.level_means, model.level_sds, p, o,
-                                   samp_ind=si[i])
+                                   stall_ints=st[i], samp_ind=si[i])
         ok += r['status'] == 0
     dt = time.perf_counter() - t0
     return n_sample / dt, n_sample, ok
@@ -97,26 +104,32 @@ def main():
     ap.add_argument('--bandwidth', type=int, default=500)
     ap.add_argument('--cpu-sample', type=int, default=150)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--preset', choices=['cfg2', 'cfg3', 'cfg1'], default=None,
-                    help='BASELINE.json configs: cfg2 10kb/W=500 (default), cfg3 10kb/W=300, cfg1 2kb/W=100')
+    ap.add_argument('--preset', choices=['cfg2', 'cfg3', 'cfg1', 'cfg4'], default=None,
+                    help='BASELINE.json configs: cfg2 10kb/W=500 (default), cfg3 10kb/W=300, '
+                         'cfg1 2kb/W=100, cfg4 RNA 3kb/W=500')
     a = ap.parse_args()
+    samp_name = 'DNA'
     if a.preset == 'cfg3':
         a.bandwidth = 300
     elif a.preset == 'cfg1':
         a.bases, a.bandwidth = 2000, 100
+    elif a.preset == 'cfg4':
+        samp_name, a.bases, a.bandwidth = 'RNA', 3000, 500
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     # synthetic input first: worker processes must be forked before HIP is initialised
     from tombo_amd import _native, tombo_stats as ts, tombo_helper as th
-    samp = th.seqSampleType('DNA', False)
+    samp = th.seqSampleType(samp_name, samp_name == 'RNA')
     model = ts.TomboModel(seq_samp_type=samp)
     params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=a.bandwidth)
     if a.bandwidth <= 100:
         params = params._replace(band_bound_thresh=10)  # the default 40 fails every read at W=100
     workers = max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))
-    seqs, raws = make_reads(a.reads, a.bases, 1000003 * (rank + 1), workers)
+    seqs, raws, stalls = make_reads(a.reads, a.bases, 1000003 * (rank + 1), workers, samp_name)
+    if samp_name != 'RNA':
+        stalls = None
     rng = np.random.RandomState(12345 + rank)
     si = None
     if a.bases > 1000:
@@ -134,9 +147,10 @@ def main():
     eng = _native.Engine(dev)
     eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
     p = _native.make_params(params)
-    o = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=1.1)
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    o = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name])
     t_up = time.perf_counter()
-    eng.upload(p, o, raws, seqs, samp_ind=si)   # host -> HBM, outside the timed region
+    eng.upload(p, o, raws, seqs, samp_ind=si, stall_ints=stalls)   # host -> HBM, outside the timed region
     t_up = time.perf_counter() - t_up
     algo_bytes, dp_cells = eng.stats()
 
@@ -186,13 +200,15 @@ def main():
         except (IOError, KeyError, ValueError):
             pass
         res = {
-            'metric': 'resquiggle reads/s (10 kb DNA, bw=500)', 'value': round(value, 2),
+            'metric': 'resquiggle reads/s (%s, bw=%d)' % (
+                '10 kb DNA' if (samp_name, a.bases) == ('DNA', 10000) else
+                '%g kb %s' % (a.bases / 1000.0, samp_name), a.bandwidth), 'value': round(value, 2),
             'unit': 'reads/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%d synthetic %d-base DNA reads per GPU per step, '
+            'config': {'workload': '%d synthetic %d-base %s reads per GPU per step, '
                                    'bandwidth=%d, full resquiggle_read path, inputs resident '
-                                   'in HBM' % (a.reads, a.bases, a.bandwidth),
+                                   'in HBM' % (a.reads, a.bases, samp_name, a.bandwidth),
                        'reads_per_gpu': a.reads, 'bases': a.bases, 'bandwidth': a.bandwidth,
                        'success_rate': round(n_ok / float(a.reads), 4),
                        'parallelism': 'reads sharded over %d process(es), no collective' % world,
@@ -208,7 +224,8 @@ def main():
                          if dp_ms > 0 else None},
         }
         if world == 1 and not a.no_cpu_baseline:
-            v, ns, ok = cpu_baseline(seqs, raws, params, model, a.cpu_sample, a.bases)
+            v, ns, ok = cpu_baseline(seqs, raws, params, model, a.cpu_sample, a.bases, samp_name,
+                                     stalls)
             res['cpu_baseline'] = {
                 'value': round(v, 3), 'unit': 'reads/s', 'cores': 1, 'kind': 'port',
                 'sample': '%d of the same reads through oracle/ (C restatement, 1 thread; '
