@@ -270,28 +270,62 @@ __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 
 }
 
 // c_valid_cpts_w_cap_t_test scores, _c_helper.pyx:152-183 (sequential sums inside each window)
+// Each workgroup step stages 256 + 2w consecutive samples in LDS (one coalesced load) and every
+// thread reads its two windows from there; WS > 0: the window width as a compile-time constant
+// (w = 12 is the RNA default), loops fully unrolled, each sample read once.
+template <int WS>
+__device__ __forceinline__ double ttest_score(const double *t, int w)
+{
+    const int W = WS > 0 ? WS : w;
+    double m1 = 0, m2 = 0, var1 = 0, var2 = 0, d;
+    if constexpr (WS > 0) {
+        double a[WS], b[WS];
+#pragma unroll
+        for (int j = 0; j < WS; j++) { a[j] = t[j]; b[j] = t[WS + j]; }
+#pragma unroll
+        for (int j = 0; j < WS; j++) m1 += a[j];
+        m1 /= (double)WS;
+#pragma unroll
+        for (int j = 0; j < WS; j++) m2 += b[j];
+        m2 /= (double)WS;
+#pragma unroll
+        for (int j = 0; j < WS; j++) { d = a[j] - m1; var1 += d * d; }
+#pragma unroll
+        for (int j = 0; j < WS; j++) { d = b[j] - m2; var2 += d * d; }
+    } else {
+        for (int j = 0; j < W; j++) m1 += t[j];
+        m1 /= (double)W;
+        for (int j = 0; j < W; j++) m2 += t[W + j];
+        m2 /= (double)W;
+        for (int j = 0; j < W; j++) { d = t[j] - m1; var1 += d * d; }
+        for (int j = 0; j < W; j++) { d = t[W + j] - m2; var2 += d * d; }
+    }
+    if (var1 + var2 == 0) return 0.0;
+    return m1 > m2 ? (m1 - m2) / sqrt(var1 + var2) : (m2 - m1) / sqrt(var1 + var2);
+}
+#define TT_MAXW 64
 __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const DevParams *dp,
     const double *raw, double *score)
 {
+    __shared__ double tile[256 + 2 * TT_MAXW];
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
     const i64 w = dp->p.running_stat_width;
     const i64 ns = r.n_raw - 2 * w;
     const double *x = raw + r.raw_off;
     double *s = score + r.raw_off;
-    for (i64 pos = (i64)blockIdx.x * 256 + threadIdx.x; pos < ns; pos += (i64)gridDim.x * 256) {
-        double m1 = 0, m2 = 0, var1 = 0, var2 = 0, d;
-        for (i64 j = 0; j < w; j++) m1 += x[pos + j];
-        m1 /= (double)w;
-        for (i64 j = 0; j < w; j++) m2 += x[pos + w + j];
-        m2 /= (double)w;
-        for (i64 j = 0; j < w; j++) { d = x[pos + j] - m1; var1 += d * d; }
-        for (i64 j = 0; j < w; j++) { d = x[pos + w + j] - m2; var2 += d * d; }
-        double t;
-        if (var1 + var2 == 0) t = 0.0;
-        else if (m1 > m2) t = (m1 - m2) / sqrt(var1 + var2);
-        else t = (m2 - m1) / sqrt(var1 + var2);
-        s[pos] = t;
+    if (w > TT_MAXW) { // no tile: straight from memory
+        for (i64 pos = (i64)blockIdx.x * 256 + threadIdx.x; pos < ns; pos += (i64)gridDim.x * 256)
+            s[pos] = ttest_score<0>(x + pos, (int)w);
+        return;
+    }
+    const int span = 256 + 2 * (int)w;
+    for (i64 p0 = (i64)blockIdx.x * 256; p0 < ns; p0 += (i64)gridDim.x * 256) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < span; k += 256) { const i64 q = p0 + k; tile[k] = q < r.n_raw ? x[q] : 0.0; }
+        __syncthreads();
+        const i64 pos = p0 + threadIdx.x;
+        if (pos < ns) s[pos] = w == 12 ? ttest_score<12>(tile + threadIdx.x, 12) : ttest_score<0>(tile + threadIdx.x, (int)w);
     }
 }
 
