@@ -185,6 +185,13 @@ int tba_batch_put(tba_engine *e, int what, const void *data, int64_t bytes,
 /* per-read num_events for the NEXT tba_batch_upload (segment_signal's argument); NULL clears */
 int tba_set_num_events(tba_engine *e, const int64_t *num_events, int64_t n_reads);
 
+/* Per-base event statistics of the finished batch (the compute part of the Events table that
+ * write_new_fast5_group stores, tombo_helper.py:2341-2362): c_new_mean_stds (_c_helper.pyx:38-57)
+ * over every successful read's final signal and boundaries, on the device.  means / stds: CSR by
+ * the reads' base counts (same layout as the ref_means of tba_batch_get), B_tot doubles each;
+ * entries of failed reads are left untouched. */
+int tba_batch_base_stats(tba_engine *e, double *means, double *stds, int64_t n_values);
+
 /* bytes of algorithmic traffic / cell updates of the last uploaded batch */
 int tba_batch_stats(tba_engine *e, double *algorithmic_bytes, double *dp_cells);
 

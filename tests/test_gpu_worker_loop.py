@@ -114,3 +114,33 @@ def test_adjust_map_res_rna_flips_and_finds_stalls():
     res = rq.resquiggle_batch_iters([adj], model, params, None, outlier_thresh=5.0,
                                     seq_samp_type=samp)
     assert not isinstance(res[0], Exception) and res[0].segs.shape[0] == 301
+
+
+def test_events_table_matches_reference_statistics():
+    """N2, compute part: the Events table of write_new_fast5_group (tombo_helper.py:2341-2362)
+    from the device-resident batch, against c_new_mean_stds restated by the oracle (itself pinned
+    on vectors from the reference's compiled function)"""
+    import oracle
+    from tombo_amd import resquiggle as rq, synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    mrs = [synth.synth_map_res(model, 700, 41), synth.synth_map_res(model, 20, 9, lead=60000),
+           synth.synth_map_res(model, 1300, 42), synth.synth_map_res(model, 260, 43)]
+    np.random.seed(1)
+    results, tables = rq.resquiggle_batch_events(mrs, model, params, 5.0, seq_samp_type=samp)
+    assert isinstance(results[1], th.TomboError) and tables[1] is None
+    for res, tab in zip(results, tables):
+        if tab is None:
+            continue
+        assert tab.dtype.names == ('norm_mean', 'norm_stdev', 'start', 'length', 'base')
+        m, s = oracle.new_mean_stds(res.raw_signal, res.segs)
+        np.testing.assert_array_equal(tab['norm_mean'], m)
+        np.testing.assert_array_equal(tab['norm_stdev'], s)
+        np.testing.assert_array_equal(tab['start'], res.segs[:-1])
+        np.testing.assert_array_equal(tab['length'], np.diff(res.segs))
+        assert b''.join(tab['base']).decode() == res.genome_seq
+        one = th.get_event_data(res)
+        np.testing.assert_array_equal(one['norm_mean'], tab['norm_mean'])
+        np.testing.assert_array_equal(one['norm_stdev'], tab['norm_stdev'])
+        assert np.isnan(th.get_event_data(res, compute_sd=False)['norm_stdev']).all()

@@ -270,6 +270,14 @@ class Engine(object):
             self._h, _p(ne, i64), i64(0 if ne is None else ne.shape[0])), 'tba_set_num_events')
         self._ne_override = ne
 
+    def base_stats(self):
+        """(means, stds) of every base of the finished batch, concatenated by ref_off"""
+        nb = int(self.ref_off[-1])
+        m, s = np.zeros(nb), np.zeros(nb)
+        self._check(self._L.tba_batch_base_stats(self._h, _p(m, f64), _p(s, f64), i64(nb)),
+                    'tba_batch_base_stats')
+        return m, s
+
     def stats(self):
         a, c = f64(0), f64(0)
         self._check(self._L.tba_batch_stats(self._h, C.byref(a), C.byref(c)), 'tba_batch_stats')

@@ -571,6 +571,50 @@ __global__ __launch_bounds__(256) void k_final_absz(const ReadState *rs, const d
                       });
 }
 
+// c_new_mean_stds (_c_helper.pyx:38-57) over the final signal and boundaries of every read of
+// the batch: what write_new_fast5_group (tombo_helper.py:2341-2362) stores per base as
+// norm_mean / norm_stdev.  Same wave-cooperative staging as k_final_absz; the variance loop runs
+// over the staged samples again (population sd around the segment mean).  grid: (blocks, reads)
+__global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const double *norm_out,
+    const i64 *segs, double *means, double *stds)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const double *x = norm_out + r.raw_off;
+    const i64 *sg = segs + r.seg_off;
+    constexpr int CAP = 768;
+    __shared__ double s_seg[4 * CAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *lds = s_seg + wave * CAP;
+    const i64 n_segs = r.B;
+    for (i64 g = (i64)blockIdx.x * 4 + wave; g * 64 < n_segs; g += (i64)gridDim.x * 4) {
+        const i64 i = g * 64 + lane;
+        const bool ok = i < n_segs;
+        const i64 a = sg[ok ? i : n_segs], b = sg[ok ? i + 1 : n_segs];
+        const i64 lo = shfl_i64(a, 0);
+        const i64 hi = sg[g * 64 + 63 < n_segs ? g * 64 + 64 : n_segs];
+        const i64 span = hi - lo;
+        const bool staged = span <= CAP;
+        if (staged) {
+            __builtin_amdgcn_wave_barrier();
+            for (i64 k = lane; k < span; k += 64) lds[k] = x[lo + k];
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double len = (double)(b - a);
+        double s = 0, v = 0, m;
+        if (staged) { // (an LDS and a global pointer must not share one variable: flat apertures)
+            for (i64 j = a - lo; j < b - lo; j++) s += lds[j];
+            m = s / len;
+            for (i64 j = a - lo; j < b - lo; j++) { const double d = lds[j] - m; v += d * d; }
+        } else {
+            for (i64 j = a; j < b; j++) s += x[j];
+            m = s / len;
+            for (i64 j = a; j < b; j++) { const double d = x[j] - m; v += d * d; }
+        }
+        if (ok) { means[r.ref_off + i] = m; stds[r.ref_off + i] = sqrt(v / len); }
+    }
+}
+
 // ts.get_read_seg_score (tombo_stats.py:2327-2338): np.mean in numpy's summation order.
 // One thread per read.
 __global__ void k_final_score(ReadState *rs, i64 n_reads, const double *absz)

@@ -64,14 +64,14 @@ struct tba_engine {
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_bm, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
-        d_moves, d_dscr, d_wide;
+        d_moves, d_dscr, d_wide, d_stat;
     void release_all()
     {
         DevBuf *all[] = {&d_rs, &d_dp, &d_kmeans, &d_ksds, &d_raw, &d_norm, &d_norm_out, &d_csum,
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_bm, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr, &d_wide};
+                         &d_moves, &d_dscr, &d_wide, &d_stat};
         for (DevBuf *b : all) b->release();
     }
 };
@@ -598,6 +598,25 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
         return 0;
     }
     return set_err(TBA_E_ARG, "unknown TBA_GET_* selector");
+}
+
+extern "C" int tba_batch_base_stats(tba_engine *e, double *means, double *stds, int64_t n_values)
+{
+    if (!e || !e->have_batch || !e->ran) return set_err(TBA_E_STATE, "no finished batch");
+    if (!means || !stds || n_values < e->B_tot) return set_err(TBA_E_ARG, "output buffers too small");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->B_tot == 0) return 0;
+    if (e->d_stat.ensure((size_t)e->B_tot * 16)) return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    double *d_m = e->d_stat.as<double>(), *d_s = d_m + e->B_tot;
+    const unsigned gB = (unsigned)std::min<i64>(std::max<i64>((e->max_B + 255) / 256, 1), 128);
+    k_base_stats<<<dim3(gB, (unsigned)e->n_reads), 256, 0, e->stream>>>(e->d_rs.as<ReadState>(),
+        e->d_norm_out.as<double>(), e->d_segs.as<i64>(), d_m, d_s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(means, d_m, (size_t)e->B_tot * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(stds, d_s, (size_t)e->B_tot * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int tba_batch_stats(tba_engine *e, double *algorithmic_bytes, double *dp_cells)

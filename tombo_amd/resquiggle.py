@@ -18,7 +18,7 @@ from ._default_parameters import (
     MAX_POINTS_FOR_THEIL_SEN)
 
 __all__ = ['resquiggle_read', 'resquiggle_batch', 'resquiggle_batch_iters', 'adjust_map_res',
-           'get_engine', 'segment_signal',
+           'resquiggle_batch_events', 'get_engine', 'segment_signal',
            'find_adaptive_base_assignment', 'find_seq_start_in_events',
            'find_static_base_assignment', 'resolve_skipped_bases_with_raw']
 
@@ -419,3 +419,23 @@ def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
                               engine, n_passes))
     out = [res[i] for i in range(n)]
     return (out, n_passes) if return_passes else out
+
+
+def resquiggle_batch_events(map_results, std_ref, rsqgl_params, outlier_thresh=None,
+                            compute_sd=True, engine=None, **kw):
+    """`resquiggle_batch` plus, per successful read, the Events table the reference writes to the
+    FAST5 file (`tombo_helper.write_new_fast5_group`, tombo_helper.py:2341-2362): the per-base
+    statistics are computed on the device from the batch's resident signal and boundaries
+    (`tba_batch_base_stats`), nothing is uploaded again.  Returns (results, tables); tables[i] is
+    None where results[i] is an exception."""
+    eng = get_engine() if engine is None else engine
+    results = resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh, engine=eng, **kw)
+    means, stds = eng.base_stats()
+    tables = []
+    for i, res in enumerate(results):
+        if isinstance(res, Exception):
+            tables.append(None)
+            continue
+        a, b = int(eng.ref_off[i]), int(eng.ref_off[i + 1])
+        tables.append(th.events_table(res, means[a:b], stds[a:b] if compute_sd else None))
+    return results, tables

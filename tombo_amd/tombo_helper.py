@@ -60,3 +60,37 @@ def get_seq_kmers(seq, kmer_width, rev_strand=False):
     """All overlapping k-mers of `seq` (reversed order for the reverse strand)."""
     kmers = [seq[i:i + kmer_width] for i in range(len(seq) - kmer_width + 1)]
     return kmers[::-1] if rev_strand else kmers
+
+
+# ---- the Events table of a resquiggled read (SURVEY.md 8f N2, compute part) -----------------
+EVENTS_DTYPE = [(str('norm_mean'), 'f8'), (str('norm_stdev'), 'f8'), (str('start'), 'u4'),
+                (str('length'), 'u4'), (str('base'), 'S1')]
+
+
+def events_table(rsqgl_res, norm_means, norm_stds=None):
+    """The structured array `write_new_fast5_group` stores as `Events`
+    (tombo_helper.py:2341-2362): per base its normalised mean, standard deviation (NaN when
+    `compute_sd` is off), start and length in raw samples and the base letter."""
+    import numpy as np
+    segs = np.asarray(rsqgl_res.segs, dtype=np.int64)
+    n = segs.shape[0] - 1
+    tab = np.empty(n, dtype=EVENTS_DTYPE)
+    tab['norm_mean'] = norm_means
+    tab['norm_stdev'] = np.nan if norm_stds is None else norm_stds
+    tab['start'] = segs[:-1]
+    tab['length'] = np.diff(segs)
+    tab['base'] = np.frombuffer(rsqgl_res.genome_seq.encode(), dtype='S1')
+    return tab
+
+
+def get_event_data(rsqgl_res, compute_sd=True):
+    """Events table of one finished read; the statistics come from the HIP kernels behind
+    c_new_mean_stds / c_new_means."""
+    from ._c_helper import c_new_mean_stds, c_new_means
+    import numpy as np
+    sig = np.ascontiguousarray(rsqgl_res.raw_signal, dtype=np.float64)
+    segs = np.ascontiguousarray(rsqgl_res.segs, dtype=np.int64)
+    if compute_sd:
+        m, s = c_new_mean_stds(sig, segs)
+        return events_table(rsqgl_res, m, s)
+    return events_table(rsqgl_res, c_new_means(sig, segs))
