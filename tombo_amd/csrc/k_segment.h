@@ -635,27 +635,38 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
 // ts.remove_stall_cpts (tombo_stats.py:1576-1597): a change point is dropped when it lies
 // strictly inside the first stall interval whose end is >= the change point (the reference's
 // forward walk; interval ends ascend).  One thread per read (RNA only, few intervals).
-__global__ void k_remove_stalls(ReadState *rs, i64 n_reads, const i64 *stall_ints,
-    i64 *valid_cpts)
+__global__ __launch_bounds__(SEL_NT) void k_remove_stalls(ReadState *rs, i64 n_reads,
+    const i64 *stall_ints, i64 *valid_cpts, double *scratch)
 {
-    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ri >= n_reads) return;
-    ReadState &r = rs[ri];
+    // workgroup per read: the interval the reference's forward walk would be looking at when it
+    // reaches a change point is the first one whose end is >= the point (the last interval once
+    // the point is past every end) -- a binary search; survivors are compacted in order through
+    // the read's scratch slice
+    __shared__ i64 s_w[SEL_NT / 64];
+    (void)n_reads;
+    ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK || r.n_stall == 0) return;
     const i64 *st = stall_ints + 2 * r.stall_off;
     i64 *c = valid_cpts + r.ev_off;
-    i64 cur = 0, out = 0;
-    for (i64 i = 0; i < r.n_cpts; i++) {
-        i64 v = c[i];
-        while (v > st[2 * cur + 1]) {
-            if (cur + 1 >= r.n_stall) break;
-            cur++;
-        }
-        if (!(st[2 * cur] < v && v < st[2 * cur + 1])) c[out++] = v;
+    i64 *tmp = (i64 *)(scratch + r.raw_off + blockIdx.x);
+    const i64 ns = r.n_stall, n = r.n_cpts;
+    const i64 out = block_compact(
+        n,
+        [&](i64 i) {
+            const i64 v = c[i];
+            i64 lo = 0, hi = ns - 1; // first interval with end >= v, else the last one
+            while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (st[2 * mid + 1] >= v) hi = mid; else lo = mid + 1; }
+            return !(st[2 * lo] < v && v < st[2 * lo + 1]);
+        },
+        [&](i64 i, i64 o) { tmp[o] = c[i]; }, s_w);
+    __threadfence_block();
+    __syncthreads();
+    for (i64 i = threadIdx.x; i < out; i += SEL_NT) c[i] = tmp[i];
+    if (threadIdx.x == 0) {
+        r.n_cpts = out;
+        r.n_ev = out - 1;
+        if (out < 2) r.status = TBA_INTERNAL;
     }
-    r.n_cpts = out;
-    r.n_ev = out - 1;
-    if (out < 2) r.status = TBA_INTERNAL;
 }
 
 // c_new_means (_c_helper.pyx:59-71) over the event boundaries: sequential sum, one divide.

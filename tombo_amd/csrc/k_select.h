@@ -420,13 +420,20 @@ __device__ __forceinline__ void wave_segment_sums(const double *__restrict__ x,
     Emit emit)
 {
     const int lane = threadIdx.x & 63;
-    for (i64 g = first_group; g * 64 < n_segs; g += group_stride) {
-        const i64 i = g * 64 + lane;
-        const bool ok = i < n_segs;
-        const i64 a = seg[ok ? i : n_segs], b = seg[ok ? i + 1 : n_segs];
-        const i64 lo = shfl_i64(a, 0);
-        const i64 i_last = g * 64 + 63 < n_segs ? g * 64 + 64 : n_segs;
-        const i64 hi = seg[i_last];
+    // segments per wave step: 64, or fewer (a power of two) when the segments are long, so that
+    // a step's samples still fit the slice (RNA: 15-sample events, 43-sample bases); the lanes
+    // beyond the group only help loading
+    int gs = 64;
+    if (n_segs > 0) {
+        const double mean_len = (double)(seg[n_segs] - seg[0]) / (double)n_segs;
+        while (gs > 4 && (double)gs * mean_len * 1.3 > (double)SEGW_CAP) gs >>= 1;
+    }
+    for (i64 g = first_group; g * gs < n_segs; g += group_stride) {
+        const i64 i = g * gs + lane;
+        const bool ok = lane < gs && i < n_segs;
+        const i64 i_end = g * gs + gs < n_segs ? g * gs + gs : n_segs;
+        const i64 a = seg[ok ? i : i_end], b = seg[ok ? i + 1 : i_end];
+        const i64 lo = seg[g * gs], hi = seg[i_end];
         const i64 span = hi - lo;
         double s = 0;
         if (span <= SEGW_CAP) {

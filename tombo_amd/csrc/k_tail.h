@@ -587,12 +587,17 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const d
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *lds = s_seg + wave * CAP;
     const i64 n_segs = r.B;
-    for (i64 g = (i64)blockIdx.x * 4 + wave; g * 64 < n_segs; g += (i64)gridDim.x * 4) {
-        const i64 i = g * 64 + lane;
-        const bool ok = i < n_segs;
-        const i64 a = sg[ok ? i : n_segs], b = sg[ok ? i + 1 : n_segs];
-        const i64 lo = shfl_i64(a, 0);
-        const i64 hi = sg[g * 64 + 63 < n_segs ? g * 64 + 64 : n_segs];
+    int gs = 64; // segments per wave step (fewer when they are long, see wave_segment_sums)
+    if (n_segs > 0) {
+        const double mean_len = (double)(sg[n_segs] - sg[0]) / (double)n_segs;
+        while (gs > 4 && (double)gs * mean_len * 1.3 > (double)CAP) gs >>= 1;
+    }
+    for (i64 g = (i64)blockIdx.x * 4 + wave; g * gs < n_segs; g += (i64)gridDim.x * 4) {
+        const i64 i = g * gs + lane;
+        const bool ok = lane < gs && i < n_segs;
+        const i64 i_end = g * gs + gs < n_segs ? g * gs + gs : n_segs;
+        const i64 a = sg[ok ? i : i_end], b = sg[ok ? i + 1 : i_end];
+        const i64 lo = sg[g * gs], hi = sg[i_end];
         const i64 span = hi - lo;
         const bool staged = span <= CAP;
         if (staged) {

@@ -349,7 +349,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     MARK(); // 3 peaks
     if (ON(TBA_STAGE_SEGMENT)) {
         k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
-        if (e->any_stall) k_remove_stalls<<<tpr, 64, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>());
+        if (e->any_stall) k_remove_stalls<<<nb, SEL_NT, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>(), e->d_csum.as<double>());
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
             k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_raw.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
             k_rna_event_scale<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_evm.as<double>());
