@@ -104,3 +104,72 @@ def test_remove_stall_cpts_walk():
     out = ts.remove_stall_cpts([(8, 25), (45, 60)], cpts)
     assert out.tolist() == [5, 30, 40, 60, 100]
     assert ts.remove_stall_cpts([], cpts) is cpts
+
+
+def test_worker_loop_control_flow_without_gpu(monkeypatch):
+    """resquiggle_batch_iters = `_resquiggle_worker`'s per-read loop (resquiggle.py:1492-1504,
+    1578-1589): re-runs while norm_params_changed (at most max_scaling_iters passes, fitted scale
+    values handed on, const_scale / skip_seq_scaling only on the first pass), then every failed
+    read started over with the save parameters.  The engine is replaced by a scripted stub."""
+    from tombo_amd import resquiggle as rq, tombo_helper as th
+    calls = []
+    # per read: outcomes of successive passes with the main parameters, then with the save ones
+    script = {
+        'a': (['ok'], []),
+        'b': (['changed', 'changed', 'ok'], []),
+        'c': (['changed', 'changed', 'changed', 'changed'], []),       # capped at 3 passes
+        'd': (['fail'], ['changed', 'ok']),
+        'e': (['changed', 'fail'], ['fail']),
+    }
+    seen = {}
+
+    def fake_batch(map_results, std_ref, params, outlier_thresh=None, all_raw_signals=None,
+                   const_scale=None, skip_seq_scaling=False, seq_samp_type=None, engine=None, **kw):
+        calls.append((params, [m.align_info for m in map_results], const_scale, skip_seq_scaling,
+                      [m.scale_values for m in map_results], all_raw_signals is not None))
+        out = []
+        for m in map_results:
+            rid = m.align_info
+            k = (rid, params)
+            seen[k] = seen.get(k, 0) + 1
+            plan = script[rid][0 if params == 'main' else 1]
+            what = plan[seen[k] - 1]
+            if what == 'fail':
+                out.append(th.TomboError('boom %s' % rid))
+            else:
+                out.append(m._replace(segs=[0, 1], scale_values=('sv', rid, params, seen[k]),
+                                      norm_params_changed=(what == 'changed')))
+        return out
+    monkeypatch.setattr(rq, 'resquiggle_batch', fake_batch)
+    mrs = [th.resquiggleResults(align_info=r, genome_loc=None, genome_seq='ACGT', mean_q_score=1.0,
+                                raw_signal='raw-' + r) for r in 'abcde']
+    res, passes = rq.resquiggle_batch_iters(mrs, None, 'main', 'save', outlier_thresh=5.0,
+                                            const_scale=12.0, skip_seq_scaling=True,
+                                            return_passes=True)
+    assert passes == [1, 3, 3, 1 + 2, 2 + 1]
+    assert [isinstance(r, Exception) for r in res] == [False, False, False, False, True]
+    assert res[2].norm_params_changed and res[2].scale_values == ('sv', 'c', 'main', 3)
+    assert res[3].scale_values == ('sv', 'd', 'save', 2) and str(res[4]) == 'boom e'
+    # first pass: everyone, with const_scale / skip_seq_scaling; re-runs: only the changed ones,
+    # carrying the fitted scale values and the un-normalised signal, options not forwarded
+    assert calls[0][:4] == ('main', list('abcde'), 12.0, True) and calls[0][4] == [None] * 5
+    assert calls[1][:4] == ('main', list('bce'), None, False) and calls[1][5]
+    assert calls[1][4] == [('sv', r, 'main', 1) for r in 'bce']
+    assert calls[2][:2] == ('main', list('bc'))
+    # the save-parameter round starts the failed reads over (d failed pass 1, e failed pass 2)
+    assert calls[3][:4] == ('save', list('de'), 12.0, True) and calls[3][4] == [None, None]
+    assert calls[4][:2] == ('save', ['d']) and len(calls) == 5
+
+
+def test_events_table_layout():
+    """the Events structured array of write_new_fast5_group (tombo_helper.py:2353-2360)"""
+    import numpy as np
+    from tombo_amd import tombo_helper as th
+    res = th.resquiggleResults(align_info=None, genome_loc=None, genome_seq='ACGTA',
+                               mean_q_score=1.0, segs=np.array([0, 3, 7, 8, 15, 20]))
+    tab = th.events_table(res, np.arange(5) * 0.5, np.arange(5) * 0.1)
+    assert tab.dtype == np.dtype([('norm_mean', 'f8'), ('norm_stdev', 'f8'), ('start', 'u4'),
+                                  ('length', 'u4'), ('base', 'S1')])
+    assert tab['start'].tolist() == [0, 3, 7, 8, 15] and tab['length'].tolist() == [3, 4, 1, 7, 5]
+    assert b''.join(tab['base']) == b'ACGTA' and tab['norm_mean'][4] == 2.0
+    assert np.isnan(th.events_table(res, np.zeros(5))['norm_stdev']).all()
