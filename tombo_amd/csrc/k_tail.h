@@ -122,6 +122,8 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
         if (b_s - ps - 1 < 0 || b_s - ps - 1 >= len) return TBA_INTERNAL;
         bf[0] = zc[0] + pf[b_s - ps - 1];
         bl[0] = 1;
+        double stay_run = bf[0]; // bf / bl of the previous position, carried in registers
+        i64 bl_run = 1;
         for (i64 pos = b_s + 1; pos < pe + 1; pos++) {
             if (pos - b_s >= len) break;
             i64 lag = 1;
@@ -136,12 +138,14 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
             if (di < 0) di += len;
             double diag = pf[di];
             if (lag > 1) diag += cum[pos - ps - 1] - cum[di];
-            double stay = bf[pos - b_s - 1];
+            const double stay = stay_run;
             double best;
             i64 dv;
             if (diag > stay) { best = diag; dv = 1; }
-            else { best = stay; dv = bl[pos - b_s - 1] + 1; }
-            bf[pos - b_s] = zc[pos - b_s] + best;
+            else { best = stay; dv = bl_run + 1; }
+            stay_run = zc[pos - b_s] + best;
+            bl_run = dv;
+            bf[pos - b_s] = stay_run;
             bl[pos - b_s] = dv;
         }
         if (b_e > pe + 1) {
