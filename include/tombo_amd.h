@@ -264,6 +264,11 @@ int tba_c_base_traceback(tba_engine *e, const double *curr_b_data, int64_t curr_
  * residual corrections) for a[i] / b[i]; must equal the IEEE quotient bit for bit */
 int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,
                           double *out);
+/* self-test: out[i] = the approximate quotient a[i] * r, r = v_rcp_f64(b[i]) + one Newton step,
+ * that the Theil-Sen kernel classifies slope pairs with (calc_kmer_fitted_shift_scale,
+ * tombo_stats.py:401-425); its relative error must stay far inside the 1e-5 guard band */
+int tba_selftest_approx_quotient(tba_engine *e, const double *a, const double *b, int64_t n,
+                                 double *out);
 
 #ifdef __cplusplus
 }

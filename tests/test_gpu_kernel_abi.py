@@ -303,3 +303,26 @@ def test_slopes_and_mean_stds_match_reference_vectors():
     got = c_compute_slopes(ev, md)
     np.testing.assert_array_equal(got, oracle.compute_slopes(ev, md))
     assert got.shape[0] == 499500 and (got == 1000.0).sum() == 1
+
+
+def test_approximate_quotient_stays_inside_its_guard_band():
+    """k_theil_sen sorts slope pairs against its window with a * (rcp(b) + one Newton step) and a
+    1e-5 guard band (exact division only inside the band): the approximation has to stay orders
+    of magnitude inside it, including tiny and huge denominators"""
+    import ctypes as C
+    from tombo_amd import resquiggle as rq
+    eng = rq.get_engine(0)
+    rng = np.random.default_rng(9)
+    n = 1 << 20
+    a = rng.normal(0, 2, n)
+    b = rng.normal(0, 1, n)
+    b[:4096] = rng.normal(0, 1, 4096) * 10.0 ** rng.integers(-16, 3, 4096)   # |e_i - e_j| tiny .. large
+    b[b == 0] = 1.0
+    out = np.empty(n)
+    pd = C.POINTER(C.c_double)
+    rc = eng._L.tba_selftest_approx_quotient(eng._h, a.ctypes.data_as(pd), b.ctypes.data_as(pd),
+                                             C.c_int64(n), out.ctypes.data_as(pd))
+    assert rc == 0
+    exact = a / b
+    rel = np.abs(out - exact) / np.maximum(np.abs(exact), 1e-300)
+    assert rel.max() < 1e-9, rel.max()

@@ -54,6 +54,17 @@ __global__ void k_c_div_check(const double *a, const double *b, i64 n, double *o
     }
 }
 
+// self-test of the approximate quotient k_theil_sen classifies pairs with: a * r, r =
+// v_rcp_f64(b) refined by one Newton step
+__global__ void k_c_rcp_check(const double *a, const double *b, i64 n, double *out)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        double rr = __builtin_amdgcn_rcp(b[i]);
+        rr = __builtin_fma(__builtin_fma(-b[i], rr, 1.0), rr, rr);
+        out[i] = a[i] * rr;
+    }
+}
+
 // c_new_mean_stds, _c_helper.pyx:38-57 (population sd around the segment mean)
 __global__ void k_c_new_mean_stds(const double *sig, const i64 *segs, i64 n_segs, double *means,
                                   double *stds)

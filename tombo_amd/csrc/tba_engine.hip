@@ -1070,3 +1070,20 @@ extern "C" int tba_selftest_division(tba_engine *e, const double *a, const doubl
     C_TRY(hipMemcpy(out, d_o.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return TBA_OK;
 }
+
+extern "C" int tba_selftest_approx_quotient(tba_engine *e, const double *a, const double *b,
+                                            int64_t n, double *out)
+{
+    if (!e || !a || !b || !out || n < 1) return set_err(TBA_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_a, d_b, d_o;
+    if (d_a.alloc((size_t)n * 8) || d_b.alloc((size_t)n * 8) || d_o.alloc((size_t)n * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_a.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_b.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
+    k_c_rcp_check<<<grid_for(n), 256, 0, e->stream>>>(d_a.as<double>(), d_b.as<double>(), n, d_o.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(out, d_o.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
