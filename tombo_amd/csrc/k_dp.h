@@ -880,7 +880,9 @@ __global__ __launch_bounds__(256) void k_scan_arena(ReadState *rs, i64 n_reads, 
 }
 
 // main traceback (c_banded_traceback, pyx:281-310) + _trim_traceback (resquiggle.py:754-764).
-// One LANE per read, 64 reads per wavefront walking in lockstep.  The pointer chase is made
+// One LANE per read; launched with only TB_LANES reads per wavefront: the walk is a chain of
+// dependent memory round trips, so what counts is the number of wavefronts in flight, not
+// the lanes in use.  The pointer chase is made
 // latency-tolerant by prefetching: the path stays near the same band position from row to row
 // (the band follows it), so for the next TBR rows a 64-cell window of packed moves around the
 // current band position (one 16-byte load per row) and the band starts are fetched together,
@@ -896,7 +898,7 @@ __device__ __forceinline__ int mv_find_le(u64 x, int top) // highest non-zero 2-
 __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, const DevParams *dp,
     const unsigned char *moves, const i64 *band_starts, i64 *read_tb)
 {
-    const i64 ri = (i64)blockIdx.x * 64 + threadIdx.x;
+    const i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (ri >= n_reads) return;
     ReadState &r = rs[ri];
     if (r.status != TBA_OK) return;

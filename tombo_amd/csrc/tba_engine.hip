@@ -48,6 +48,7 @@ static const char *STAGE_NAMES[N_STAGE] = {
     "rna_scale", "total"};
 
 #define WIDE_BLOCKS 64 // workgroups of k_dp_wide (each owns two scratch rows)
+#define TB_LANES 16    // reads per wavefront of the latency-bound lane-per-read kernels
 struct tba_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -387,7 +388,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 10 main tb
     if (ON(TBA_STAGE_ASSIGN)) {
-        k_main_tb<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        k_main_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         k_tb_gather<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
     }
     MARK(); // 11 skip resolve
@@ -405,7 +406,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     if (ON(TBA_STAGE_RESCALE)) {
         k_rescale<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_norm_out.as<double>());
         k_final_absz<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
-        k_final_score<<<tpr, 64, 0, s>>>(rs, n, e->d_absz.as<double>());
+        k_final_score<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, e->d_absz.as<double>());
     }
     MARK(); // 14 end
 #undef MARK
