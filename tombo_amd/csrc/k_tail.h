@@ -624,6 +624,63 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const d
     }
 }
 
+// k_rescale + k_final_absz in one pass over the signal: a wavefront takes a group of consecutive
+// bases, rescales the samples they span (coalesced read of norm, coalesced write of norm_out),
+// keeps them in its LDS slice and sums every base from there.  The bases tile the trimmed
+// signal exactly (segs[0] = 0, segs[B] = norm_len), so every sample is written once.
+// grid: (blocks, reads)
+__global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const DevParams *dp,
+    const double *norm, double *norm_out, const i64 *segs, const double *ref_means,
+    const double *ref_sds, double *absz)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const double *x = norm + r.raw_off + r.read_start;
+    double *y = norm_out + r.raw_off;
+    const i64 *sg = segs + r.seg_off;
+    const bool skip = dp->o.skip_seq_scaling != 0;
+    const double ca = r.ts[2], cb = r.ts[3];
+    constexpr int CAP = 768;
+    __shared__ double s_seg[4 * CAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *lds = s_seg + wave * CAP;
+    const i64 n_segs = r.B;
+    int gs = 64; // bases per wave step (fewer when they are long, see wave_segment_sums)
+    if (n_segs > 0) {
+        const double mean_len = (double)(sg[n_segs] - sg[0]) / (double)n_segs;
+        while (gs > 4 && (double)gs * mean_len * 1.3 > (double)CAP) gs >>= 1;
+    }
+    for (i64 g = (i64)blockIdx.x * 4 + wave; g * gs < n_segs; g += (i64)gridDim.x * 4) {
+        const i64 i = g * gs + lane;
+        const bool ok = lane < gs && i < n_segs;
+        const i64 i_end = g * gs + gs < n_segs ? g * gs + gs : n_segs;
+        const i64 a = sg[ok ? i : i_end], b = sg[ok ? i + 1 : i_end];
+        const i64 lo = sg[g * gs], hi = sg[i_end];
+        const i64 span = hi - lo;
+        double s = 0;
+        if (span <= CAP) {
+            __builtin_amdgcn_wave_barrier();
+            for (i64 k = lane; k < span; k += 64) {
+                const double v = skip ? x[lo + k] : (x[lo + k] - ca) / cb; // resquiggle.py:1190
+                y[lo + k] = v;
+                lds[k] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (i64 j = a - lo; j < b - lo; j++) s += lds[j];
+        } else {
+            for (i64 j = a; j < b; j++) {
+                const double v = skip ? x[j] : (x[j] - ca) / cb;
+                y[j] = v;
+                s += v;
+            }
+        }
+        if (ok) {
+            const double m = s / (double)(b - a);
+            absz[r.ref_off + i] = fabs((m - ref_means[r.ref_off + i]) / ref_sds[r.ref_off + i]);
+        }
+    }
+}
+
 // ts.get_read_seg_score (tombo_stats.py:2327-2338): np.mean in numpy's summation order.
 // One thread per read.
 __global__ void k_final_score(ReadState *rs, i64 n_reads, const double *absz)
