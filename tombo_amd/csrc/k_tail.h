@@ -401,7 +401,7 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     // any other distribution costs refinement passes, not correctness; k_select.h).
     //
     // Fast form (n >= TSW_MIN_POINTS), ONE pass over the pairs:
-    //  1. a sample (TSW_SAMPLE_DIST evenly spread circular distances, exact slopes) is
+    //  1. a sample (TSW_SAMPLE_DIST evenly spread circular distances, approximate slopes) is
     //     histogrammed; the buckets at the sample quantiles 0.5 -/+ 4 sigma give a window
     //     [t1, t2) that holds the two middle ranks of ALL slopes with near certainty;
     //  2. every pair is classified against the window by an approximate quotient
@@ -428,8 +428,11 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
             const int d = 1 + (int)(((i64)t0 * dmax) / ds);
             for (int i = tid; i < nn; i += SEL_NT) {
                 int j = i + d; j = j >= nn ? j - nn : j;
-                const double ei = s_ev[i], ej = s_ev[j];
-                const double sl = (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) / (ei - ej);
+                // the sample only steers the window: the approximate quotient is good enough
+                const double ei = s_ev[i], ej = s_ev[j], b = ei - ej;
+                double rr = __builtin_amdgcn_rcp(b);
+                rr = __builtin_fma(__builtin_fma(-b, rr, 1.0), rr, rr);
+                const double sl = (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) * rr;
                 atomicAdd(&sm.hist[bs_bucket(sl, glo, gsc)], 1u);
             }
         }
