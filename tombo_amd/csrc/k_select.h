@@ -221,7 +221,9 @@ __device__ double block_kth_fe(FE fe, i64 n, i64 k, double lo, double hi, Bucket
     const int tid = threadIdx.x;
     if (tid == 0) { sm->nlev = 0; sm->k = k; sm->found = 0; sm->cnt = n; }
     __syncthreads();
-    const bool small = n <= BS_CAP; // everything fits the candidate buffer: no histogram
+    // few elements: gather them all and count ranks directly (quadratic, so only when that is
+    // cheaper than a histogram pass)
+    const bool small = n <= 192;
     for (int level = 0; level < BS_LEVELS; level++) {
         double scale = (double)BS_NB / (hi - lo);
         if (!small && (!(hi > lo) || !(scale < 1e300))) break; // degenerate range -> radix

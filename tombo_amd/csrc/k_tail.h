@@ -527,8 +527,9 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
         }
     }
     if (!fast_done) slope = block_median_fe(slopes, ns, 0.5, 1.5, &sm);
-    double inter = block_median_fast([&](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, 0.0,
-                                     1.0, &sm); // n <= 1000: gathered directly
+    // intercepts of a normalised read sit within a unit or so of 0 (first bucket range only)
+    double inter = block_median_fast([&](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, -2.0,
+                                     2.0, &sm);
     if (tid == 0) {
         if (slope == 0) { r.status = TBA_RESCALE_FAIL; return; }
         double scale_corr = 1 / slope;
