@@ -190,10 +190,10 @@ def main():
         dp_ms = float(stage[i_dp])
         achieved = algo_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
         # HBM traffic of that kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes
-        # (profiles/r01f_pmc_hbm_traffic.json, bytes per read), scaled to this launch
+        # (profiles/r01h_pmc_hbm_traffic.json, bytes per read), scaled to this launch
         traffic = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01f_pmc_hbm_traffic.json')) as fp:
+            with open(os.path.join(ROOT, 'profiles', 'r01h_pmc_hbm_traffic.json')) as fp:
                 pmc = json.load(fp)
             if a.bases == 10000 and a.bandwidth == 500:
                 traffic = float(pmc['k_dp_bytes_per_read']) * a.reads
