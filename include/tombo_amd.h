@@ -1,7 +1,7 @@
 /* include/tombo_amd.h -- C ABI of the MI355X-native resquiggle engine (libtombo_amd.so).
  *
  * Drop-in boundary for the hot path of nanoporetech/tombo v1.5.1: everything below
- * tombo.resquiggle.resquiggle_read() (tombo/resquiggle.py:1122-1214) -- i.e. the twelve
+ * tombo.resquiggle.resquiggle_read() (tombo/resquiggle.py:1122-1214) -- i.e. the thirteen
  * Python-callable Cython kernels of tombo/_c_dynamic_programming.pyx and tombo/_c_helper.pyx
  * plus the numpy glue between them -- runs as HIP kernels for gfx950 behind these entry points.
  * Plain pointers and sizes only; caller owns every host buffer; no exceptions cross the ABI:
@@ -12,7 +12,11 @@
  * Two levels:
  *   1. the batch engine (tba_engine_*, tba_batch_*): N reads packed as ragged SoA buffers, one
  *      fixed kernel sequence per batch on one HIP stream; this is what resquiggle_read /
- *      resquiggle_batch call and what bench.py times (inputs resident in HBM).
+ *      resquiggle_batch call and what bench.py times (inputs resident in HBM).  The same
+ *      sequence can be run stage by stage with the caller's intermediates injected
+ *      (tba_batch_run_stages / tba_batch_put: the reference's public per-stage functions,
+ *      resquiggle.py:63-67), and tba_batch_base_stats adds the per-base statistics of the
+ *      Events table (tombo_helper.py:2341-2362).
  *   2. per-kernel entry points (tba_c_*): one call == one call of the Cython function it
  *      cites, same argument meaning, host pointers in / host pointers out, executed by the same
  *      device code (batch of one).  These are what a maintainer binds in place of the Cython
