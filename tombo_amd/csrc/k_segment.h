@@ -350,8 +350,8 @@ __device__ __forceinline__ bool prio_before(double sp, i64 p, double sq, i64 q)
 //            index, so that is score[p + d] >= score[p]); "this position outranks the one at
 //            -d" is the complement over valid pairs, shifted up by d
 //   T, S     taken / suppressed so far
-// The masks come from one compare + ballot per 64 positions and offset, moved into their lane
-// with v_writelane.  A round is then ~20 bit operations per offset for 4096 positions:
+// The masks come from one compare + ballot per 64 positions and offset, selected into their
+// lane.  A round is then ~20 bit operations per offset for 4096 positions:
 // taken-by-a-higher-neighbour suppresses, no-undecided-higher-neighbour takes; the neighbour
 // words cross lanes through DPP.  Decisions are only ever taken from decided neighbours, so
 // whatever is decided here is final; the first and last lane of a tile are halo (their outside
@@ -386,12 +386,10 @@ __device__ __forceinline__ W64 w_from_lane_above(W64 x, W64 lane63) // lane l <-
 }
 __device__ __forceinline__ W64 w_ballot_to_lane(W64 old, u64 m, int g) // word of lane g <- m
 {
-    u32 lo = old.lo, hi = old.hi;
-    const u32 mlo = (u32)m, mhi = (u32)(m >> 32);
-    // one SGPR operand per VALU instruction on gfx9: the lane select goes through m0
-    asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-        : "+v"(lo), "+v"(hi) : "s"(mlo), "s"(g), "s"(mhi) : "m0");
-    return {lo, hi};
+    // (v_writelane_b32 would do this in two instructions, but on gfx9 its lane select has to
+    // go through m0 next to the SGPR value -- not worth an inline-asm clobber of m0)
+    const bool mine = (int)(threadIdx.x & 63) == g;
+    return {mine ? (u32)m : old.lo, mine ? (u32)(m >> 32) : old.hi};
 }
 // Taken scores of the core positions are appended to `dense` on the way (order is irrelevant to
 // the selection that follows): one LDS counter bump per 64 positions.
