@@ -155,7 +155,7 @@ def test_forward_pass_and_traceback_kernels(read):
             p.stay_pen, nb, -15.0, True, p.max_half_z_score)
 
 
-@pytest.mark.parametrize('bw', [64, 100, 257, 500, 700, 1000, 1500, 1610, 2000, 2500, 3072])
+@pytest.mark.parametrize('bw', [64, 100, 257, 300, 320, 321, 500, 700, 1000, 1500, 1610, 2000, 2500, 3072])
 def test_row_engine_every_band_class(bw):
     """c_banded_forward_pass over random z-scores and random band offsets for every
     cells-per-lane instantiation of the wave-per-read kernel (CPL 4..48), noise-like scores with

@@ -21,8 +21,9 @@
 
 __host__ __device__ inline int cpl_class(i64 W)
 {
-    const int cls[] = {4, 8, 12, 16, 24, 32, 48};
-    for (int i = 0; i < 7; i++) if ((i64)cls[i] * 64 >= W) return cls[i];
+    // 5: Tombo's default DNA bandwidth (300) without a third of the lanes' cells idle
+    const int cls[] = {4, 5, 8, 12, 16, 24, 32, 48};
+    for (int i = 0; i < 8; i++) if ((i64)cls[i] * 64 >= W) return cls[i];
     return 0;
 }
 
@@ -112,13 +113,15 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
 
 // bytes of packed 2-bit moves per lane per row: 4 cells per byte, so a row is plainly linear
 // (cell b -> byte b/4, bits 2*(b%4)) and 16*CPL bytes long
-__host__ __device__ constexpr int mv_bpl(int cpl) { return cpl / 4; }
+__host__ __device__ constexpr int mv_bpl(int cpl) { return cpl / 4; } // (whole bytes: cpl % 4 == 0)
+// bytes of a packed row of a band class: 64 lanes x cpl cells x 2 bits
+__host__ __device__ constexpr int mv_class_rowb(int cpl) { return cpl * 16; }
 // bytes of one packed 2-bit move row of a W-cell band: the band class' row (64 lanes x cpl/4
 // bytes) or, for bands wider than every class (k_dp_wide), W rounded up to 256 cells
 __host__ __device__ inline i64 mv_row_bytes(i64 W)
 {
     const int c = cpl_class(W);
-    return c ? (i64)64 * mv_bpl(c) : ((W + 255) / 256) * 64;
+    return c ? (i64)mv_class_rowb(c) : ((W + 255) / 256) * 64;
 }
 
 // wave-uniform values the compiler cannot prove uniform (they come from vector loads or
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     const int Wi = W;
     const int half_bw = W / 2; // integer division, pyx:327
     const double NEG_INF = -INFINITY;
-    const i64 mv_stride = (i64)BPL * 64;
+    const i64 mv_stride = mv_class_rowb(CPL);
     const int b0 = lane * CPL;   // my first band cell
     int nvalid = Wi - b0;        // how many of my cells are inside the band
     nvalid = nvalid < 0 ? 0 : (nvalid > CPL ? CPL : nvalid);
@@ -501,6 +504,21 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         }
         {
             unsigned char *mrow = mv + (row + 1) * mv_stride + lane * BPL;
+            if constexpr (CPL % 4 != 0) {
+                // 5 cells = 10 bits per lane: a quad's 40 bits are 5 whole bytes, assembled by
+                // its first lane (quad_perm broadcasts) -- the row stays linear in the cell index
+                static_assert(CPL == 5, "odd class: 5 cells per lane");
+                const u32 q0 = mvw[0];
+                const u32 q1 = (u32)__builtin_amdgcn_update_dpp(0, (int)q0, 0x55, 0xf, 0xf, false); // quad_perm:[1,1,1,1]
+                const u32 q2 = (u32)__builtin_amdgcn_update_dpp(0, (int)q0, 0xaa, 0xf, 0xf, false); // [2,2,2,2]
+                const u32 q3 = (u32)__builtin_amdgcn_update_dpp(0, (int)q0, 0xff, 0xf, 0xf, false); // [3,3,3,3]
+                if ((lane & 3) == 0) {
+                    const u64 bits = (u64)q0 | ((u64)q1 << 10) | ((u64)q2 << 20) | ((u64)q3 << 30);
+                    unsigned char *p = mv + (row + 1) * mv_stride + (lane >> 2) * 5;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) p[q] = (unsigned char)(bits >> (8 * q));
+                }
+            } else
             if constexpr (BPL == 1) *mrow = (unsigned char)mvw[0];
             else if constexpr (BPL == 2) *(unsigned short *)mrow = (unsigned short)mvw[0];
             else if constexpr (BPL % 4 == 0) {
@@ -660,7 +678,8 @@ __global__ __launch_bounds__(64) void k_dp_wide(ReadState *rs, i64 n_reads, cons
 __device__ __forceinline__ int mv_get(const unsigned char *mv, i64 row, int cpl, int bpl, i64 b)
 {
     (void)cpl;
-    return (mv[row * (i64)(64 * bpl) + (b >> 2)] >> (2 * (b & 3))) & 3;
+    (void)bpl;
+    return (mv[row * (i64)mv_class_rowb(cpl) + (b >> 2)] >> (2 * (b & 3))) & 3;
 }
 
 // c_banded_traceback (pyx:281-310); python wrap-around indexing of a negative band position
@@ -838,7 +857,7 @@ __global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *ban
         hi_a[sp] = (i32)(sml + nzs);
     }
     r.path = PATH_ADAPTIVE; r.clip = clip; r.offset = offset; r.W = bw; r.n_static = msl;
-    r.moves_off = (r.B + 1) * (i64)mv_bpl(cpl_class(bw)) * 64;
+    r.moves_off = (r.B + 1) * (i64)mv_class_rowb(cpl_class(bw));
 }
 
 // exclusive scan of per-read arena sizes (held in `field`) into arena offsets: one workgroup,

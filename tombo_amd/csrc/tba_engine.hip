@@ -221,7 +221,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     const i64 start_w = std::max(p->start_bw, p->start_save_bw);
     if (cpl_class(p->start_bw) == 0 || cpl_class(p->start_save_bw) == 0 || cpl_main == 0)
         return set_err(TBA_E_ARG, "bandwidth / start bandwidth above TBA_MAX_BAND");
-    e->start_moves_stride = (p->start_n_bases + 1) * 64 * (i64)mv_bpl(cpl_class(start_w));
+    e->start_moves_stride = (p->start_n_bases + 1) * (i64)mv_class_rowb(cpl_class(start_w));
     e->moves_arena = moves_need + moves_need / 8 + (64ll << 20);
 
     const size_t S = (size_t)std::max<i64>(e->S_tot, 1), Bt = (size_t)std::max<i64>(e->B_tot, 1),
@@ -301,6 +301,7 @@ static void launch_dp(tba_engine *e, int cpl, int mode)
 {
     switch (cpl) {
     case 4: launch_dp_t<4>(e, mode); break;
+    case 5: launch_dp_t<5>(e, mode); break;
     case 8: launch_dp_t<8>(e, mode); break;
     case 12: launch_dp_t<12>(e, mode); break;
     case 16: launch_dp_t<16>(e, mode); break;
@@ -381,7 +382,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 9 main dp
     if (ON(TBA_STAGE_ASSIGN)) {
-        const int cls[] = {4, 8, 12, 16, 24, 32, 48};
+        const int cls[] = {4, 5, 8, 12, 16, 24, 32, 48};
         for (int c : cls) launch_dp(e, c, DP_MAIN);
         if (e->wide_w) // a static band wider than every class is possible in this batch
             k_dp_wide<<<WIDE_BLOCKS, 64, 0, s>>>(rs, n, dp, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), e->d_moves.as<unsigned char>(), e->d_wide.as<double>(), e->wide_w);
@@ -652,6 +653,7 @@ static void launch_direct(tba_engine *e, int cpl, DpJob *job)
 {
     switch (cpl) {
     case 4: launch_direct_t<4>(e, job); break;
+    case 5: launch_direct_t<5>(e, job); break;
     case 8: launch_direct_t<8>(e, job); break;
     case 12: launch_direct_t<12>(e, job); break;
     case 16: launch_direct_t<16>(e, job); break;
@@ -667,7 +669,7 @@ static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i6
                          double *fwd_host, int64_t *tb_host, int64_t *starts_host, i64 starts_from)
 {
     const i64 stride = (i64)cpl * 64;            // forward rows
-    const i64 mstride = (i64)mv_bpl(cpl) * 64;   // packed 2-bit move rows
+    const i64 mstride = mv_class_rowb(cpl);      // packed 2-bit move rows
     Tmp d_fwd, d_mv, d_job;
     if (d_fwd.alloc((size_t)(n_rows + 1) * stride * 8) || d_mv.alloc((size_t)(n_rows + 1) * mstride) ||
         d_job.alloc(sizeof(DpJob)))
