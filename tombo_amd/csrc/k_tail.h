@@ -545,43 +545,9 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     }
 }
 
-// norm_out[i] = (norm[read_start + i] - shift_corr) / scale_corr (resquiggle.py:1190), or a
-// plain trim copy when sequence rescaling is skipped.  grid: (blocks, reads)
-__global__ __launch_bounds__(256) void k_rescale(const ReadState *rs, const DevParams *dp,
-    const double *norm, double *norm_out)
-{
-    const ReadState &r = rs[blockIdx.y];
-    if (r.status != TBA_OK) return;
-    const double *x = norm + r.raw_off + r.read_start;
-    double *y = norm_out + r.raw_off;
-    const bool skip = dp->o.skip_seq_scaling != 0;
-    const double a = r.ts[2], b = r.ts[3];
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.norm_len; i += (i64)gridDim.x * 256)
-        y[i] = skip ? x[i] : (x[i] - a) / b;
-}
-
-// c_new_means over the final signal (already trimmed: offset 0) -> |z| per base
-// grid: (blocks, reads)
-__global__ __launch_bounds__(256) void k_final_absz(const ReadState *rs, const double *norm_out,
-    const i64 *segs, const double *ref_means, const double *ref_sds, double *absz)
-{
-    const ReadState &r = rs[blockIdx.y];
-    if (r.status != TBA_OK) return;
-    const double *x = norm_out + r.raw_off;
-    const i64 *sg = segs + r.seg_off;
-    constexpr int CAP = 768; // 64 bases of ~9 samples
-    __shared__ double s_seg[4 * CAP];
-    const int wave = threadIdx.x >> 6;
-    wave_segment_sums<CAP>(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
-                      [&](i64 i, double s, i64 len) {
-                          const double m = s / (double)len;
-                          absz[r.ref_off + i] = fabs((m - ref_means[r.ref_off + i]) / ref_sds[r.ref_off + i]);
-                      });
-}
-
 // c_new_mean_stds (_c_helper.pyx:38-57) over the final signal and boundaries of every read of
 // the batch: what write_new_fast5_group (tombo_helper.py:2341-2362) stores per base as
-// norm_mean / norm_stdev.  Same wave-cooperative staging as k_final_absz; the variance loop runs
+// norm_mean / norm_stdev.  Same wave-cooperative staging as k_rescale_absz; the variance loop runs
 // over the staged samples again (population sd around the segment mean).  grid: (blocks, reads)
 __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const double *norm_out,
     const i64 *segs, double *means, double *stds)
@@ -628,8 +594,10 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const d
     }
 }
 
-// k_rescale + k_final_absz in one pass over the signal: a wavefront takes a group of consecutive
-// bases, rescales the samples they span (coalesced read of norm, coalesced write of norm_out),
+// norm_out[i] = (norm[read_start + i] - shift_corr) / scale_corr (resquiggle.py:1190; a plain
+// trim copy when sequence rescaling is skipped) and, in the same pass, c_new_means over the
+// final signal -> |z| per base (ts.get_read_seg_score, tombo_stats.py:2327-2338): a wavefront
+// takes a group of consecutive bases, rescales the samples they span (coalesced read of norm, coalesced write of norm_out),
 // keeps them in its LDS slice and sums every base from there.  The bases tile the trimmed
 // signal exactly (segs[0] = 0, segs[B] = norm_len), so every sample is written once.
 // grid: (blocks, reads)
