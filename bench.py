@@ -176,8 +176,11 @@ def main():
         dt = float(t.item())
     out = eng.download(want_norm=False)
     if os.environ.get('TBA_DBG_PHASES'):
+        # profiling aid: per-read debug counters of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS build
+        # (TBA_EXTRA_HIPCC_FLAGS, see tombo_amd/_native.py), to stderr
         d = eng.get(99)
-        print("dbg mean", " ".join("%.1f" % x for x in d.mean(axis=0)), file=sys.stderr); print("phase cycles median", ' '.join(str(int(x)) for x in np.median(d, axis=0)), file=sys.stderr)
+        print('dbg mean', ' '.join('%.1f' % x for x in d.mean(axis=0)), file=sys.stderr)
+        print('dbg median', ' '.join(str(int(x)) for x in np.median(d, axis=0)), file=sys.stderr)
     n_ok = int((out['status'] == 0).sum())
     stage /= max(a.steps, 1)
 
