@@ -55,6 +55,7 @@ struct tba_engine {
     hipEvent_t ev[N_STAGE + 1] = {};
     float stage_ms[32] = {};
     bool have_model = false, have_batch = false, ran = false;
+    bool finished = false; // the last stage (rescale + score) has run on the uploaded batch
     DevParams hp;
     i64 n_reads = 0, S_tot = 0, seq_tot = 0, B_tot = 0, E_tot = 0, max_raw = 0, max_B = 0;
     i64 start_moves_stride = 0, moves_arena = 0, skip_arena = 0, wide_w = 0;
@@ -150,6 +151,7 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     HIP_TRY(hipSetDevice(e->device));
     e->have_batch = false;
     e->ran = false;
+    e->finished = false;
     e->hp.p = *p;
     e->hp.o = *o;
     e->hp.fill_masked = (MASK_FILL_Z_SCORE - p->z_shift) + p->z_shift;
@@ -413,6 +415,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
 #undef ON
     HIP_TRY(hipGetLastError());
     e->ran = true;
+    e->finished = last == TBA_STAGE_RESCALE;
     return 0;
 }
 
@@ -603,7 +606,7 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
 
 extern "C" int tba_batch_base_stats(tba_engine *e, double *means, double *stds, int64_t n_values)
 {
-    if (!e || !e->have_batch || !e->ran) return set_err(TBA_E_STATE, "no finished batch");
+    if (!e || !e->have_batch || !e->finished) return set_err(TBA_E_STATE, "no finished batch");
     if (!means || !stds || n_values < e->B_tot) return set_err(TBA_E_ARG, "output buffers too small");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
