@@ -264,6 +264,18 @@ int tba_c_base_traceback(tba_engine *e, const double *curr_b_data, int64_t curr_
     int64_t curr_start, const double *next_b_data, int64_t next_len, int64_t next_start,
     int64_t next_end, int64_t sig_start, int64_t min_obs_per_base, int64_t *sig_pos);
 
+/* ---- row N4: per-position log-likelihood ratios of the model-comparison statistics ---------
+ * c_calc_llh_ratio (kind 0), c_calc_llh_ratio_const_var (1), c_calc_scaled_llh_ratio_const_var (2)
+ * (_c_helper.pyx:277-358) for n_windows windows of `width` values starting at starts[i] of the
+ * per-base arrays (n_values entries each), the slicing of tombo_stats.py:4042-4074.  kind 1 / 2
+ * take the constant variance from ref_vars[starts[i]] and ignore alt_vars (may be NULL);
+ * kind 2: par = {scale_factor, density_height_factor, density_height_power}.  One call with
+ * one window == one call of the Cython function.  Transcendental functions are the device
+ * library's: results match the reference to ~1e-13 relative, kind 1 bit for bit. */
+int tba_llh_ratio_windows(tba_engine *e, int kind, const double *means, const double *ref_means,
+    const double *alt_means, const double *ref_vars, const double *alt_vars, int64_t n_values,
+    int64_t width, const int64_t *starts, int64_t n_windows, const double *par, double *out);
+
 /* self-test: out[i] = the row-constant division used inside the DP kernel (reciprocal + two
  * residual corrections) for a[i] / b[i]; must equal the IEEE quotient bit for bit */
 int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,

@@ -287,3 +287,25 @@ def base_traceback(curr_b_data, curr_start, next_b_data, next_start, next_end, s
     lib().orc_base_traceback.restype = C.c_int64
     return int(lib().orc_base_traceback(_p(cur), i64(curr_start), _p(nxt), i64(next_start),
                                         i64(next_end), i64(sig_start), i64(min_obs_per_base)))
+
+
+def calc_llh_ratio(means, ref_means, alt_means, ref_vars, alt_vars):
+    a = [_c(x, np.float64) for x in (means, ref_means, alt_means, ref_vars, alt_vars)]
+    lib().orc_calc_llh_ratio.restype = C.c_double
+    return float(lib().orc_calc_llh_ratio(*[_p(x) for x in a], i64(a[0].shape[0])))
+
+
+def calc_llh_ratio_const_var(means, ref_means, alt_means, const_var):
+    a = [_c(x, np.float64) for x in (means, ref_means, alt_means)]
+    lib().orc_calc_llh_ratio_const_var.restype = C.c_double
+    return float(lib().orc_calc_llh_ratio_const_var(*[_p(x) for x in a], i64(a[0].shape[0]),
+                                                    f64(const_var)))
+
+
+def calc_scaled_llh_ratio_const_var(means, ref_means, alt_means, const_var, scale_factor,
+                                    density_height_factor, density_height_power):
+    a = [_c(x, np.float64) for x in (means, ref_means, alt_means)]
+    lib().orc_calc_scaled_llh_ratio_const_var.restype = C.c_double
+    return float(lib().orc_calc_scaled_llh_ratio_const_var(
+        *[_p(x) for x in a], i64(a[0].shape[0]), f64(const_var), f64(scale_factor),
+        f64(density_height_factor), f64(density_height_power)))

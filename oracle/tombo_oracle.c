@@ -273,6 +273,58 @@ void orc_compute_slopes(const double *ev, const double *model, i64 n, double max
                                          : (model[i] - model[j]) / (ev[i] - ev[j]);
 }
 
+/* c_calc_llh_ratio, _c_helper.pyx:277-296 */
+double orc_calc_llh_ratio(const double *means, const double *ref_means, const double *alt_means,
+                          const double *ref_vars, const double *alt_vars, i64 n)
+{
+    double ref_z_sum = 0.0, ref_log_var_sum = 0.0, alt_z_sum = 0.0, alt_log_var_sum = 0.0;
+    for (i64 i = 0; i < n; i++) {
+        double ref_diff = means[i] - ref_means[i];
+        ref_z_sum += (ref_diff * ref_diff) / ref_vars[i];
+        ref_log_var_sum += log(ref_vars[i]);
+        double alt_diff = means[i] - alt_means[i];
+        alt_z_sum += (alt_diff * alt_diff) / alt_vars[i];
+        alt_log_var_sum += log(alt_vars[i]);
+    }
+    return alt_z_sum + alt_log_var_sum - ref_z_sum - ref_log_var_sum;
+}
+
+/* c_calc_llh_ratio_const_var, _c_helper.pyx:298-311 */
+double orc_calc_llh_ratio_const_var(const double *means, const double *ref_means,
+                                    const double *alt_means, i64 n, double const_var)
+{
+    double run = 0.0;
+    for (i64 i = 0; i < n; i++) {
+        double obs = means[i];
+        double ref_diff = obs - ref_means[i];
+        double alt_diff = obs - alt_means[i];
+        run += ((alt_diff * alt_diff) - (ref_diff * ref_diff)) / const_var;
+    }
+    return run;
+}
+
+/* c_calc_scaled_llh_ratio_const_var, _c_helper.pyx:313-358 */
+double orc_calc_scaled_llh_ratio_const_var(const double *means, const double *ref_means,
+    const double *alt_means, i64 n, double const_var, double scale_factor,
+    double density_height_factor, double density_height_power)
+{
+    double run = 0.0;
+    for (i64 i = 0; i < n; i++) {
+        double ref_mean = ref_means[i], alt_mean = alt_means[i];
+        if (ref_mean == alt_mean) continue;
+        double obs = means[i];
+        double scale_mean = (alt_mean + ref_mean) / 2;
+        double ref_diff = obs - ref_mean, alt_diff = obs - alt_mean;
+        double scale_diff = obs - scale_mean;
+        double means_diff = alt_mean - ref_mean;
+        if (means_diff < 0) means_diff = means_diff * -1;
+        run += exp(-(scale_diff * scale_diff) / (scale_factor * const_var)) *
+               ((alt_diff * alt_diff) - (ref_diff * ref_diff)) /
+               (const_var * pow(means_diff, density_height_power) * density_height_factor);
+    }
+    return run;
+}
+
 /* ------------------------------------------------------- _c_dynamic_programming.pyx ------ */
 
 /* c_base_z_scores, _c_dynamic_programming.pyx:17-32 (negative half z-score) */

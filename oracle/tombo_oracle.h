@@ -123,6 +123,13 @@ int orc_base_forward_pass(const double *b_data, i64 b_start, i64 b_end, const do
     const i64 *prev_b_last_diag, i64 min_obs_per_base, double *b_fwd_data, i64 *b_last_diag);
 i64 orc_base_traceback(const double *curr_b_data, i64 curr_start, const double *next_b_data,
     i64 next_start, i64 next_end, i64 sig_start, i64 min_obs_per_base);
+double orc_calc_llh_ratio(const double *means, const double *ref_means, const double *alt_means,
+    const double *ref_vars, const double *alt_vars, i64 n);
+double orc_calc_llh_ratio_const_var(const double *means, const double *ref_means,
+    const double *alt_means, i64 n, double const_var);
+double orc_calc_scaled_llh_ratio_const_var(const double *means, const double *ref_means,
+    const double *alt_means, i64 n, double const_var, double scale_factor,
+    double density_height_factor, double density_height_power);
 double orc_median(const double *x, i64 n);
 double orc_np_sum(const double *a, i64 n);
 void orc_linspace(double start, double stop, i64 num, double *out);

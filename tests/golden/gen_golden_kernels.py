@@ -4,7 +4,8 @@ compiled Cython functions (build container only):
     python tests/golden/gen_golden_kernels.py      # writes tests/golden/kernels_tail.npz
 
 c_reg_z_scores, c_base_forward_pass, c_base_traceback (_c_dynamic_programming.pyx:34-182),
-c_compute_slopes, c_new_mean_stds (_c_helper.pyx:362-377, 38-57) are called on seeded inputs;
+c_compute_slopes, c_new_mean_stds (_c_helper.pyx:362-377, 38-57) and the three log-likelihood
+ratio kernels (_c_helper.pyx:277-358) are called on seeded inputs;
 inputs and outputs are stored as data (ragged lists as concatenation + offsets).
 """
 import os
@@ -100,6 +101,27 @@ segs = np.concatenate([[0], np.sort(rng.choice(np.arange(1, 5000), 300, replace=
 segs = segs.astype(np.int64)
 m, s = th.c_new_mean_stds(sig, segs)
 out['ms_sig'], out['ms_segs'], out['ms_means'], out['ms_stds'] = sig, segs, m, s
+
+# c_calc_llh_ratio, c_calc_llh_ratio_const_var, c_calc_scaled_llh_ratio_const_var
+# (_c_helper.pyx:277-358): per-position log-likelihood ratio tests of the model-comparison
+# statistics (tombo_stats.py:4059-4074), regions of one k-mer width; OCLLHR_* as in
+# _default_parameters.py:132-134
+rng = np.random.default_rng(31)
+n_reg, kw = 400, 6
+L = n_reg + kw - 1
+lm, lr, la = rng.normal(0, 1, L), rng.normal(0, 1, L), rng.normal(0, 1, L)
+la[50:60] = lr[50:60]                      # equal reference / alternative levels are skipped
+lrv, lav = rng.uniform(0.01, 0.3, L), rng.uniform(0.01, 0.3, L)
+out['llh_means'], out['llh_ref_means'], out['llh_alt_means'] = lm, lr, la
+out['llh_ref_vars'], out['llh_alt_vars'] = lrv, lav
+out['llh_kw'] = np.array([kw], np.int64)
+out['llh_scaled_params'] = np.array([4.0, 1.0, 0.2])
+out['llh_var'] = np.array([ts.c_calc_llh_ratio(lm[i:i + kw], lr[i:i + kw], la[i:i + kw],
+                                               lrv[i:i + kw], lav[i:i + kw]) for i in range(n_reg)])
+out['llh_const'] = np.array([ts.c_calc_llh_ratio_const_var(lm[i:i + kw], lr[i:i + kw], la[i:i + kw],
+                                                           lrv[i]) for i in range(n_reg)])
+out['llh_scaled'] = np.array([ts.c_calc_scaled_llh_ratio_const_var(
+    lm[i:i + kw], lr[i:i + kw], la[i:i + kw], lrv[i], 4.0, 1.0, 0.2) for i in range(n_reg)])
 
 np.savez_compressed(os.path.join(HERE, 'kernels_tail.npz'), **out)
 print('wrote kernels_tail.npz: %d arrays, %.1f KB' % (

@@ -326,3 +326,32 @@ def test_approximate_quotient_stays_inside_its_guard_band():
     exact = a / b
     rel = np.abs(out - exact) / np.maximum(np.abs(exact), 1e-300)
     assert rel.max() < 1e-9, rel.max()
+
+
+def test_llh_ratio_kernels_match_reference_vectors():
+    """row N4: the model-comparison log-likelihood ratio kernels against vectors recorded from the
+    reference's compiled functions; the constant-variance form has no transcendental and is bit
+    equal, the others use the device log / exp / pow (tolerance 1e-12 relative)"""
+    from tombo_amd import _c_helper as ch
+    g = _kt()
+    kw = int(g['llh_kw'][0])
+    m, r, a = g['llh_means'], g['llh_ref_means'], g['llh_alt_means']
+    rv, av = g['llh_ref_vars'], g['llh_alt_vars']
+    sf, hf, hp = (float(x) for x in g['llh_scaled_params'])
+    n = g['llh_var'].shape[0]
+    starts = np.arange(n, dtype=np.int64)
+    got_var = ch.llh_ratio_windows(0, m, r, a, rv, starts, kw, alt_vars=av)
+    got_const = ch.llh_ratio_windows(1, m, r, a, rv, starts, kw)
+    got_scaled = ch.llh_ratio_windows(2, m, r, a, rv, starts, kw, scale_factor=sf,
+                                      density_height_factor=hf, density_height_power=hp)
+    np.testing.assert_array_equal(got_const, g['llh_const'])
+    np.testing.assert_allclose(got_var, g['llh_var'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got_scaled, g['llh_scaled'], rtol=1e-12, atol=1e-13)
+    # one window per call == the Cython signatures
+    for i in (0, 7, 55, n - 1):
+        sl = slice(i, i + kw)
+        assert ch.c_calc_llh_ratio_const_var(m[sl], r[sl], a[sl], rv[i]) == g['llh_const'][i]
+        assert abs(ch.c_calc_llh_ratio(m[sl], r[sl], a[sl], rv[sl], av[sl]) - g['llh_var'][i]) \
+            <= 1e-12 * max(1.0, abs(g['llh_var'][i]))
+        assert abs(ch.c_calc_scaled_llh_ratio_const_var(m[sl], r[sl], a[sl], rv[i], sf, hf, hp)
+                   - g['llh_scaled'][i]) <= 1e-12 * max(1.0, abs(g['llh_scaled'][i]))

@@ -69,3 +69,18 @@ def test_slopes_and_mean_stds(kt):
     m, s = oracle.new_mean_stds(kt['ms_sig'], kt['ms_segs'])
     np.testing.assert_array_equal(m, kt['ms_means'])
     np.testing.assert_array_equal(s, kt['ms_stds'])
+
+
+def test_llh_ratio_kernels(kt):
+    """row N4: the per-position log-likelihood ratio kernels (_c_helper.pyx:277-358)"""
+    import oracle
+    kw = int(kt['llh_kw'][0])
+    m, r, a = kt['llh_means'], kt['llh_ref_means'], kt['llh_alt_means']
+    rv, av = kt['llh_ref_vars'], kt['llh_alt_vars']
+    sf, hf, hp = (float(x) for x in kt['llh_scaled_params'])
+    for i in range(kt['llh_var'].shape[0]):
+        sl = slice(i, i + kw)
+        assert oracle.calc_llh_ratio(m[sl], r[sl], a[sl], rv[sl], av[sl]) == kt['llh_var'][i]
+        assert oracle.calc_llh_ratio_const_var(m[sl], r[sl], a[sl], rv[i]) == kt['llh_const'][i]
+        assert oracle.calc_scaled_llh_ratio_const_var(m[sl], r[sl], a[sl], rv[i], sf, hf, hp) == \
+            kt['llh_scaled'][i]

@@ -9,6 +9,8 @@ the per-kernel C ABI (tba_c_*):
   c_valid_cpts_w_cap_t_test  :144-202
   c_new_mean_stds            :38-57
   c_compute_slopes           :362-377
+  c_calc_llh_ratio, c_calc_llh_ratio_const_var, c_calc_scaled_llh_ratio_const_var  :277-358
+                             (row N4: plus llh_ratio_windows, many windows per call)
 """
 import ctypes as C
 
@@ -81,3 +83,45 @@ def c_compute_slopes(r_event_means, r_model_means, max_slope=1000.0):
         eng._h, ev.ctypes.data_as(_pd), md.ctypes.data_as(_pd), C.c_int64(n),
         C.c_double(max_slope), out.ctypes.data_as(_pd)), eng)
     return out
+
+
+def llh_ratio_windows(kind, means, ref_means, alt_means, ref_vars, starts, width, alt_vars=None,
+                      scale_factor=None, density_height_factor=None, density_height_power=None):
+    """Log-likelihood ratios of many k-mer-width windows in one call (kind 0: per-base variances,
+    1: constant variance ref_vars[start], 2: the scaled form) -- the loop body of
+    tombo_stats.py:4042-4074 over all tested positions of a read."""
+    m, r, a, rv = (_f8(x, n) for x, n in ((means, 'reg_means'), (ref_means, 'reg_ref_means'),
+                                          (alt_means, 'reg_alt_means'), (ref_vars, 'reg_ref_vars')))
+    av = None if alt_vars is None else _f8(alt_vars, 'reg_alt_vars')
+    st = _i8(np.asarray(starts, dtype=np.int64), 'starts')
+    out = np.empty(st.shape[0], dtype=np.float64)
+    par = (C.c_double * 3)(scale_factor or 0.0, density_height_factor or 0.0,
+                           density_height_power or 0.0)
+    eng = _engine()
+    _raise(eng._L.tba_llh_ratio_windows(
+        eng._h, C.c_int(kind), m.ctypes.data_as(_pd), r.ctypes.data_as(_pd), a.ctypes.data_as(_pd),
+        rv.ctypes.data_as(_pd), None if av is None else av.ctypes.data_as(_pd),
+        C.c_int64(m.shape[0]), C.c_int64(int(width)), st.ctypes.data_as(_pi),
+        C.c_int64(st.shape[0]), par, out.ctypes.data_as(_pd)), eng)
+    return out
+
+
+def c_calc_llh_ratio(reg_means, reg_ref_means, reg_alt_means, reg_ref_vars, reg_alt_vars):
+    return float(llh_ratio_windows(0, reg_means, reg_ref_means, reg_alt_means, reg_ref_vars, [0],
+                                   len(reg_means), alt_vars=reg_alt_vars)[0])
+
+
+def c_calc_llh_ratio_const_var(reg_means, reg_ref_means, reg_alt_means, const_var):
+    n = len(reg_means)
+    return float(llh_ratio_windows(1, reg_means, reg_ref_means, reg_alt_means,
+                                   np.full(max(n, 1), float(const_var)), [0], n)[0])
+
+
+def c_calc_scaled_llh_ratio_const_var(reg_means, reg_ref_means, reg_alt_means, const_var,
+                                      scale_factor, density_height_factor, density_height_power):
+    n = len(reg_means)
+    return float(llh_ratio_windows(2, reg_means, reg_ref_means, reg_alt_means,
+                                   np.full(max(n, 1), float(const_var)), [0], n,
+                                   scale_factor=scale_factor,
+                                   density_height_factor=density_height_factor,
+                                   density_height_power=density_height_power)[0])

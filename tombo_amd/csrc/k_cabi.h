@@ -219,3 +219,54 @@ __global__ void k_c_base_traceback(const double *curr, i64 curr_len, i64 curr_st
         if (next[ni] > curr[ci]) { *out = sp; return; }
     }
 }
+
+// Row N4: the per-position log-likelihood ratio kernels of the model-comparison
+// statistics, c_calc_llh_ratio / c_calc_llh_ratio_const_var / c_calc_scaled_llh_ratio_const_var
+// (_c_helper.pyx:277-358), over many windows at once: window i covers width values from
+// starts[i] of the per-base arrays, as tombo_stats.py:4042-4074 slices them; one thread per
+// window, terms accumulated in index order like the reference.  kind 0: per-base variances;
+// 1: constant variance ref_vars[starts[i]]; 2: the scaled form (par = scale, height, power).
+// log / exp / pow are the device library's (not glibc's): parity is a stated tolerance here.
+__global__ void k_c_llh_windows(int kind, const double *means, const double *ref_means,
+    const double *alt_means, const double *ref_vars, const double *alt_vars, i64 width,
+    const i64 *starts, i64 n_windows, double par0, double par1, double par2, double *out)
+{
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < n_windows; w += (i64)gridDim.x * blockDim.x) {
+        const i64 s = starts[w];
+        if (kind == 0) {
+            double ref_z = 0.0, ref_lv = 0.0, alt_z = 0.0, alt_lv = 0.0;
+            for (i64 i = s; i < s + width; i++) {
+                const double rd = means[i] - ref_means[i];
+                ref_z += (rd * rd) / ref_vars[i];
+                ref_lv += log(ref_vars[i]);
+                const double ad = means[i] - alt_means[i];
+                alt_z += (ad * ad) / alt_vars[i];
+                alt_lv += log(alt_vars[i]);
+            }
+            out[w] = alt_z + alt_lv - ref_z - ref_lv;
+        } else if (kind == 1) {
+            const double cv = ref_vars[s];
+            double run = 0.0;
+            for (i64 i = s; i < s + width; i++) {
+                const double obs = means[i], rd = obs - ref_means[i], ad = obs - alt_means[i];
+                run += ((ad * ad) - (rd * rd)) / cv;
+            }
+            out[w] = run;
+        } else {
+            const double cv = ref_vars[s];
+            double run = 0.0;
+            for (i64 i = s; i < s + width; i++) {
+                const double rm = ref_means[i], am = alt_means[i];
+                if (rm == am) continue;
+                const double obs = means[i];
+                const double sm = (am + rm) / 2;
+                const double rd = obs - rm, ad = obs - am, sd = obs - sm;
+                double md = am - rm;
+                if (md < 0) md = md * -1;
+                run += exp(-(sd * sd) / (par0 * cv)) * ((ad * ad) - (rd * rd)) / (cv * pow(md, par2) * par1);
+            }
+            out[w] = run;
+        }
+    }
+}
+

@@ -1059,6 +1059,41 @@ extern "C" int tba_c_base_traceback(tba_engine *e, const double *curr_b_data, in
     return TBA_OK;
 }
 
+extern "C" int tba_llh_ratio_windows(tba_engine *e, int kind, const double *means,
+    const double *ref_means, const double *alt_means, const double *ref_vars,
+    const double *alt_vars, int64_t n_values, int64_t width, const int64_t *starts,
+    int64_t n_windows, const double *par, double *out)
+{
+    if (!e || !means || !ref_means || !alt_means || !ref_vars || !starts || !out || kind < 0 ||
+        kind > 2 || (kind == 0 && !alt_vars) || (kind == 2 && !par) || n_values < 0 || width < 0 ||
+        n_windows < 0)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (n_windows == 0) return TBA_OK;
+    for (i64 i = 0; i < n_windows; i++)
+        if (starts[i] < 0 || starts[i] + width > n_values || (kind != 0 && starts[i] >= n_values))
+            return set_err(TBA_E_ARG, "window outside the arrays");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t nb = (size_t)n_values * 8;
+    Tmp d_m, d_r, d_a, d_rv, d_av, d_s, d_o;
+    if (d_m.alloc(nb) || d_r.alloc(nb) || d_a.alloc(nb) || d_rv.alloc(nb) || d_av.alloc(nb) ||
+        d_s.alloc((size_t)n_windows * 8) || d_o.alloc((size_t)n_windows * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_m.p, means, nb, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_r.p, ref_means, nb, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_a.p, alt_means, nb, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_rv.p, ref_vars, nb, hipMemcpyHostToDevice));
+    if (alt_vars) C_TRY(hipMemcpy(d_av.p, alt_vars, nb, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_s.p, starts, (size_t)n_windows * 8, hipMemcpyHostToDevice));
+    k_c_llh_windows<<<grid_for(n_windows), 256, 0, e->stream>>>(kind, d_m.as<double>(),
+        d_r.as<double>(), d_a.as<double>(), d_rv.as<double>(), d_av.as<double>(), width,
+        d_s.as<i64>(), n_windows, par ? par[0] : 0.0, par ? par[1] : 0.0, par ? par[2] : 0.0,
+        d_o.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(out, d_o.p, (size_t)n_windows * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
 extern "C" int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,
                                      double *out)
 {
