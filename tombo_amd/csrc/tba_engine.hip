@@ -148,6 +148,17 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     if (p->bandwidth < 2 || p->running_stat_width < 1 || p->min_obs_per_base < 1 ||
         p->raw_min_obs_per_base < 1 || p->mean_obs_per_event < 1 || p->start_n_bases < 1)
         return set_err(TBA_E_ARG, "bad resquiggle parameters");
+    // CSR offsets: start at 0, never decrease (a foreign caller's mistake must not become an
+    // out-of-bounds device access)
+    if (raw_off[0] != 0 || seq_off[0] != 0) return set_err(TBA_E_ARG, "offset arrays must start at 0");
+    for (i64 i = 0; i < n_reads; i++)
+        if (raw_off[i + 1] < raw_off[i] || seq_off[i + 1] < seq_off[i])
+            return set_err(TBA_E_ARG, "offset arrays must be non-decreasing");
+    if (stall_ints && stall_off) {
+        if (stall_off[0] != 0) return set_err(TBA_E_ARG, "offset arrays must start at 0");
+        for (i64 i = 0; i < n_reads; i++)
+            if (stall_off[i + 1] < stall_off[i]) return set_err(TBA_E_ARG, "offset arrays must be non-decreasing");
+    }
     HIP_TRY(hipSetDevice(e->device));
     e->have_batch = false;
     e->ran = false;
