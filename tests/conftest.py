@@ -23,9 +23,10 @@ def sha(a):
 
 
 def golden_names():
-    # read-level cases; kernels_*.npz hold stand-alone kernel vectors (test_oracle_kernels_golden)
+    # read-level cases; kernels_*.npz hold stand-alone kernel vectors (test_oracle_kernels_golden),
+    # dacq_*.npz the reference's runs on DAC-quantised reads (test_dac_quantised)
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))
-                  if not os.path.basename(f).startswith('kernels_'))
+                  if not os.path.basename(f).startswith(('kernels_', 'dacq_', 'stats_')))
 
 
 class GoldenCase(object):

@@ -1,0 +1,143 @@
+"""Parity on int16-DAC-quantised input (the reference's production input, resquiggle.py:1397).
+
+On quantised signal 79-94 % of the change-point scores of c_valid_cpts_w_cap tie exactly and the
+reference ranks them with an unstable `np.argsort` (_c_helper.pyx:95-98) whose tie order depends
+on numpy's CPU dispatch: tests/golden/gen_golden_dac.py recorded the live reference under the
+AVX512, AVX2 and scalar sorts and the three runs differ from each other (DNA: 0.1-0.3 % of the
+boundaries, shifts up to 19 samples).  There is no single reference answer to be bit-equal to, so
+the bar here is: (1) the oracle and the engine, which share one fixed tie rule (score descending,
+index descending), agree with each other bit for bit; (2) their distance to every recorded run is
+no larger than the distance between the reference's own runs (identity rate of the absolute
+boundaries, largest shift); (3) wherever the reference's runs agree with each other exactly
+(RNA: t-test scores do not tie) the result is bit-equal to them.
+"""
+import os
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+CASES = ['dacq_dna_b2000_w100', 'dacq_dna_b10000_w500', 'dacq_rna_b3000_w500']
+
+
+def to_dac(raw):
+    return np.round(raw / 0.1709 + 10.0).astype(np.int16)
+
+
+def load_case(name):
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    g = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    m = json.loads(str(g['meta']))
+    samp = th.seqSampleType(m['samp_name'], False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    if m.get('bandwidth'):
+        params = params._replace(bandwidth=m['bandwidth'])
+    if m.get('band_bound_thresh'):
+        params = params._replace(band_bound_thresh=m['band_bound_thresh'])
+    kw = dict(synth.DNA_SYNTH if m['samp_name'] == 'DNA' else synth.RNA_SYNTH)
+    reads = []
+    for seed in m['seeds']:
+        seq, raw, _ = synth.synth_read(model, m['n_bases'], seed, **kw)
+        dac = to_dac(raw)
+        stalls = None
+        if m['samp_name'] == 'RNA':
+            stalls = ts.identify_stalls(dac.astype(np.float64))
+            want = g['avx512__s%d_stall_ints' % seed]
+            got = np.array([[int(a), int(b)] for a, b in stalls]).reshape(-1, 2)
+            assert np.array_equal(got, want)
+        st = np.random.get_state()
+        np.random.seed(seed)
+        si = np.random.choice(m['n_bases'], 1000, replace=False) if m['n_bases'] > 1000 else None
+        np.random.set_state(st)
+        reads.append(dict(seed=seed, seq=seq, dac=dac, stalls=stalls, samp_ind=si))
+    return g, m, samp, model, params, reads
+
+
+def distance(a_abs, b_abs):
+    """(fraction of identical absolute boundaries, largest shift)"""
+    assert a_abs.shape == b_abs.shape
+    return float((a_abs == b_abs).mean()), int(np.abs(a_abs - b_abs).max())
+
+
+def check_against_runs(g, m, seed, mine_abs, mine_cpts):
+    runs = {d: g['%s__s%d_segs' % (d, seed)].astype(np.int64) +
+            int(g['%s__s%d_read_start' % (d, seed)]) for d in m['dispatch']}
+    # the reference against itself
+    ref_ident, ref_shift = 1.0, 0
+    names = list(runs)
+    for i in range(len(names)):
+        for j in range(i + 1, len(names)):
+            f, s = distance(runs[names[i]], runs[names[j]])
+            ref_ident, ref_shift = min(ref_ident, f), max(ref_shift, s)
+    rep = []
+    for d in names:
+        f, s = distance(mine_abs, runs[d])
+        c = float(np.isin(mine_cpts, g['%s__s%d_valid_cpts' % (d, seed)]).mean())
+        rep.append((d, f, s, c))
+        if ref_ident == 1.0:
+            assert f == 1.0 and s == 0, (d, f, s)  # the reference is self-consistent: bit-equal
+        else:
+            # inside the reference's own envelope (slack: one more differing tie neighbourhood)
+            assert f >= 1.0 - 2.0 * (1.0 - ref_ident) - 2e-3, (d, f, ref_ident)
+            assert s <= 2 * ref_shift + 8, (d, s, ref_shift)
+            assert c >= 0.995, (d, c)
+    return ref_ident, ref_shift, rep
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_oracle_within_reference_envelope_on_dac_input(name):
+    import oracle
+    from tombo_amd import tombo_stats as ts
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    g, m, samp, model, params, reads = load_case(name)
+    p = oracle.make_params(params)
+    o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
+                         sig_match_thresh=SIG_MATCH_THRESH[m['samp_name']])
+    for rd in reads:
+        r = oracle.resquiggle_read(rd['dac'].astype(np.float64), ts.encode_seq(rd['seq']),
+                                   model.level_means, model.level_sds, p, o,
+                                   stall_ints=rd['stalls'], samp_ind=rd['samp_ind'], debug=True)
+        assert r['status'] == 0
+        ref_ident, ref_shift, rep = check_against_runs(
+            g, m, rd['seed'], r['segs'] + r['read_start_rel_to_raw'], r['dbg']['valid_cpts'])
+        print('%s seed %d: reference runs among themselves: identical %.4f, max shift %d; oracle vs '
+              % (name, rd['seed'], ref_ident, ref_shift) +
+              ', '.join('%s %.4f / %d' % (d, f, s) for d, f, s, _ in rep))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
+def test_engine_equals_oracle_on_dac_input(name, dtype):
+    """the int16 / float32 upload paths convert on the device (exact): same bits as the float64
+    path and as the oracle, tie-heavy scores included"""
+    import oracle
+    from tombo_amd import resquiggle as rq, tombo_stats as ts, tombo_helper as th
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    g, m, samp, model, params, reads = load_case(name)
+    p = oracle.make_params(params)
+    o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
+                         sig_match_thresh=SIG_MATCH_THRESH[m['samp_name']])
+    conv = {'i16': lambda d: d, 'f32': lambda d: d.astype(np.float32),
+            'f64': lambda d: d.astype(np.float64)}[dtype]
+    mrs = [th.resquiggleResults(
+        align_info=th.alignInfo('r', 'BaseCalled_template', 0, 0, 0, 0, m['n_bases'], 0),
+        genome_loc=th.genomeLocation(0, '+', 'synth'), genome_seq=rd['seq'], mean_q_score=10.0,
+        raw_signal=conv(rd['dac']), stall_ints=rd['stalls']) for rd in reads]
+    res = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp,
+                              samp_inds=[rd['samp_ind'] for rd in reads])
+    for rd, r in zip(reads, res):
+        assert not isinstance(r, Exception), r
+        want = oracle.resquiggle_read(rd['dac'].astype(np.float64), ts.encode_seq(rd['seq']),
+                                      model.level_means, model.level_sds, p, o,
+                                      stall_ints=rd['stalls'], samp_ind=rd['samp_ind'])
+        assert want['status'] == 0
+        np.testing.assert_array_equal(r.segs, want['segs'])
+        assert r.read_start_rel_to_raw == want['read_start_rel_to_raw']
+        np.testing.assert_array_equal(r.raw_signal, want['norm_signal'])
+        assert r.sig_match_score == want['sig_match_score']
+        assert r.scale_values.shift == want['scale_values'][0]
+        assert r.scale_values.scale == want['scale_values'][1]
