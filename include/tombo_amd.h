@@ -83,6 +83,10 @@ typedef struct {
     double  min_event_to_seq_ratio;
     int64_t use_rna_event_scale, rna_scale_num_events;    /* _default_parameters.py:78-80 */
     double  rna_scale_max_frac_events;
+    int64_t skip_norm_out; /* engine option: do not materialise the final normalised signal (the
+                              caller recomputes it from raw + scale_values, as Tombo does when it
+                              reads a resquiggled FAST5 back: tombo_helper.py get_raw_read_slot /
+                              tombo_stats.normalize_raw_signal); norm_signal downloads are refused */
 } tba_opts;
 
 typedef struct tba_engine tba_engine;
@@ -95,11 +99,28 @@ int  tba_engine_create(int device, tba_engine **out);
 void tba_engine_destroy(tba_engine *e);
 const char *tba_last_error(void);
 int  tba_device_count(void);
+/* free / total bytes of the engine's device (hipMemGetInfo): what a batch planner budgets against */
+int  tba_device_mem(tba_engine *e, int64_t *free_bytes, int64_t *total_bytes);
 
 /* canonical k-mer level table, lexicographic k-mer order (TomboModel, tombo_stats.py:580-919;
  * lookup replaces get_exp_levels_from_seq :834-862) */
 int tba_set_model(tba_engine *e, const double *kmer_means, const double *kmer_sds,
                   int64_t kmer_width, int64_t central_pos);
+
+/* ---- host memory for streaming -----------------------------------------------------------
+ * Page-locked host buffers: uploads from / downloads into them are true DMA transfers that
+ * overlap with kernels of other engines (one engine == one batch slot == one HIP stream; a
+ * streaming caller keeps 2-3 engines per GPU busy: upload N+1 || compute N || download N-1,
+ * the analogue of the reference's reader -> worker -> writer processes,
+ * resquiggle.py:1859-1950).  Pageable buffers work everywhere too, but make the "async" calls
+ * block while HIP stages them. */
+int tba_pinned_alloc(int64_t bytes, void **out);
+int tba_pinned_free(void *p);
+
+/* raw sample types accepted at the boundary: float64 (the reference's in-memory type), float32,
+ * or the int16 DAC values as the FAST5 file stores them (`Signal`, resquiggle.py:1397).  Widening
+ * to float64 happens on the device and is exact: results are bit-identical for the same values. */
+enum { TBA_RAW_F64 = 0, TBA_RAW_F32 = 1, TBA_RAW_I16 = 2 };
 
 /* ---- batch pipeline == resquiggle_read() for n_reads reads -------------------------------
  * raw_off[n+1], seq_off[n+1]: CSR offsets into raw (float64 pA / DAC values) and seq (uint8
@@ -119,11 +140,28 @@ int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_opts *o, int6
                      const double *sv_in, const int32_t *sv_flags,
                      const int64_t *samp_ind,
                      const int64_t *stall_ints, const int64_t *stall_off);
+/* Same with a typed raw buffer (TBA_RAW_*), enqueue only: every copy is issued on the engine's
+ * stream and the call returns; the caller's buffers (raw, seq, sv_in, samp_ind, stall_ints) must
+ * stay valid and unchanged until tba_batch_sync / tba_batch_query reports the engine idle.
+ * tba_batch_upload == this with TBA_RAW_F64 followed by tba_batch_sync. */
+int tba_batch_upload_async(tba_engine *e, const tba_params *p, const tba_opts *o, int64_t n_reads,
+                           const void *raw, int raw_dtype, const int64_t *raw_off,
+                           const uint8_t *seq, const int64_t *seq_off,
+                           const double *sv_in, const int32_t *sv_flags,
+                           const int64_t *samp_ind,
+                           const int64_t *stall_ints, const int64_t *stall_off);
+/* device bytes a batch of these reads would occupy (what tba_batch_upload* allocates): lets a
+ * host planner cut a read list into batches that fit a memory budget before uploading */
+int tba_batch_footprint(const tba_params *p, const tba_opts *o, int64_t kmer_width, int raw_dtype,
+                        int64_t n_reads, const int64_t *n_raw, const int64_t *seq_len,
+                        double *bytes);
 /* runs the whole kernel sequence on the uploaded batch; returns after the stream is idle */
 int tba_batch_run(tba_engine *e);
 /* same, but only enqueues (for timing with events / overlapping); pair with tba_batch_sync */
 int tba_batch_enqueue(tba_engine *e);
 int tba_batch_sync(tba_engine *e);
+/* 0: the engine's stream is idle; 1: work still in flight (never blocks) */
+int tba_batch_query(tba_engine *e);
 /* Outputs (any pointer may be NULL):
  *   status[n]; segs (CSR by seg_off[i] = seq_off[i] - i*(K-1) + i, B_i+1 entries per read);
  *   read_start_rel_to_raw[n]; norm_signal (same CSR as raw; first norm_len[i] entries valid);
@@ -132,6 +170,19 @@ int tba_batch_download(tba_engine *e, int32_t *status, int64_t *segs,
                        int64_t *read_start_rel_to_raw, double *norm_signal, int64_t *norm_len,
                        double *scale_values, double *sig_match_score,
                        int32_t *norm_params_changed);
+/* Compact per-read record + enqueue-only download: results[n] (64 bytes per read: what
+ * resquiggle_read returns besides the arrays), the base boundaries as int32 (segs32) and / or
+ * int64 (segs64), CSR by seg_off like tba_batch_download, and the normalised signal (refused
+ * under tba_opts.skip_norm_out).  The records and int32 boundaries are packed by a kernel on the
+ * engine's stream, the copies follow on the same stream; the outputs are valid after
+ * tba_batch_sync.  lower_lim / upper_lim are NaN where scale_values has None. */
+typedef struct {
+    int32_t status, norm_params_changed;
+    int64_t read_start_rel_to_raw, norm_len;
+    double shift, scale, lower_lim, upper_lim, sig_match_score;
+} tba_read_result;
+int tba_batch_download_async(tba_engine *e, tba_read_result *results, int32_t *segs32,
+                             int64_t *segs64, double *norm_signal);
 /* stage-wise intermediates of the last run, for parity tests (what: TBA_GET_*; CSR layouts in
  * tombo_amd/_native.py) */
 enum {
@@ -153,7 +204,9 @@ enum {
     TBA_GET_REF_SDS = 16,
     TBA_GET_SEGS = 17,        /* int64, CSR by seg_off: boundaries after skipped-base resolution */
     TBA_GET_STATUS = 18,      /* int32[n] */
-    TBA_GET_START_FAIL = 19   /* int32[n]: status that failed the first start-discovery try (0: none) */
+    TBA_GET_START_FAIL = 19,  /* int32[n]: status that failed the first start-discovery try (0: none) */
+    TBA_GET_DEBUG_COUNTERS = 99 /* int64[n][8]: ReadState.dbg, only filled by -DTBA_PHASE_DEBUG /
+                                   -DTBA_SWEEP_STATS profiling builds (zeros otherwise) */
 };
 int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_bytes);
 /* ---- stepwise execution (the reference's public per-stage API, resquiggle.py:63-67) ---------
@@ -199,7 +252,9 @@ int tba_batch_base_stats(tba_engine *e, double *means, double *stds, int64_t n_v
 /* bytes of algorithmic traffic / cell updates of the last uploaded batch */
 int tba_batch_stats(tba_engine *e, double *algorithmic_bytes, double *dp_cells);
 
-/* ---- per-kernel entry points (one call == one Cython call; host buffers) ----------------- */
+/* ---- per-kernel entry points (one call == one Cython call; host buffers) -----------------
+ * These are the parity surface, not the throughput path: every call allocates and frees its
+ * device temporaries (hipMalloc / hipFree) and synchronises the stream. */
 /* c_adaptive_banded_forward_pass, _c_dynamic_programming.pyx:314-412: fwd_pass[(n_bases+1)*bw],
  * fwd_pass_tb[(n_bases+1)*bw] (int64 moves) and event_starts[n_bases] are updated in place
  * from row start_seq_pos. */

@@ -173,3 +173,33 @@ def test_events_table_layout():
     assert tab['start'].tolist() == [0, 3, 7, 8, 15] and tab['length'].tolist() == [3, 4, 1, 7, 5]
     assert b''.join(tab['base']) == b'ACGTA' and tab['norm_mean'][4] == 2.0
     assert np.isnan(th.events_table(res, np.zeros(5))['norm_stdev']).all()
+
+
+def test_planner_cuts_by_memory_and_orders_by_length():
+    """host planner (no GPU needed: tba_batch_footprint is a host-only entry point)"""
+    import numpy as np
+    from tombo_amd import planner, _native, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=500)
+    p = _native.make_params(params)
+    o = _native.make_opts(outlier_thresh=5.0, skip_norm_out=True)
+    rng = np.random.default_rng(3)
+    B = np.clip(np.exp(rng.normal(np.log(8000), 0.9, 3000)), 1000, 100000).astype(np.int64)
+    S, L = B * 9 + 300, B + 5
+    budget = 8e9
+    plan = planner.plan_batches(S, L, p, o, 6, budget, np.int16)
+    assert sorted(np.concatenate(plan).tolist()) == list(range(3000))       # every read once
+    for idx in plan:
+        assert planner.exact_bytes(S[idx], L[idx], p, o, 6, np.int16) <= budget or len(idx) == 1
+        assert np.all(np.diff(B[idx]) <= 0)                                 # longest first inside
+    longest = [int(B[idx].max()) for idx in plan]
+    assert longest == sorted(longest, reverse=True)        # longest critical path first
+    assert B[plan[0]].max() == B.max()
+    # the vectorised estimate tracks the engine's own figure
+    est = planner.estimate_bytes(S, L, p, o, 6, np.int16).sum()
+    exact = planner.exact_bytes(S, L, p, o, 6, np.int16)
+    assert abs(est - exact) / exact < 0.05
+    # input order kept on request; int16 input is smaller than float64
+    plan2 = planner.plan_batches(S, L, p, o, 6, budget, np.int16, sort=False)
+    assert np.array_equal(np.concatenate(plan2), np.arange(3000))
+    assert planner.exact_bytes(S, L, p, o, 6, np.int16) < planner.exact_bytes(S, L, p, o, 6, np.float64)

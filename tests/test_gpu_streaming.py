@@ -1,0 +1,181 @@
+"""Streaming path on the GPU: typed raw input (int16 / float32 / float64), enqueue-only upload /
+download through page-locked buffers, several engine slots in flight, skip_norm_out, automatic
+sub-batching.  Every result is compared bit for bit with the plain one-batch path
+(`resquiggle_batch`, itself checked against the oracle in test_gpu_parity.py) and, for the
+compact records, with the oracle directly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_reads=23, seed0=500, dac=False):
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    rng = np.random.RandomState(seed0)
+    reads = []
+    for i in range(n_reads):
+        nb = int(rng.choice([300, 700, 1200, 1800]))
+        seq, raw, _ = synth.synth_read(model, nb, seed0 + i, **synth.DNA_SYNTH)
+        if dac:
+            raw = np.round(raw / 0.1709 + 10.0).astype(np.int16)
+        si = rng.choice(nb, 1000, replace=False).astype(np.int64) if nb > 1000 else None
+        reads.append((seq, raw, si))
+    return samp, model, params, reads
+
+
+def _map_results(reads):
+    from tombo_amd import tombo_helper as th
+    return [th.resquiggleResults(
+        align_info=th.alignInfo('r%d' % i, 'BaseCalled_template', 0, 0, 0, 0, len(s) - 5, 0),
+        genome_loc=th.genomeLocation(0, '+', 'synth'), genome_seq=s, mean_q_score=10.0,
+        raw_signal=r) for i, (s, r, _) in enumerate(reads)]
+
+
+@pytest.mark.parametrize('dac', [False, True])
+def test_stream_pipeline_equals_single_batches(dac):
+    from tombo_amd import resquiggle as rq, streaming, tombo_stats as ts
+    samp, model, params, reads = _setup(dac=dac)
+    ref = rq.resquiggle_batch(_map_results(reads), model, params, outlier_thresh=5.0,
+                              seq_samp_type=samp, samp_inds=[si for _, _, si in reads])
+    cuts = [0, 5, 6, 13, 16, 20, 23]   # ragged batches, more batches than slots
+    for want_norm, sd in ((False, np.int32), (True, np.int64)):
+        pipe = streaming.StreamPipeline(model, params, n_slots=3, outlier_thresh=5.0,
+                                        seq_samp_type=samp, want_norm=want_norm, segs_dtype=sd)
+        batches = [streaming.ReadBatch.from_lists(
+            [r for _, r, _ in reads[a:b]], [ts.encode_seq(s) for s, _, _ in reads[a:b]],
+            samp_inds=[si for _, _, si in reads[a:b]], tag=(a, b), pinned=(a % 2 == 0))
+            for a, b in zip(cuts[:-1], cuts[1:])]
+        seen = []
+        for res in pipe.run(batches):
+            a, b = res.tag
+            seen.append(res.tag)
+            assert res.n == b - a
+            for k in range(b - a):
+                want = ref[a + k]
+                rec = res.results[k]
+                if isinstance(want, Exception):
+                    assert rec['status'] != 0
+                    continue
+                assert rec['status'] == 0
+                np.testing.assert_array_equal(res.segs_of(k).astype(np.int64), want.segs)
+                assert rec['read_start_rel_to_raw'] == want.read_start_rel_to_raw
+                assert rec['sig_match_score'] == want.sig_match_score
+                assert rec['shift'] == want.scale_values.shift
+                assert rec['scale'] == want.scale_values.scale
+                assert rec['lower_lim'] == want.scale_values.lower_lim
+                assert bool(rec['norm_params_changed']) == want.norm_params_changed
+                assert rec['norm_len'] == want.raw_signal.shape[0]
+                if want_norm:
+                    np.testing.assert_array_equal(res.norm_of(k), want.raw_signal)
+        assert seen == [(a, b) for a, b in zip(cuts[:-1], cuts[1:])]   # submission order
+        pipe.close()
+
+
+def test_compact_records_equal_oracle_on_int16():
+    import oracle
+    from tombo_amd import streaming, tombo_stats as ts
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    samp, model, params, reads = _setup(n_reads=9, seed0=900, dac=True)
+    pipe = streaming.StreamPipeline(model, params, n_slots=2, outlier_thresh=5.0, seq_samp_type=samp)
+    b = streaming.ReadBatch.from_lists([r for _, r, _ in reads], [ts.encode_seq(s) for s, _, _ in reads],
+                                       samp_inds=[si for _, _, si in reads], pinned=True)
+    res = list(pipe.run([b]))[0]
+    p = oracle.make_params(params)
+    o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
+                         sig_match_thresh=SIG_MATCH_THRESH['DNA'])
+    for k, (s, r, si) in enumerate(reads):
+        want = oracle.resquiggle_read(r.astype(np.float64), ts.encode_seq(s), model.level_means,
+                                      model.level_sds, p, o, samp_ind=si)
+        assert res.results['status'][k] == want['status']
+        if want['status'] == 0:
+            np.testing.assert_array_equal(res.segs_of(k), want['segs'])
+            assert res.results['sig_match_score'][k] == want['sig_match_score']
+            assert res.results['read_start_rel_to_raw'][k] == want['read_start_rel_to_raw']
+    pipe.close()
+
+
+def test_skip_norm_out_keeps_events_table_and_refuses_norm_download():
+    from tombo_amd import _native, resquiggle as rq, tombo_stats as ts
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    samp, model, params, reads = _setup(n_reads=6, seed0=40)
+    eng = rq.get_engine(0)
+    eng.ensure_model(model)
+    p = _native.make_params(params)
+    si = np.zeros((len(reads), 1000), np.int64)
+    for i, (_, _, s) in enumerate(reads):
+        if s is not None:
+            si[i] = s
+    outs = {}
+    for skip in (False, True):
+        o = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH['DNA'],
+                              skip_norm_out=skip)
+        eng.upload(p, o, [r for _, r, _ in reads], [ts.encode_seq(s) for s, _, _ in reads], samp_ind=si)
+        eng.run()
+        outs[skip] = (eng.download(want_norm=False), eng.base_stats())
+        if skip:
+            with pytest.raises(_native.EngineError):
+                eng.download_async(norm=np.zeros(eng.n_raw_total))
+    a, b = outs[False], outs[True]
+    np.testing.assert_array_equal(a[0]['segs'], b[0]['segs'])
+    np.testing.assert_array_equal(a[0]['score'], b[0]['score'])
+    np.testing.assert_array_equal(a[1][0], b[1][0])   # per-base means
+    np.testing.assert_array_equal(a[1][1], b[1][1])   # per-base sds
+
+
+def test_auto_sub_batching_gives_the_one_batch_result():
+    from tombo_amd import resquiggle as rq
+    samp, model, params, reads = _setup(n_reads=17, seed0=70)
+    mrs = _map_results(reads)
+    sis = [si for _, _, si in reads]
+    one = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp, samp_inds=sis)
+    # a budget that only fits a handful of these reads at a time
+    cut = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp,
+                              samp_inds=sis, mem_budget=5.6e8)
+    assert len(one) == len(cut) == len(mrs)
+    for x, y in zip(one, cut):
+        assert isinstance(x, Exception) == isinstance(y, Exception)
+        if not isinstance(x, Exception):
+            np.testing.assert_array_equal(x.segs, y.segs)
+            np.testing.assert_array_equal(x.raw_signal, y.raw_signal)
+            assert x.sig_match_score == y.sig_match_score
+
+
+def test_put_rejects_indices_outside_the_signal():
+    from tombo_amd import _native, resquiggle as rq, tombo_stats as ts
+    samp, model, params, reads = _setup(n_reads=1, seed0=11)
+    eng = rq.get_engine(0)
+    eng.ensure_model(model)
+    seq, raw, _ = reads[0]
+    eng.set_num_events([40])
+    eng.upload(_native.make_params(params), _native.make_opts(), [raw], [ts.encode_seq(seq)])
+    good = np.arange(0, 400, 10, dtype=np.int64)
+    for bad in (good[::-1].copy(), good + raw.shape[0], np.where(np.arange(40) == 7, good[6], good)):
+        with pytest.raises(_native.EngineError):
+            eng.put(_native.PUT_VALID_CPTS, bad, per_read=[40])
+    eng.put(_native.PUT_VALID_CPTS, good, per_read=[40])
+    nseg = int(eng.seg_off[-1])
+    segs = np.linspace(0, 300, nseg).astype(np.int64)
+    with pytest.raises(_native.EngineError):
+        eng.put(_native.PUT_DP_SEGS, segs[::-1].copy(), per_read=[0, 300])
+    with pytest.raises(_native.EngineError):
+        eng.put(_native.PUT_DP_SEGS, segs, per_read=[0, 200])      # boundaries past norm_len
+    eng.put(_native.PUT_DP_SEGS, segs, per_read=[0, 300])
+
+
+def test_failed_upload_does_not_leave_forced_event_counts_armed():
+    from tombo_amd import _native, resquiggle as rq, tombo_stats as ts
+    samp, model, params, reads = _setup(n_reads=1, seed0=12)
+    eng = rq.get_engine(0)
+    eng.ensure_model(model)
+    seq, raw, _ = reads[0]
+    eng.set_num_events([7])
+    with pytest.raises(_native.EngineError):   # start bandwidth above TBA_MAX_BAND: refused
+        eng.upload(_native.make_params(params._replace(start_bw=5000)), _native.make_opts(),
+                   [raw], [ts.encode_seq(seq)])
+    eng.upload(_native.make_params(params), _native.make_opts(outlier_thresh=5.0), [raw],
+               [ts.encode_seq(seq)])
+    eng.run_stages(_native.STAGE_SEGMENT, _native.STAGE_SEGMENT)
+    assert int(eng.get(_native.GET_N_CPTS)[0]) == int(eng.num_events[0]) != 7

@@ -52,12 +52,18 @@ def _worker(rank, world, port, n_reads, q):
     from tombo_amd import sharding
     dist.init_process_group('gloo', rank=rank, world_size=world)
     model, reads = _reads(n_reads)
-    mine = sharding.resquiggle_sharded(reads, _process(model), batch_size=3, gather=False,
-                                       queue_key='q1')
+    # same call twice with the default key: every call gets a fresh counter
+    mine = sharding.resquiggle_sharded(reads, _process(model), batch_size=3, gather=False)
     dist.barrier()
-    full = sharding.resquiggle_sharded(reads, _process(model), batch_size=3, gather=True,
-                                       queue_key='q2')
-    q.put((rank, sorted(mine.keys()), full))
+    full = sharding.resquiggle_sharded(reads, _process(model), batch_size=3, gather=True)
+    dist.barrier()
+    # large-job form: batches are loaded by the rank that draws them, results go to a sink
+    loaded, sunk = [], []
+    f = _process(model)
+    sharding.run_sharded(5, lambda b: (loaded.append(b), reads[3 * b:3 * b + 3])[1], f,
+                         sink=lambda b, res: sunk.append((b, [st for st, _ in res])))
+    assert loaded == [b for b, _ in sunk]
+    q.put((rank, sorted(mine.keys()), full, sorted(loaded)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +84,7 @@ def test_two_rank_work_queue_gloo():
     got.sort()
     keys = got[0][1] + got[1][1]
     assert sorted(keys) == list(range(5)), 'every batch exactly once: %r' % (keys,)
+    assert sorted(got[0][3] + got[1][3]) == list(range(5)), 'sink form: every batch exactly once'
     model, reads = _reads(n_reads)
     from tombo_amd import sharding
     single = sharding.resquiggle_sharded(reads, _process(model), batch_size=3)

@@ -48,13 +48,34 @@ class Opts(C.Structure):
                 ('check_start_score', i64), ('sig_match_thresh', f64),
                 ('max_raw_cpts', i64), ('min_event_to_seq_ratio', f64),
                 ('use_rna_event_scale', i64), ('rna_scale_num_events', i64),
-                ('rna_scale_max_frac_events', f64)]
+                ('rna_scale_max_frac_events', f64), ('skip_norm_out', i64)]
+
+
+class ReadResult(C.Structure):
+    """tba_read_result: the scalar part of what resquiggle_read returns, 64 bytes per read"""
+    _fields_ = [('status', i32), ('norm_params_changed', i32),
+                ('read_start_rel_to_raw', i64), ('norm_len', i64),
+                ('shift', f64), ('scale', f64), ('lower_lim', f64), ('upper_lim', f64),
+                ('sig_match_score', f64)]
+
+
+RESULT_DTYPE = np.dtype([
+    ('status', np.int32), ('norm_params_changed', np.int32),
+    ('read_start_rel_to_raw', np.int64), ('norm_len', np.int64),
+    ('shift', np.float64), ('scale', np.float64), ('lower_lim', np.float64),
+    ('upper_lim', np.float64), ('sig_match_score', np.float64)])
+assert RESULT_DTYPE.itemsize == C.sizeof(ReadResult) == 64
+
+RAW_F64, RAW_F32, RAW_I16 = 0, 1, 2
+RAW_DTYPES = {np.dtype(np.float64): RAW_F64, np.dtype(np.float32): RAW_F32,
+              np.dtype(np.int16): RAW_I16}
 
 
 # TBA_GET_* selectors
 GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START, \
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
     GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL = range(1, 20)
+GET_DEBUG_COUNTERS = 99  # ReadState.dbg of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS profiling build
 STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, STAGE_SKIP, \
     STAGE_RESCALE = range(7)
 PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
@@ -98,7 +119,8 @@ def make_params(rp):
 
 
 def make_opts(outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
-              sig_match_thresh=None, max_raw_cpts=200, min_event_to_seq_ratio=1.1):
+              sig_match_thresh=None, max_raw_cpts=200, min_event_to_seq_ratio=1.1,
+              skip_norm_out=False):
     o = Opts()
     o.has_outlier_thresh = int(outlier_thresh is not None)
     o.outlier_thresh = 0.0 if outlier_thresh is None else float(outlier_thresh)
@@ -110,7 +132,38 @@ def make_opts(outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
     o.max_raw_cpts = -1 if max_raw_cpts is None else int(max_raw_cpts)
     o.min_event_to_seq_ratio = float(min_event_to_seq_ratio)
     o.use_rna_event_scale, o.rna_scale_num_events, o.rna_scale_max_frac_events = 1, 10000, 0.75
+    o.skip_norm_out = int(bool(skip_norm_out))
     return o
+
+
+class PinnedArray(object):
+    """A numpy array over page-locked host memory (tba_pinned_alloc): uploads from it and
+    downloads into it are asynchronous DMA transfers.  `.a` is the array; freed on close / GC."""
+
+    def __init__(self, shape, dtype):
+        self._L = lib()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) if not np.isscalar(shape) else int(shape)
+        self.nbytes = max(n * dtype.itemsize, 1)
+        ptr = C.c_void_p()
+        rc = self._L.tba_pinned_alloc(i64(self.nbytes), C.byref(ptr))
+        if rc != 0:
+            raise EngineError('tba_pinned_alloc failed (%d): %s' % (rc, self._L.tba_last_error().decode()))
+        self._ptr = ptr
+        buf = (C.c_char * self.nbytes).from_address(ptr.value)
+        self.a = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+    def close(self):
+        if getattr(self, '_ptr', None):
+            self.a = None
+            self._L.tba_pinned_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class EngineError(RuntimeError):
@@ -129,6 +182,7 @@ class Engine(object):
                 rc, self._L.tba_last_error().decode()))
         self.kmer_width = None
         self._keep = None
+        self._model_key = None
 
     def _check(self, rc, what):
         if rc != 0:
@@ -153,19 +207,60 @@ class Engine(object):
         self._check(self._L.tba_set_model(self._h, _p(m, f64), _p(s, f64), i64(kmer_width),
                                           i64(central_pos)), 'tba_set_model')
         self.kmer_width = int(kmer_width)
+        self._model_key = None
+
+    def ensure_model(self, std_ref):
+        """upload std_ref's level table unless the engine already holds the same table (compared
+        by content: ids are reused after garbage collection and TomboModel arrays are mutable)"""
+        import hashlib
+        m = np.ascontiguousarray(std_ref.level_means, dtype=np.float64)
+        sd = np.ascontiguousarray(std_ref.level_sds, dtype=np.float64)
+        key = (int(std_ref.kmer_width), int(std_ref.central_pos),
+               hashlib.blake2b(m.tobytes() + sd.tobytes(), digest_size=16).digest())
+        if key != self._model_key:
+            self.set_model(m, sd, std_ref.kmer_width, std_ref.central_pos)
+            self._model_key = key
 
     def upload(self, params, opts, raws, seqs, sv_in=None, sv_flags=None, samp_ind=None,
                stall_ints=None):
-        """raws: list of float64 arrays; seqs: list of uint8 code arrays."""
+        """raws: list of sample arrays (all int16, all float32, or anything else -> float64);
+        seqs: list of uint8 code arrays."""
         n = len(raws)
-        self.n = n
         raw_off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum([r.shape[0] for r in raws], out=raw_off[1:])
         seq_off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum([s.shape[0] for s in seqs], out=seq_off[1:])
-        raw = np.ascontiguousarray(np.concatenate(raws), dtype=np.float64) \
-            if n > 1 else np.ascontiguousarray(raws[0], dtype=np.float64)
+        dts = set(np.asarray(r).dtype for r in raws)
+        dt = next(iter(dts)) if len(dts) == 1 and next(iter(dts)) in RAW_DTYPES \
+            else np.dtype(np.float64)
+        raw = np.ascontiguousarray(np.concatenate(raws), dtype=dt) \
+            if n > 1 else np.ascontiguousarray(raws[0], dtype=dt)
         seq = np.ascontiguousarray(np.concatenate(seqs), dtype=np.uint8)
+        st = sto = None
+        if stall_ints is not None:
+            cnt = [0 if s is None else len(s) for s in stall_ints]
+            sto = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(cnt, out=sto[1:])
+            rows = [np.array([[int(a), int(b)] for a, b in s], dtype=np.int64).reshape(-1, 2)
+                    for s in stall_ints if s is not None and len(s)]
+            st = np.ascontiguousarray(np.concatenate(rows)) if rows else np.zeros((1, 2), np.int64)
+        self.upload_packed(params, opts, raw, raw_off, seq, seq_off, sv_in=sv_in,
+                           sv_flags=sv_flags, samp_ind=samp_ind, stall_ints=st, stall_off=sto,
+                           wait=True)
+
+    def upload_packed(self, params, opts, raw, raw_off, seq, seq_off, sv_in=None, sv_flags=None,
+                      samp_ind=None, stall_ints=None, stall_off=None, wait=False):
+        """One batch as flat CSR arrays (tba_batch_upload_async): raw (int16 / float32 / float64)
+        and seq (uint8 codes) concatenated, offsets int64[n+1].  Enqueue only unless `wait`; the
+        arrays are kept referenced until the next upload, but must not be modified before
+        `sync()`.  Arrays in PinnedArray memory are transferred by DMA."""
+        raw_off = np.ascontiguousarray(raw_off, dtype=np.int64)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        n = raw_off.shape[0] - 1
+        self.n = n
+        if raw.dtype not in RAW_DTYPES or not raw.flags.c_contiguous:
+            raw = np.ascontiguousarray(raw, dtype=np.float64)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
         K = self.kmer_width
         self.raw_off, self.seq_off = raw_off, seq_off
         self.B = np.maximum(np.diff(seq_off) - K + 1, 0)
@@ -184,20 +279,18 @@ class Engine(object):
         svi = None if sv_in is None else np.ascontiguousarray(sv_in, dtype=np.float64)
         svf = None if sv_flags is None else np.ascontiguousarray(sv_flags, dtype=np.int32)
         si = None if samp_ind is None else np.ascontiguousarray(samp_ind, dtype=np.int64)
-        st = sto = None
-        if stall_ints is not None:
-            cnt = [0 if s is None else len(s) for s in stall_ints]
-            sto = np.zeros(n + 1, dtype=np.int64)
-            np.cumsum(cnt, out=sto[1:])
-            rows = [np.array([[int(a), int(b)] for a, b in s], dtype=np.int64).reshape(-1, 2)
-                    for s in stall_ints if s is not None and len(s)]
-            st = np.ascontiguousarray(np.concatenate(rows)) if rows else np.zeros((1, 2), np.int64)
+        st = None if stall_ints is None else np.ascontiguousarray(stall_ints, dtype=np.int64)
+        sto = None if stall_off is None else np.ascontiguousarray(stall_off, dtype=np.int64)
         self._keep = (raw, seq, raw_off, seq_off, svi, svf, si, st, sto)
-        self._check(self._L.tba_batch_upload(
-            self._h, C.byref(params), C.byref(opts), i64(n), _p(raw, f64), _p(raw_off, i64),
+        self.skip_norm_out = bool(opts.skip_norm_out)
+        self._check(self._L.tba_batch_upload_async(
+            self._h, C.byref(params), C.byref(opts), i64(n), raw.ctypes.data_as(C.c_void_p),
+            C.c_int(RAW_DTYPES[raw.dtype]), _p(raw_off, i64),
             _p(seq, C.c_uint8), _p(seq_off, i64), _p(svi, f64), _p(svf, i32), _p(si, i64),
-            _p(st, i64), _p(sto, i64)), 'tba_batch_upload')
+            _p(st, i64), _p(sto, i64)), 'tba_batch_upload_async')
         self.n_raw_total = int(raw_off[-1])
+        if wait:
+            self.sync()
 
     def run(self):
         self._check(self._L.tba_batch_run(self._h), 'tba_batch_run')
@@ -208,8 +301,47 @@ class Engine(object):
     def sync(self):
         self._check(self._L.tba_batch_sync(self._h), 'tba_batch_sync')
 
+    def device_mem(self):
+        """(free, total) bytes of this engine's device"""
+        a, b = i64(0), i64(0)
+        self._check(self._L.tba_device_mem(self._h, C.byref(a), C.byref(b)), 'tba_device_mem')
+        return a.value, b.value
+
+    def query(self):
+        """True while work of this engine is still in flight (never blocks)"""
+        rc = self._L.tba_batch_query(self._h)
+        if rc < 0:
+            self._check(rc, 'tba_batch_query')
+        return rc == 1
+
+    def download_async(self, results=None, segs32=None, segs64=None, norm=None):
+        """Enqueue the copies of the finished batch's outputs into the given arrays (ideally
+        PinnedArray memory): results RESULT_DTYPE[n], segs32 int32 / segs64 int64 [seg_off[-1]],
+        norm float64[n_raw_total].  Valid after sync()."""
+        for a, dt, cnt in ((results, RESULT_DTYPE, self.n), (segs32, np.int32, int(self.seg_off[-1])),
+                           (segs64, np.int64, int(self.seg_off[-1])),
+                           (norm, np.float64, self.n_raw_total)):
+            if a is not None and (a.dtype != dt or a.size < cnt or not a.flags.c_contiguous):
+                raise ValueError('output array has the wrong dtype / size')
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self._keep_out = (results, segs32, segs64, norm)
+        self._check(self._L.tba_batch_download_async(
+            self._h, vp(results), vp(segs32), vp(segs64), vp(norm)), 'tba_batch_download_async')
+
+    def footprint(self, params, opts, n_raw, seq_len, raw_dtype=np.float64):
+        """device bytes a batch of reads with these lengths would occupy"""
+        nr = np.ascontiguousarray(n_raw, dtype=np.int64)
+        sl = np.ascontiguousarray(seq_len, dtype=np.int64)
+        out = f64(0)
+        self._check(self._L.tba_batch_footprint(
+            C.byref(params), C.byref(opts), i64(self.kmer_width),
+            C.c_int(RAW_DTYPES[np.dtype(raw_dtype)]), i64(nr.shape[0]), _p(nr, i64), _p(sl, i64),
+            C.byref(out)), 'tba_batch_footprint')
+        return out.value
+
     def download(self, want_norm=True):
         n = self.n
+        want_norm = want_norm and not getattr(self, 'skip_norm_out', False)
         status = np.zeros(n, np.int32)
         segs = np.zeros(int(self.seg_off[-1]), np.int64)
         rs = np.zeros(n, np.int64)
@@ -231,7 +363,7 @@ class Engine(object):
             GET_SEG_SV: (np.float64, (n, 4)), GET_START: (np.float64, (n, 4)),
             GET_THEIL_SEN: (np.float64, (n, 4)), GET_PATH: (np.int32, (n, 4)),
             GET_LAST_ROW: (np.float64, (n, MAX_BAND)), GET_KERNEL_MS: (np.float32, 32),
-            99: (np.int64, (n, 8)),
+            GET_DEBUG_COUNTERS: (np.int64, (n, 8)),
             GET_SEG_NORM: (np.float64, self.n_raw_total),
             GET_BAND_STARTS: (np.int64, int(self.ref_off[-1])),
             GET_READ_TB: (np.int64, int(self.seg_off[-1])),

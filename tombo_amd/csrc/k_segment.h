@@ -7,15 +7,19 @@
 // ts.normalize_raw_signal (tombo_stats.py:482-573) for 'median', 'median_const_scale' and given
 // scale values; one workgroup per read.  mode 0: DNA order (normalise first); mode 1: RNA,
 // called after event detection with scale values already in ReadState.
+// RT: the raw sample type at the boundary (double, float, or the int16 DAC values of the FAST5
+// file, resquiggle.py:1397); widening to float64 is exact, so every pass sees the values the
+// reference sees after its own int16 -> float64 promotion.
+template <class RT>
 __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevParams *dp,
-    const double *raw, double *norm, const double *sv_in, int mode)
+    const RT *raw, double *norm, const double *sv_in, int mode)
 {
     __shared__ BucketSmem sm;
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
     const int tid = threadIdx.x;
     const i64 n = r.n_raw;
-    const double *x = raw + r.raw_off;
+    const RawSamples<RT> x{raw + r.raw_off};
     double *y = norm + r.raw_off;
     const tba_opts &o = dp->o;
     double shift, scale, lo = 0, hi = 0;
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 
 // Each workgroup step stages 256 + 2w consecutive samples in LDS (one coalesced load) and every
 // thread reads its two windows from there; WS > 0: the window width as a compile-time constant
 // (w = 12 is the RNA default), loops fully unrolled, each sample read once.
-template <int WS>
-__device__ __forceinline__ double ttest_score(const double *t, int w)
+template <int WS, class Acc>
+__device__ __forceinline__ double ttest_score(Acc t, int w)
 {
     const int W = WS > 0 ? WS : w;
     double m1 = 0, m2 = 0, var1 = 0, var2 = 0, d;
@@ -304,15 +308,16 @@ __device__ __forceinline__ double ttest_score(const double *t, int w)
     return m1 > m2 ? (m1 - m2) / sqrt(var1 + var2) : (m2 - m1) / sqrt(var1 + var2);
 }
 #define TT_MAXW 64
+template <class RT>
 __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const DevParams *dp,
-    const double *raw, double *score)
+    const RT *raw, double *score)
 {
     __shared__ double tile[256 + 2 * TT_MAXW];
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
     const i64 w = dp->p.running_stat_width;
     const i64 ns = r.n_raw - 2 * w;
-    const double *x = raw + r.raw_off;
+    const RawSamples<RT> x{raw + r.raw_off};
     double *s = score + r.raw_off;
     if (w > TT_MAXW) { // no tile: straight from memory
         for (i64 pos = (i64)blockIdx.x * 256 + threadIdx.x; pos < ns; pos += (i64)gridDim.x * 256)
@@ -669,12 +674,13 @@ __global__ __launch_bounds__(SEL_NT) void k_remove_stalls(ReadState *rs, i64 n_r
 
 // c_new_means (_c_helper.pyx:59-71) over the event boundaries: sequential sum, one divide.
 // grid: (blocks, reads)
-__global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const double *sig,
+template <class RT>
+__global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const RT *sig,
     const i64 *valid_cpts, double *event_means, int from_raw_limit)
 {
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
-    const double *x = sig + r.raw_off;
+    const RawSamples<RT> x{sig + r.raw_off};
     const i64 *c = valid_cpts + r.ev_off;
     double *em = event_means + r.ev_off;
     i64 n = r.n_cpts - 1;

@@ -416,8 +416,8 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
 // cap is per kernel: a smaller LDS slice lets more workgroups share a CU (these kernels are
 // bandwidth bound, occupancy is what keeps bytes in flight).
 // seg has n_segs + 1 ascending boundaries; emit(i, sum, length) per segment.
-template <int SEGW_CAP, class Emit>
-__device__ __forceinline__ void wave_segment_sums(const double *__restrict__ x,
+template <int SEGW_CAP, class Sig, class Emit>
+__device__ __forceinline__ void wave_segment_sums(Sig x,
     const i64 *__restrict__ seg, i64 n_segs, i64 first_group, i64 group_stride, double *lds,
     Emit emit)
 {

@@ -549,12 +549,22 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
 // the batch: what write_new_fast5_group (tombo_helper.py:2341-2362) stores per base as
 // norm_mean / norm_stdev.  Same wave-cooperative staging as k_rescale_absz; the variance loop runs
 // over the staged samples again (population sd around the segment mean).  grid: (blocks, reads)
-__global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const double *norm_out,
-    const i64 *segs, double *means, double *stds)
+// the final signal of a read: the materialised norm_out, or (skip_norm_out batches) the signal of
+// segment_signal rescaled on the fly with k_rescale_absz's expression (same operation, same bits)
+struct FinalSignal {
+    const double *p;
+    bool rescale;
+    double ca, cb;
+    __device__ __forceinline__ double operator[](i64 i) const { return rescale ? (p[i] - ca) / cb : p[i]; }
+};
+__global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const DevParams *dp,
+    const double *norm_out, const double *norm, const i64 *segs, double *means, double *stds)
 {
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
-    const double *x = norm_out + r.raw_off;
+    const FinalSignal x = norm_out != nullptr
+        ? FinalSignal{norm_out + r.raw_off, false, 0.0, 1.0}
+        : FinalSignal{norm + r.raw_off + r.read_start, dp->o.skip_seq_scaling == 0, r.ts[2], r.ts[3]};
     const i64 *sg = segs + r.seg_off;
     constexpr int CAP = 768;
     __shared__ double s_seg[4 * CAP];
@@ -608,7 +618,7 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
     const double *x = norm + r.raw_off + r.read_start;
-    double *y = norm_out + r.raw_off;
+    double *y = norm_out != nullptr ? norm_out + r.raw_off : nullptr; // NULL: skip_norm_out batch
     const i64 *sg = segs + r.seg_off;
     const bool skip = dp->o.skip_seq_scaling != 0;
     const double ca = r.ts[2], cb = r.ts[3];
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
             __builtin_amdgcn_wave_barrier();
             for (i64 k = lane; k < span; k += 64) {
                 const double v = skip ? x[lo + k] : (x[lo + k] - ca) / cb; // resquiggle.py:1190
-                y[lo + k] = v;
+                if (y) y[lo + k] = v;
                 lds[k] = v;
             }
             __builtin_amdgcn_wave_barrier();
@@ -642,7 +652,7 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
         } else {
             for (i64 j = a; j < b; j++) {
                 const double v = skip ? x[j] : (x[j] - ca) / cb;
-                y[j] = v;
+                if (y) y[j] = v;
                 s += v;
             }
         }

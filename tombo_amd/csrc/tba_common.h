@@ -62,6 +62,14 @@ struct DevParams {
                         // resquiggle.py:665-668,678
 };
 
+// raw samples of one read as float64 (exact widening of float / int16 input)
+template <class RT>
+struct RawSamples {
+    const RT *p;
+    __device__ __forceinline__ double operator[](i64 i) const { return (double)p[i]; }
+    __device__ __forceinline__ RawSamples operator+(i64 k) const { return RawSamples{p + k}; }
+};
+
 // order-preserving map double -> u64 (ascending); no NaNs on this path
 __device__ __forceinline__ u64 f64_key(double x)
 {

@@ -40,6 +40,24 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
+// page-locked host buffer (engine-owned staging of the small per-batch records, so that the
+// "async" upload never falls back to HIP's blocking pageable path)
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return set_err(TBA_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
 
 enum { N_STAGE = 16 };
 static const char *STAGE_NAMES[N_STAGE] = {
@@ -62,7 +80,9 @@ struct tba_engine {
     bool any_stall = false, have_samp = false, have_sv = false;
     std::vector<i64> ne_override; // per-read num_events for the next upload (stepwise API)
     double algo_bytes = 0, dp_cells = 0;
-    std::vector<ReadState> h_rs;
+    int raw_dtype = TBA_RAW_F64;
+    PinBuf h_rs, h_dp;            // ReadState[n] / DevParams as uploaded (pinned)
+    DevBuf d_res, d_segs32;       // packed results of tba_batch_download_async
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_bm, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
@@ -73,8 +93,10 @@ struct tba_engine {
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_bm, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr, &d_wide, &d_stat};
+                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32};
         for (DevBuf *b : all) b->release();
+        h_rs.release();
+        h_dp.release();
     }
 };
 
@@ -133,17 +155,195 @@ extern "C" int tba_set_model(tba_engine *e, const double *kmer_means, const doub
     e->hp.kmer_width = kmer_width;
     e->hp.central_pos = central_pos;
     e->have_model = true;
+    // a batch uploaded under another model has stale per-read geometry (B depends on K)
+    e->have_batch = e->ran = e->finished = false;
     return 0;
 }
 
-extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_opts *o,
-                                int64_t n_reads, const double *raw, const int64_t *raw_off,
-                                const uint8_t *seq, const int64_t *seq_off, const double *sv_in,
-                                const int32_t *sv_flags, const int64_t *samp_ind,
-                                const int64_t *stall_ints, const int64_t *stall_off)
+extern "C" int tba_device_mem(tba_engine *e, int64_t *free_bytes, int64_t *total_bytes)
 {
+    if (!e) return set_err(TBA_E_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return 0;
+}
+
+extern "C" int tba_pinned_alloc(int64_t bytes, void **out)
+{
+    if (!out || bytes < 0) return set_err(TBA_E_ARG, "bad arguments");
+    void *p = nullptr;
+    hipError_t rc = hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault);
+    if (rc != hipSuccess) return set_err(TBA_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(rc));
+    *out = p;
+    return 0;
+}
+extern "C" int tba_pinned_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess) return set_err(TBA_E_HIP, "hipHostFree failed");
+    return 0;
+}
+
+// ---- batch sizing -----------------------------------------------------------------------------
+// Everything the device buffers of a batch depend on, from the per-read lengths alone (shared by
+// tba_batch_upload_async and tba_batch_footprint).
+static size_t raw_elem_bytes(int dt) { return dt == TBA_RAW_I16 ? 2 : dt == TBA_RAW_F32 ? 4 : 8; }
+
+struct BatchSizes {
+    i64 S_tot = 0, seq_tot = 0, B_tot = 0, E_tot = 0, max_raw = 0, max_B = 0, max_nev = 0;
+    i64 moves_need = 0, start_moves_stride = 0, moves_arena = 0, skip_arena = 0, wide_w = 0;
+    i64 n_stall = 0;
+    double algo_bytes = 0, cells = 0;
+};
+
+// per-read geometry; rs may be NULL (footprint only).  Returns 0 or TBA_E_ARG.
+static int plan_batch(const tba_params *p, const tba_opts *o, i64 K, i64 n, const i64 *raw_off,
+                      const i64 *n_raw_arr, const i64 *seq_off, const i64 *seq_len_arr,
+                      const std::vector<i64> &ne_override, const int32_t *sv_flags,
+                      const i64 *stall_off, ReadState *rs, BatchSizes &z)
+{
+    const int cpl_main = cpl_class(p->bandwidth);
+    if (cpl_class(p->start_bw) == 0 || cpl_class(p->start_save_bw) == 0 || cpl_main == 0)
+        return set_err(TBA_E_ARG, "bandwidth / start bandwidth above TBA_MAX_BAND");
+    i64 ref_acc = 0, ev_acc = 0, raw_acc = 0, seq_acc = 0;
+    for (i64 i = 0; i < n; i++) {
+        const i64 n_raw = raw_off ? raw_off[i + 1] - raw_off[i] : n_raw_arr[i];
+        const i64 seq_len = seq_off ? seq_off[i + 1] - seq_off[i] : seq_len_arr[i];
+        if (n_raw < 0 || seq_len < 0) return set_err(TBA_E_ARG, "negative read length");
+        ReadState tmp;
+        ReadState &r = rs ? rs[i] : tmp;
+        memset(&r, 0, sizeof(r));
+        r.raw_off = raw_acc; r.n_raw = n_raw; raw_acc += n_raw;
+        r.seq_off = seq_acc; r.seq_len = seq_len; seq_acc += seq_len;
+        const i64 B = seq_len - K + 1;
+        r.ref_off = ref_acc;
+        r.seg_off = ref_acc + i;
+        r.B = B > 0 ? B : 0;
+        ref_acc += r.B;
+        r.ev_off = ev_acc;
+        r.status = TBA_OK;
+        r.sv_flags = sv_flags ? sv_flags[i] : 0;
+        if (stall_off) { r.stall_off = stall_off[i]; r.n_stall = stall_off[i + 1] - stall_off[i]; }
+        if (B <= 0 || n_raw <= 0) {
+            r.status = n_raw <= 0 ? TBA_NO_RAW : TBA_INTERNAL;
+            continue;
+        }
+        // ts.compute_num_events (tombo_stats.py:1558-1574) and the guard of resquiggle.py:1159
+        i64 num_events = std::max(n_raw / p->mean_obs_per_event,
+                                  (i64)((double)B * o->min_event_to_seq_ratio));
+        const bool forced = (i64)ne_override.size() == n && ne_override[(size_t)i] > 0;
+        if (forced) num_events = ne_override[(size_t)i]; // caller-chosen (segment_signal)
+        r.num_events = num_events; // event space is reserved for every read with B > 0
+        ev_acc += num_events;
+        if (!forced && (double)num_events / (double)p->bandwidth > (double)B) { r.status = TBA_TOO_MUCH_SIGNAL; continue; }
+        if (num_events <= 1 || n_raw < 4 * p->running_stat_width + 2) { r.status = TBA_INTERNAL; continue; }
+        z.max_raw = std::max(z.max_raw, n_raw);
+        z.max_B = std::max(z.max_B, B);
+        const i64 n_ev = num_events - 1;
+        const bool short_read = n_ev < p->start_bw + p->start_n_bases || B < p->start_n_bases;
+        // packed move rows: the adaptive band, or the whole-read static band of a short read
+        // (n_ev - mask_len cells, any width: k_dp_wide beyond the widest class)
+        i64 row_bytes = mv_row_bytes(p->bandwidth);
+        if (short_read) row_bytes = std::max(row_bytes, mv_row_bytes(n_ev));
+        z.moves_need += (B + 1) * row_bytes;
+        z.max_nev = std::max(z.max_nev, n_ev);
+        // algorithmic traffic (SURVEY.md 8d): raw in + seq + norm out + segs + band starts +
+        // 2-bit moves + scalars
+        z.algo_bytes += 8.0 * n_raw + (double)seq_len + 8.0 * n_raw + 8.0 * (B + 1) + 8.0 * B +
+                        (double)((B * p->bandwidth + 3) / 4) + 64.0;
+        z.cells += (double)B * p->bandwidth + (short_read ? 0.0 : (double)p->start_n_bases * p->start_bw);
+    }
+    z.S_tot = raw_acc; z.seq_tot = seq_acc; z.B_tot = ref_acc; z.E_tot = ev_acc;
+    z.wide_w = z.max_nev > TBA_MAX_BAND ? ((z.max_nev + 63) / 64) * 64 : 0;
+    const i64 start_w = std::max(p->start_bw, p->start_save_bw);
+    z.start_moves_stride = (p->start_n_bases + 1) * (i64)mv_class_rowb(cpl_class(start_w));
+    z.moves_arena = z.moves_need + z.moves_need / 8 + (64ll << 20);
+    // raw-DP scratch arena (8-byte units): windows are a few bases x tens of samples; reads that
+    // do not fit the arena get TBA_UNSUPPORTED
+    z.skip_arena = n * 32768 + (32ll << 20);
+    z.n_stall = stall_off ? stall_off[n] : 0;
+    return 0;
+}
+
+// the device buffers of a batch: (buffer, bytes) through `f`
+template <class F>
+static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_opts *o, i64 n,
+                                  const BatchSizes &z, int raw_dtype, F f)
+{
+    const size_t S = (size_t)std::max<i64>(z.S_tot, 1), Bt = (size_t)std::max<i64>(z.B_tot, 1),
+                 Et = (size_t)std::max<i64>(z.E_tot, 1), N = (size_t)n;
+    tba_engine *q = e; // q == NULL: sizes only
+#define BUF(name_, bytes_) f(q ? &q->name_ : (DevBuf *)nullptr, (size_t)(bytes_))
+    BUF(d_rs, N * sizeof(ReadState));
+    BUF(d_dp, sizeof(DevParams));
+    BUF(d_raw, S * raw_elem_bytes(raw_dtype));
+    BUF(d_norm, S * 8);
+    if (!o->skip_norm_out) BUF(d_norm_out, S * 8);
+    BUF(d_csum, (S + N) * 8);
+    BUF(d_score, S * 8);
+    BUF(d_state, S);
+    BUF(d_cpts, Et * 8);
+    BUF(d_evm, Et * 8);
+    BUF(d_seq, (size_t)std::max<i64>(z.seq_tot, 1));
+    BUF(d_refm, Bt * 8);
+    BUF(d_refs, Bt * 8);
+    BUF(d_bst, Bt * 8);
+    BUF(d_lo, Bt * 4);
+    BUF(d_hi, Bt * 4);
+    BUF(d_readtb, (Bt + N) * 8);
+    BUF(d_dpsegs, (Bt + N) * 8);
+    BUF(d_segs, (Bt + N) * 8);
+    BUF(d_win, (Bt + N) * 24);
+    BUF(d_bm, Bt * 8);
+    BUF(d_absz, Bt * 8);
+    BUF(d_sv_in, N * 32);
+    BUF(d_samp, N * MAX_TS_POINTS * 8);
+    BUF(d_lastrow, N * TBA_MAX_BAND * 8);
+    BUF(d_startvals, N * (size_t)p->start_n_bases * 8);
+    BUF(d_smoves, N * (size_t)z.start_moves_stride);
+    BUF(d_moves, (size_t)z.moves_arena);
+    BUF(d_dscr, (size_t)z.skip_arena * 8);
+    if (z.wide_w) BUF(d_wide, (size_t)WIDE_BLOCKS * 2 * (size_t)z.wide_w * 8);
+    if (z.n_stall > 0) BUF(d_stall, (size_t)z.n_stall * 16);
+    BUF(d_res, N * sizeof(tba_read_result));
+    BUF(d_segs32, (Bt + N) * 4);
+#undef BUF
+}
+
+extern "C" int tba_batch_footprint(const tba_params *p, const tba_opts *o, int64_t kmer_width,
+                                   int raw_dtype, int64_t n_reads, const int64_t *n_raw,
+                                   const int64_t *seq_len, double *bytes)
+{
+    if (!p || !o || !n_raw || !seq_len || !bytes || n_reads <= 0 || kmer_width < 1)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (raw_dtype < TBA_RAW_F64 || raw_dtype > TBA_RAW_I16) return set_err(TBA_E_ARG, "unknown raw dtype");
+    BatchSizes z;
+    std::vector<i64> none;
+    if (int rc = plan_batch(p, o, kmer_width, n_reads, nullptr, n_raw, nullptr, seq_len, none, nullptr,
+                            nullptr, nullptr, z))
+        return rc;
+    double tot = 0;
+    for_each_batch_buffer(nullptr, p, o, n_reads, z, raw_dtype,
+                          [&](DevBuf *, size_t b) { tot += (double)(b + b / 8 + 256); });
+    *bytes = tot;
+    return 0;
+}
+
+extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const tba_opts *o,
+                                      int64_t n_reads, const void *raw, int raw_dtype,
+                                      const int64_t *raw_off, const uint8_t *seq,
+                                      const int64_t *seq_off, const double *sv_in,
+                                      const int32_t *sv_flags, const int64_t *samp_ind,
+                                      const int64_t *stall_ints, const int64_t *stall_off)
+{
+    // the forced event counts apply to this upload only, whatever its outcome
+    std::vector<i64> ne_override;
+    if (e) ne_override.swap(e->ne_override);
     if (!e || !p || !o || n_reads <= 0 || !raw || !raw_off || !seq || !seq_off)
         return set_err(TBA_E_ARG, "bad batch arguments");
+    if (raw_dtype < TBA_RAW_F64 || raw_dtype > TBA_RAW_I16) return set_err(TBA_E_ARG, "unknown raw dtype");
     if (!e->have_model) return set_err(TBA_E_STATE, "tba_set_model has not been called");
     if (p->bandwidth < 2 || p->running_stat_width < 1 || p->min_obs_per_base < 1 ||
         p->raw_min_obs_per_base < 1 || p->mean_obs_per_event < 1 || p->start_n_bases < 1)
@@ -154,141 +354,74 @@ extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_op
     for (i64 i = 0; i < n_reads; i++)
         if (raw_off[i + 1] < raw_off[i] || seq_off[i + 1] < seq_off[i])
             return set_err(TBA_E_ARG, "offset arrays must be non-decreasing");
-    if (stall_ints && stall_off) {
+    const bool stalls = stall_ints && stall_off;
+    if (stalls) {
         if (stall_off[0] != 0) return set_err(TBA_E_ARG, "offset arrays must start at 0");
-        for (i64 i = 0; i < n_reads; i++)
+        for (i64 i = 0; i < n_reads; i++) {
             if (stall_off[i + 1] < stall_off[i]) return set_err(TBA_E_ARG, "offset arrays must be non-decreasing");
+            // interval ends ascend (k_remove_stalls binary-searches them; the values themselves are
+            // only compared, never used as indices: identify_stalls widens past the signal ends)
+            for (i64 k = stall_off[i] + 1; k < stall_off[i + 1]; k++)
+                if (stall_ints[2 * k + 1] < stall_ints[2 * k - 1])
+                    return set_err(TBA_E_ARG, "stall interval ends must ascend");
+        }
     }
     HIP_TRY(hipSetDevice(e->device));
+    // the previous batch of this engine must be done with the buffers (and with h_rs)
+    HIP_TRY(hipStreamSynchronize(e->stream));
     e->have_batch = false;
     e->ran = false;
     e->finished = false;
     e->hp.p = *p;
     e->hp.o = *o;
     e->hp.fill_masked = (MASK_FILL_Z_SCORE - p->z_shift) + p->z_shift;
-    const i64 K = e->hp.kmer_width;
     const i64 n = n_reads;
+    if (e->h_rs.ensure((size_t)n * sizeof(ReadState)) || e->h_dp.ensure(sizeof(DevParams))) return TBA_E_NOMEM;
+    BatchSizes z;
+    if (int rc = plan_batch(p, o, e->hp.kmer_width, n, raw_off, nullptr, seq_off, nullptr, ne_override,
+                            sv_flags, stalls ? stall_off : nullptr, e->h_rs.as<ReadState>(), z))
+        return rc;
     e->n_reads = n;
-    e->h_rs.assign((size_t)n, ReadState());
-    i64 ref_acc = 0, ev_acc = 0, max_raw = 0, max_B = 0;
-    double algo_bytes = 0, cells = 0;
-    i64 moves_need = 0, max_nev = 0;
-    const int cpl_main = cpl_class(p->bandwidth);
-    for (i64 i = 0; i < n; i++) {
-        ReadState &r = e->h_rs[(size_t)i];
-        memset(&r, 0, sizeof(r));
-        r.raw_off = raw_off[i];
-        r.n_raw = raw_off[i + 1] - raw_off[i];
-        r.seq_off = seq_off[i];
-        r.seq_len = seq_off[i + 1] - seq_off[i];
-        i64 B = r.seq_len - K + 1;
-        r.ref_off = ref_acc;
-        r.seg_off = ref_acc + i;
-        r.B = B > 0 ? B : 0;
-        ref_acc += r.B;
-        r.ev_off = ev_acc;
-        r.status = TBA_OK;
-        r.sv_flags = sv_flags ? sv_flags[i] : 0;
-        if (stall_off) { r.stall_off = stall_off[i]; r.n_stall = stall_off[i + 1] - stall_off[i]; }
-        if (B <= 0 || r.n_raw <= 0) {
-            r.status = r.n_raw <= 0 ? TBA_NO_RAW : TBA_INTERNAL;
-            continue;
-        }
-        // ts.compute_num_events (tombo_stats.py:1558-1574) and the guard of resquiggle.py:1159
-        i64 num_events = std::max(r.n_raw / p->mean_obs_per_event,
-                                  (i64)((double)B * o->min_event_to_seq_ratio));
-        const bool forced = (i64)e->ne_override.size() == n && e->ne_override[(size_t)i] > 0;
-        if (forced) num_events = e->ne_override[(size_t)i]; // caller-chosen (segment_signal)
-        r.num_events = num_events; // event space is reserved for every read with B > 0
-        ev_acc += num_events;
-        if (!forced && (double)num_events / (double)p->bandwidth > (double)B) { r.status = TBA_TOO_MUCH_SIGNAL; continue; }
-        if (num_events <= 1 || r.n_raw < 4 * p->running_stat_width + 2) { r.status = TBA_INTERNAL; continue; }
-        max_raw = std::max(max_raw, r.n_raw);
-        max_B = std::max(max_B, B);
-        const i64 n_ev = num_events - 1;
-        const bool short_read = n_ev < p->start_bw + p->start_n_bases || B < p->start_n_bases;
-        // packed move rows: the adaptive band, or the whole-read static band of a short read
-        // (n_ev - mask_len cells, any width: k_dp_wide beyond the widest class)
-        i64 row_bytes = mv_row_bytes(p->bandwidth);
-        if (short_read) row_bytes = std::max(row_bytes, mv_row_bytes(n_ev));
-        moves_need += (B + 1) * row_bytes;
-        max_nev = std::max(max_nev, n_ev);
-        // algorithmic traffic (SURVEY.md 8d): raw in + seq + norm out + segs + band starts +
-        // 2-bit moves + scalars
-        algo_bytes += 8.0 * r.n_raw + (double)r.seq_len + 8.0 * r.n_raw + 8.0 * (B + 1) + 8.0 * B +
-                      (double)((B * p->bandwidth + 3) / 4) + 64.0;
-        cells += (double)B * p->bandwidth + (short_read ? 0.0 : (double)p->start_n_bases * p->start_bw);
-    }
-    e->S_tot = raw_off[n];
-    e->seq_tot = seq_off[n];
-    e->B_tot = ref_acc;
-    e->E_tot = ev_acc;
-    e->max_raw = max_raw;
-    e->max_B = max_B;
-    e->wide_w = max_nev > TBA_MAX_BAND ? ((max_nev + 63) / 64) * 64 : 0;
-    e->algo_bytes = algo_bytes;
-    e->dp_cells = cells;
-    e->any_stall = stall_off != nullptr && stall_off[n] > 0;
+    e->S_tot = z.S_tot; e->seq_tot = z.seq_tot; e->B_tot = z.B_tot; e->E_tot = z.E_tot;
+    e->max_raw = z.max_raw; e->max_B = z.max_B; e->wide_w = z.wide_w;
+    e->algo_bytes = z.algo_bytes; e->dp_cells = z.cells;
+    e->any_stall = stalls && stall_off[n] > 0;
     e->have_samp = samp_ind != nullptr;
     e->have_sv = sv_in != nullptr && sv_flags != nullptr;
-    const i64 start_w = std::max(p->start_bw, p->start_save_bw);
-    if (cpl_class(p->start_bw) == 0 || cpl_class(p->start_save_bw) == 0 || cpl_main == 0)
-        return set_err(TBA_E_ARG, "bandwidth / start bandwidth above TBA_MAX_BAND");
-    e->start_moves_stride = (p->start_n_bases + 1) * (i64)mv_class_rowb(cpl_class(start_w));
-    e->moves_arena = moves_need + moves_need / 8 + (64ll << 20);
-
-    const size_t S = (size_t)std::max<i64>(e->S_tot, 1), Bt = (size_t)std::max<i64>(e->B_tot, 1),
-                 Et = (size_t)std::max<i64>(e->E_tot, 1), N = (size_t)n;
+    e->start_moves_stride = z.start_moves_stride;
+    e->moves_arena = z.moves_arena;
+    e->skip_arena = z.skip_arena;
+    e->raw_dtype = raw_dtype;
     int rc = 0;
-    rc |= e->d_rs.ensure(N * sizeof(ReadState));
-    rc |= e->d_dp.ensure(sizeof(DevParams));
-    rc |= e->d_raw.ensure(S * 8);
-    rc |= e->d_norm.ensure(S * 8);
-    rc |= e->d_norm_out.ensure(S * 8);
-    rc |= e->d_csum.ensure((S + N) * 8);
-    rc |= e->d_score.ensure(S * 8);
-    rc |= e->d_state.ensure(S);
-    rc |= e->d_cpts.ensure(Et * 8);
-    rc |= e->d_evm.ensure(Et * 8);
-    rc |= e->d_seq.ensure((size_t)std::max<i64>(e->seq_tot, 1));
-    rc |= e->d_refm.ensure(Bt * 8);
-    rc |= e->d_refs.ensure(Bt * 8);
-    rc |= e->d_bst.ensure(Bt * 8);
-    rc |= e->d_lo.ensure(Bt * 4);
-    rc |= e->d_hi.ensure(Bt * 4);
-    rc |= e->d_readtb.ensure((Bt + N) * 8);
-    rc |= e->d_dpsegs.ensure((Bt + N) * 8);
-    rc |= e->d_segs.ensure((Bt + N) * 8);
-    rc |= e->d_win.ensure((Bt + N) * 24);
-    rc |= e->d_bm.ensure(Bt * 8);
-    rc |= e->d_absz.ensure(Bt * 8);
-    rc |= e->d_sv_in.ensure(N * 32);
-    rc |= e->d_samp.ensure(N * MAX_TS_POINTS * 8);
-    rc |= e->d_lastrow.ensure(N * TBA_MAX_BAND * 8);
-    rc |= e->d_startvals.ensure(N * (size_t)p->start_n_bases * 8);
-    rc |= e->d_smoves.ensure(N * (size_t)e->start_moves_stride);
-    rc |= e->d_moves.ensure((size_t)e->moves_arena);
-    // raw-DP scratch arena (8-byte units): windows are a few bases x tens of samples; reads that
-    // do not fit the arena get TBA_UNSUPPORTED
-    e->skip_arena = (i64)N * 32768 + (32ll << 20);
-    rc |= e->d_dscr.ensure((size_t)e->skip_arena * 8);
-    if (e->wide_w) rc |= e->d_wide.ensure((size_t)WIDE_BLOCKS * 2 * (size_t)e->wide_w * 8);
-    if (e->any_stall) rc |= e->d_stall.ensure((size_t)stall_off[n] * 16);
+    for_each_batch_buffer(e, p, o, n, z, raw_dtype, [&](DevBuf *b, size_t bytes) { rc |= b->ensure(bytes); });
     if (rc) return TBA_E_NOMEM;
 
     hipStream_t s = e->stream;
-    HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.data(), N * sizeof(ReadState), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(e->d_dp.p, &e->hp, sizeof(DevParams), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(e->d_raw.p, raw, (size_t)e->S_tot * 8, hipMemcpyHostToDevice, s));
+    const size_t N = (size_t)n;
+    memcpy(e->h_dp.p, &e->hp, sizeof(DevParams));
+    HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.p, N * sizeof(ReadState), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_dp.p, e->h_dp.p, sizeof(DevParams), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_raw.p, raw, (size_t)e->S_tot * raw_elem_bytes(raw_dtype), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(e->d_seq.p, seq, (size_t)e->seq_tot, hipMemcpyHostToDevice, s));
     if (e->have_sv) HIP_TRY(hipMemcpyAsync(e->d_sv_in.p, sv_in, N * 32, hipMemcpyHostToDevice, s));
     if (e->have_samp)
         HIP_TRY(hipMemcpyAsync(e->d_samp.p, samp_ind, N * MAX_TS_POINTS * 8, hipMemcpyHostToDevice, s));
     if (e->any_stall)
         HIP_TRY(hipMemcpyAsync(e->d_stall.p, stall_ints, (size_t)stall_off[n] * 16, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
     e->have_batch = true;
-    e->ne_override.clear();
+    return 0;
+}
+
+extern "C" int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_opts *o,
+                                int64_t n_reads, const double *raw, const int64_t *raw_off,
+                                const uint8_t *seq, const int64_t *seq_off, const double *sv_in,
+                                const int32_t *sv_flags, const int64_t *samp_ind,
+                                const int64_t *stall_ints, const int64_t *stall_off)
+{
+    int rc = tba_batch_upload_async(e, p, o, n_reads, raw, TBA_RAW_F64, raw_off, seq, seq_off, sv_in,
+                                    sv_flags, samp_ind, stall_ints, stall_off);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 
@@ -325,6 +458,14 @@ static void launch_dp(tba_engine *e, int cpl, int mode)
     }
 }
 
+// launch a kernel template instantiated for the batch's raw sample type
+#define RAW_DISPATCH(dt_, call_)                                                               \
+    do {                                                                                       \
+        if ((dt_) == TBA_RAW_I16) { typedef int16_t RT; call_; }                               \
+        else if ((dt_) == TBA_RAW_F32) { typedef float RT; call_; }                            \
+        else { typedef double RT; call_; }                                                     \
+    } while (0)
+
 static int enqueue_stages(tba_engine *e, int first, int last)
 {
     if (!e || !e->have_batch) return set_err(TBA_E_STATE, "no batch uploaded");
@@ -338,7 +479,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     const DevParams *dp = e->d_dp.as<DevParams>();
     // starting from the top discards the state of a previous run of the same batch
     if (first == 0)
-        HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.data(), (size_t)n * sizeof(ReadState), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.p, (size_t)n * sizeof(ReadState), hipMemcpyHostToDevice, s));
     const unsigned nb = (unsigned)n;
     const unsigned tpr = (unsigned)((n + 63) / 64); // blocks for thread-per-read kernels
     auto gx = [](i64 items) { i64 g = (items + 255) / 256; return (unsigned)std::min<i64>(std::max<i64>(g, 1), 128); };
@@ -348,8 +489,9 @@ static int enqueue_stages(tba_engine *e, int first, int last)
 #define ON(stage_) ((stage_) >= first && (stage_) <= last)
     const bool rna = P.use_t_test_seg != 0;
     MARK(); // 0 normalize
+    const int rdt = e->raw_dtype;
     if (ON(TBA_STAGE_SEGMENT) && !rna)
-        k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0);
+        RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0)));
     MARK(); // 1 cumsum
     const bool fused_scores = 2 * P.running_stat_width <= 64; // cumsum + scores in one kernel
     if (ON(TBA_STAGE_SEGMENT) && !rna) {
@@ -359,21 +501,21 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     MARK(); // 2 scores
     if (ON(TBA_STAGE_SEGMENT)) {
         if (!rna) { if (!fused_scores) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>()); }
-        else k_scores_ttest<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_score.as<double>());
+        else RAW_DISPATCH(rdt, (k_scores_ttest<RT><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_score.as<double>())));
     }
     MARK(); // 3 peaks
     if (ON(TBA_STAGE_SEGMENT)) {
         k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
         if (e->any_stall) k_remove_stalls<<<nb, SEL_NT, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>(), e->d_csum.as<double>());
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
-            k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_raw.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+            RAW_DISPATCH(rdt, (k_event_means<RT><<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0)));
             k_rna_event_scale<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_evm.as<double>());
-            k_normalize<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<double>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1);
+            RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1)));
         }
     }
     MARK(); // 4 event means
     if (ON(TBA_STAGE_EVENT_MEANS))
-        k_event_means<<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+        k_event_means<double><<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
     MARK(); // 5 ref levels
     if (ON(TBA_STAGE_REF_LEVELS))
         k_ref_levels<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_seq.as<uint8_t>(), e->d_kmeans.as<double>(), e->d_ksds.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>());
@@ -418,7 +560,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 13 rescale + score
     if (ON(TBA_STAGE_RESCALE)) {
-        k_rescale_absz<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
+        k_rescale_absz<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->hp.o.skip_norm_out ? nullptr : e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
         k_final_score<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, e->d_absz.as<double>());
     }
     MARK(); // 14 end
@@ -445,6 +587,7 @@ extern "C" int tba_batch_put(tba_engine *e, int what, const void *data, int64_t 
 {
     if (!e || !e->have_batch || !data) return set_err(TBA_E_STATE, "no batch uploaded");
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     const size_t N = (size_t)e->n_reads;
     auto put = [&](DevBuf &b, size_t cap_bytes) -> int {
         if ((size_t)bytes > cap_bytes) return set_err(TBA_E_ARG, "input larger than the batch buffer");
@@ -453,18 +596,24 @@ extern "C" int tba_batch_put(tba_engine *e, int what, const void *data, int64_t 
     };
     std::vector<ReadState> rs(N);
     // the first injection of a fresh batch starts from the uploaded state
-    if (!e->ran) HIP_TRY(hipMemcpy(e->d_rs.p, e->h_rs.data(), N * sizeof(ReadState), hipMemcpyHostToDevice));
+    if (!e->ran) HIP_TRY(hipMemcpy(e->d_rs.p, e->h_rs.p, N * sizeof(ReadState), hipMemcpyHostToDevice));
     e->ran = true;
     HIP_TRY(hipMemcpy(rs.data(), e->d_rs.p, N * sizeof(ReadState), hipMemcpyDeviceToHost));
     int rc = 0;
     switch (what) {
     case TBA_PUT_VALID_CPTS: // per_read[i] = number of change points of read i
         if (!per_read) return set_err(TBA_E_ARG, "per_read counts required");
-        rc = put(e->d_cpts, (size_t)e->E_tot * 8);
-        for (size_t i = 0; i < N && !rc; i++) {
+        // the kernels index the signal with these values: strictly increasing inside [0, n_raw]
+        for (size_t i = 0; i < N; i++) {
             if (per_read[i] > rs[i].num_events || per_read[i] < 2) return set_err(TBA_E_ARG, "change point count outside the reserved space");
-            rs[i].n_cpts = per_read[i]; rs[i].n_ev = per_read[i] - 1;
+            if ((size_t)(rs[i].ev_off + per_read[i]) * 8 > (size_t)bytes) return set_err(TBA_E_ARG, "change point array shorter than the counts");
+            const i64 *c = (const i64 *)data + rs[i].ev_off;
+            for (i64 k = 0; k < per_read[i]; k++)
+                if (c[k] < 0 || c[k] > rs[i].n_raw || (k > 0 && c[k] <= c[k - 1]))
+                    return set_err(TBA_E_ARG, "change points must be strictly increasing inside [0, n_raw]");
         }
+        rc = put(e->d_cpts, (size_t)e->E_tot * 8);
+        for (size_t i = 0; i < N && !rc; i++) { rs[i].n_cpts = per_read[i]; rs[i].n_ev = per_read[i] - 1; }
         break;
     case TBA_PUT_EVENT_MEANS: rc = put(e->d_evm, (size_t)e->E_tot * 8); break;
     case TBA_PUT_NORM: rc = put(e->d_norm, (size_t)e->S_tot * 8); break;
@@ -472,11 +621,19 @@ extern "C" int tba_batch_put(tba_engine *e, int what, const void *data, int64_t 
     case TBA_PUT_REF_SDS: rc = put(e->d_refs, (size_t)e->B_tot * 8); break;
     case TBA_PUT_DP_SEGS: // per_read[2i] = read_start_rel_to_raw, per_read[2i+1] = trimmed signal length
         if (!per_read) return set_err(TBA_E_ARG, "per_read (read_start, norm_len) required");
+        if ((size_t)bytes < (size_t)(e->B_tot + e->n_reads) * 8) return set_err(TBA_E_ARG, "segment array shorter than the batch");
+        for (size_t i = 0; i < N; i++) { // boundaries index the signal: non-decreasing inside [0, norm_len]
+            const i64 rstart = per_read[2 * i], nl = per_read[2 * i + 1];
+            if (rstart < 0 || nl < 0 || rstart + nl > rs[i].n_raw) return set_err(TBA_E_ARG, "segments outside the signal");
+            const i64 *sg = (const i64 *)data + rs[i].seg_off;
+            for (i64 k = 0; k <= rs[i].B; k++)
+                if (sg[k] < 0 || sg[k] > nl || (k > 0 && sg[k] < sg[k - 1]))
+                    return set_err(TBA_E_ARG, "segment boundaries must be non-decreasing inside [0, norm_len]");
+        }
         rc = put(e->d_dpsegs, (size_t)(e->B_tot + e->n_reads) * 8);
         for (size_t i = 0; i < N && !rc; i++) {
             rs[i].read_start = rs[i].dp_read_start = per_read[2 * i];
             rs[i].norm_len = per_read[2 * i + 1];
-            if (rs[i].read_start < 0 || rs[i].read_start + rs[i].norm_len > rs[i].n_raw) return set_err(TBA_E_ARG, "segments outside the signal");
         }
         break;
     case TBA_PUT_START_STATE: // per_read[i]: 4 = force the static whole-read path
@@ -516,7 +673,10 @@ extern "C" int tba_batch_download(tba_engine *e, int32_t *status, int64_t *segs,
                                   double *sig_match_score, int32_t *norm_params_changed)
 {
     if (!e || !e->ran) return set_err(TBA_E_STATE, "no batch has been run");
+    if (norm_signal && e->hp.o.skip_norm_out)
+        return set_err(TBA_E_STATE, "the batch was run with skip_norm_out: there is no normalised signal to download");
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     const size_t N = (size_t)e->n_reads;
     std::vector<ReadState> rs(N);
     HIP_TRY(hipMemcpy(rs.data(), e->d_rs.p, N * sizeof(ReadState), hipMemcpyDeviceToHost));
@@ -538,10 +698,69 @@ extern "C" int tba_batch_download(tba_engine *e, int32_t *status, int64_t *segs,
     return 0;
 }
 
+// per-read records + int32 boundaries, packed on the device so that the download is a few
+// contiguous copies (grid: (blocks, reads))
+__global__ __launch_bounds__(256) void k_pack_results(const ReadState *rs, const i64 *segs,
+    tba_read_result *res, i32 *segs32)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        tba_read_result o;
+        o.status = r.status; o.norm_params_changed = r.changed;
+        o.read_start_rel_to_raw = r.read_start;
+        o.norm_len = r.status == TBA_OK ? r.norm_len : 0;
+        o.shift = r.shift; o.scale = r.scale;
+        o.lower_lim = r.has_lims ? r.lower : NAN;
+        o.upper_lim = r.has_lims ? r.upper : NAN;
+        o.sig_match_score = r.score;
+        res[blockIdx.y] = o;
+    }
+    if (segs32 == nullptr) return;
+    const i64 *sg = segs + r.seg_off;
+    i32 *o32 = segs32 + r.seg_off;
+    const bool ok = r.status == TBA_OK;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i <= r.B; i += (i64)gridDim.x * 256)
+        o32[i] = ok ? (i32)sg[i] : 0;
+}
+
+extern "C" int tba_batch_download_async(tba_engine *e, tba_read_result *results, int32_t *segs32,
+                                        int64_t *segs64, double *norm_signal)
+{
+    if (!e || !e->ran) return set_err(TBA_E_STATE, "no batch has been run");
+    if (norm_signal && e->hp.o.skip_norm_out)
+        return set_err(TBA_E_STATE, "the batch was run with skip_norm_out: there is no normalised signal to download");
+    if (segs32 && e->max_raw > 0x7fffffffll) return set_err(TBA_E_ARG, "signal too long for int32 boundaries");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const size_t N = (size_t)e->n_reads;
+    const unsigned gB = (unsigned)std::min<i64>(std::max<i64>((e->max_B + 1 + 255) / 256, 1), 64);
+    if (results || segs32) {
+        k_pack_results<<<dim3(segs32 ? gB : 1, (unsigned)N), 256, 0, s>>>(e->d_rs.as<ReadState>(),
+            e->d_segs.as<i64>(), e->d_res.as<tba_read_result>(), segs32 ? e->d_segs32.as<i32>() : nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    if (results) HIP_TRY(hipMemcpyAsync(results, e->d_res.p, N * sizeof(tba_read_result), hipMemcpyDeviceToHost, s));
+    if (segs32) HIP_TRY(hipMemcpyAsync(segs32, e->d_segs32.p, (size_t)(e->B_tot + e->n_reads) * 4, hipMemcpyDeviceToHost, s));
+    if (segs64) HIP_TRY(hipMemcpyAsync(segs64, e->d_segs.p, (size_t)(e->B_tot + e->n_reads) * 8, hipMemcpyDeviceToHost, s));
+    if (norm_signal) HIP_TRY(hipMemcpyAsync(norm_signal, e->d_norm_out.p, (size_t)e->S_tot * 8, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+extern "C" int tba_batch_query(tba_engine *e)
+{
+    if (!e) return set_err(TBA_E_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    const hipError_t rc = hipStreamQuery(e->stream);
+    if (rc == hipSuccess) return 0;
+    if (rc == hipErrorNotReady) return 1;
+    return set_err(TBA_E_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(rc));
+}
+
 extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_bytes)
 {
     if (!e || !e->ran || !out) return set_err(TBA_E_STATE, "no batch has been run");
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     const size_t N = (size_t)e->n_reads;
     auto copy = [&](const DevBuf &b, size_t bytes) -> int {
         if ((size_t)out_bytes < bytes) return set_err(TBA_E_ARG, "output buffer too small");
@@ -598,7 +817,7 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
                                : (k == 0 ? rs[i].shift : k == 1 ? rs[i].scale : k == 2 ? rs[i].lower : rs[i].upper);
         return 0;
     }
-    if (what == 99) { // debug: phase cycle counters
+    if (what == TBA_GET_DEBUG_COUNTERS) { // phase cycle / sweep counters of a profiling build
         if ((size_t)out_bytes < N * 64) return set_err(TBA_E_ARG, "output buffer too small");
         for (size_t i = 0; i < N; i++) memcpy((char *)out + 64 * i, rs[i].dbg, 64);
         return 0;
@@ -626,7 +845,8 @@ extern "C" int tba_batch_base_stats(tba_engine *e, double *means, double *stds, 
     double *d_m = e->d_stat.as<double>(), *d_s = d_m + e->B_tot;
     const unsigned gB = (unsigned)std::min<i64>(std::max<i64>((e->max_B + 255) / 256, 1), 128);
     k_base_stats<<<dim3(gB, (unsigned)e->n_reads), 256, 0, e->stream>>>(e->d_rs.as<ReadState>(),
-        e->d_norm_out.as<double>(), e->d_segs.as<i64>(), d_m, d_s);
+        e->d_dp.as<DevParams>(), e->hp.o.skip_norm_out ? nullptr : e->d_norm_out.as<double>(),
+        e->d_norm.as<double>(), e->d_segs.as<i64>(), d_m, d_s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(means, d_m, (size_t)e->B_tot * 8, hipMemcpyDeviceToHost));
@@ -730,6 +950,10 @@ extern "C" int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pas
         return set_err(TBA_E_ARG, "bad arguments");
     const int cpl = cpl_class(bandwidth);
     if (!cpl) return TBA_UNSUPPORTED;
+    if (n_events < 1) return set_err(TBA_E_ARG, "no events");
+    for (i64 i = 0; i < start_seq_pos; i++) // the given (static) rows' band starts index the events
+        if (event_starts[i] < 0 || event_starts[i] >= n_events || (i > 0 && event_starts[i] < event_starts[i - 1]))
+            return set_err(TBA_E_ARG, "event_starts must be non-decreasing inside [0, n_events)");
     HIP_TRY(hipSetDevice(e->device));
     Tmp d_ev, d_mu, d_sd, d_st, d_init;
     if (d_ev.alloc((size_t)n_events * 8) || d_mu.alloc((size_t)n_bases * 8) ||
@@ -761,6 +985,9 @@ extern "C" int tba_c_banded_forward_pass(tba_engine *e, const double *shifted_z_
         return set_err(TBA_E_ARG, "bad arguments");
     const int cpl = cpl_class(bandwidth);
     if (!cpl) return TBA_UNSUPPORTED;
+    for (i64 i = 0; i < n_bases; i++)
+        if (event_starts[i] < 0 || (i > 0 && event_starts[i] < event_starts[i - 1]))
+            return set_err(TBA_E_ARG, "event_starts must be non-negative and non-decreasing");
     HIP_TRY(hipSetDevice(e->device));
     Tmp d_z, d_st;
     if (d_z.alloc((size_t)n_bases * bandwidth * 8) || d_st.alloc((size_t)n_bases * 8))
@@ -891,7 +1118,7 @@ static int c_valid_cpts(tba_engine *e, const double *sig, int64_t n, int64_t min
         k_cumsum<<<1, 64, 0, s>>>(d_rs.as<ReadState>(), 1, d_sig.as<double>(), d_csum.as<double>());
         k_scores_dna<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_csum.as<double>(), d_score.as<double>());
     } else {
-        k_scores_ttest<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
+        k_scores_ttest<double><<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
     }
     k_peaks<<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_score.as<double>(),
                                  d_state.as<unsigned char>(), d_csum.as<double>(), d_cpts.as<i64>(), ttest);

@@ -25,13 +25,17 @@ __all__ = ['resquiggle_read', 'resquiggle_batch', 'resquiggle_batch_iters', 'adj
 _ENGINES = {}
 
 
+def default_device():
+    """$LOCAL_RANK (one process per GPU) modulo the visible devices, else 0"""
+    device = int(os.environ.get('LOCAL_RANK', '0'))
+    n = _native.lib().tba_device_count()
+    return device % n if n > 0 else device
+
+
 def get_engine(device=None):
     """Process-wide engine for `device` (default: $LOCAL_RANK or 0): one process per GPU."""
     if device is None:
-        device = int(os.environ.get('LOCAL_RANK', '0'))
-        n = _native.lib().tba_device_count()
-        if n > 0:
-            device %= n
+        device = default_device()
     if device not in _ENGINES:
         _ENGINES[device] = _native.Engine(device)
     return _ENGINES[device]
@@ -48,23 +52,51 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                      min_event_to_seq_ratio=MIN_EVENT_TO_SEQ_RATIO, const_scale=None,
                      skip_seq_scaling=False,
                      seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False),
-                     samp_inds=None, engine=None, return_debug=False):
+                     samp_inds=None, engine=None, return_debug=False, mem_budget=None):
     """resquiggle_read over a list of `resquiggleResults` (mapping results).
 
     Returns a list with, per read, either a `resquiggleResults` or a `TomboError` instance
     (same message the reference raises).  `samp_inds[i]`: optional precomputed Theil-Sen
     subsample for read i (1000 indices); when omitted it is drawn from numpy's global RNG in
     read order for every read longer than 1000 bases.
+
+    A list of any size is accepted: when its device footprint (`tba_batch_footprint`) exceeds
+    `mem_budget` bytes (default: 60 % of the device memory that is free right now) the list is
+    cut into consecutive sub-batches that fit and the results are returned in input order.
     """
     eng = get_engine() if engine is None else engine
     n = len(map_results)
     if n == 0:
         return []
-    if eng.kmer_width != std_ref.kmer_width or getattr(eng, '_model_id', None) != id(std_ref):
-        eng.set_model(std_ref.level_means, std_ref.level_sds, std_ref.kmer_width,
-                      std_ref.central_pos)
-        eng._model_id = id(std_ref)
+    eng.ensure_model(std_ref)
     K = std_ref.kmer_width
+    if n > 1 and not return_debug:
+        from . import planner
+        if mem_budget is None:
+            mem_budget = 0.6 * eng.device_mem()[0]
+        p_ = _native.make_params(rsqgl_params)
+        o_ = _native.make_opts(min_event_to_seq_ratio=min_event_to_seq_ratio)
+        n_raw = [0 if (mr.raw_signal if all_raw_signals is None or all_raw_signals[i] is None
+                       else all_raw_signals[i]) is None else
+                 len(mr.raw_signal if all_raw_signals is None or all_raw_signals[i] is None
+                     else all_raw_signals[i]) for i, mr in enumerate(map_results)]
+        seq_len = [len(mr.genome_seq) for mr in map_results]
+        if planner.exact_bytes(n_raw, seq_len, p_, o_, K) > mem_budget:
+            # consecutive cuts (sort=False): the Theil-Sen subsamples are drawn from the global
+            # RNG in read order, exactly as for one big batch
+            parts = planner.plan_batches(n_raw, seq_len, p_, o_, K, mem_budget, sort=False)
+            out = []
+            for idx in parts:
+                a, b = int(idx[0]), int(idx[-1]) + 1
+                out.extend(resquiggle_batch(
+                    map_results[a:b], std_ref, rsqgl_params, outlier_thresh=outlier_thresh,
+                    all_raw_signals=None if all_raw_signals is None else all_raw_signals[a:b],
+                    max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
+                    const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
+                    seq_samp_type=seq_samp_type,
+                    samp_inds=None if samp_inds is None else samp_inds[a:b], engine=eng,
+                    mem_budget=float('inf')))
+            return out
     raws, seqs = [], []
     pre_err = [None] * n
     sv_in = np.zeros((n, 4))
@@ -77,7 +109,11 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
         if raw is None:
             pre_err[i] = th.TomboError(errors.MESSAGES[21])
             raw = np.zeros(1)
-        raws.append(np.ascontiguousarray(raw, dtype=np.float64))
+        # int16 DAC (the FAST5 `Signal`) and float32 go to the device as they are; the engine
+        # widens them to float64 exactly
+        raw = np.asarray(raw)
+        raws.append(np.ascontiguousarray(
+            raw, dtype=raw.dtype if raw.dtype in _native.RAW_DTYPES else np.float64))
         codes = ts.encode_seq(mr.genome_seq)
         seqs.append(codes)
         if mr.scale_values is not None:
@@ -180,10 +216,7 @@ def resquiggle_read(map_res, std_ref, rsqgl_params, outlier_thresh=None, all_raw
 # stage's inputs instead of recomputing the earlier stages (include/tombo_amd.h, "stepwise
 # execution").
 def _set_model(eng, std_ref):
-    if eng.kmer_width != std_ref.kmer_width or getattr(eng, '_model_id', None) != id(std_ref):
-        eng.set_model(std_ref.level_means, std_ref.level_sds, std_ref.kmer_width,
-                      std_ref.central_pos)
-        eng._model_id = id(std_ref)
+    eng.ensure_model(std_ref)
 
 
 def _status_or_raise(eng):

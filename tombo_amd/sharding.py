@@ -1,87 +1,142 @@
-"""Multi-GPU sharding of the resquiggle path: reads are independent, so the only shared state is
-a host-side work queue of batches.  One process per GPU (torch.distributed launch: RANK /
-LOCAL_RANK / WORLD_SIZE); each process owns one engine and pulls batch indices from an atomic
-counter in the process group's key-value store -- no collective on the data path.
-Results are gathered to rank 0 with gather_object (control plane only).
+"""Multi-GPU sharding of a resquiggle job: one process per GPU, batches pulled from a shared
+work queue, no collective on the data path.
 
-Replaces the reference's `resquiggle_all_reads` worker pool (resquiggle.py:1859-1950,
-multiprocessing pipes/queues) for the compute part only; FAST5 I/O and mapping stay outside.
+The reference shards reads over worker processes through multiprocessing queues
+(`resquiggle_all_reads`, tombo/resquiggle.py:1859-1950: a filler process enqueues reads, N
+`_resquiggle_worker`s pull them one at a time).  Reads are independent, so here the unit of work
+is a *batch* of reads (one pass of the HIP pipeline) and the queue is a single shared counter:
+every rank atomically draws the next batch index until the job is exhausted.  Dynamic
+assignment -- not a static split -- because batches differ in cost (read lengths) and GPUs in
+speed.  A rank only ever materialises the batches it drew (`load_batch(b)` reads / generates
+them); results stay on the rank that produced them unless a `sink` ships them elsewhere.
+
+The counter lives in a `torch.distributed.TCPStore` of its own (public API; rank 0 hosts it on a
+free port that it announces through the default process group).  Without an initialised process
+group (world size 1) the queue is a plain local counter.
 """
 import os
+import socket
+
+__all__ = ['BatchQueue', 'split_batches', 'run_sharded', 'resquiggle_sharded']
+
+_STORE = None      # this process' connection to the queue store
+_N_QUEUES = 0      # queues created so far (same order on every rank -> same key)
 
 
-class BatchQueue(object):
-    """Dynamic work queue over `n_batches` batch indices shared by all ranks."""
+def _dist():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    return dist if dist.is_available() and dist.is_initialized() else None
 
-    def __init__(self, n_batches, store=None, key='tombo_amd/next_batch'):
-        self.n_batches = int(n_batches)
-        self.key = key
-        self.store = store
-        self._local = 0
 
-    def next(self):
-        if self.store is None:          # single process
-            i = self._local
-            self._local += 1
-        else:
-            i = self.store.add(self.key, 1) - 1
-        return i if i < self.n_batches else None
-
-    def __iter__(self):
-        while True:
-            i = self.next()
-            if i is None:
-                return
-            yield i
+def _queue_store():
+    """TCPStore shared by all ranks of the default process group (created on first use)"""
+    global _STORE
+    if _STORE is not None:
+        return _STORE
+    import torch.distributed as dist
+    from datetime import timedelta
+    rank, world = dist.get_rank(), dist.get_world_size()
+    host = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = [0]
+    if rank == 0:
+        s = socket.socket()
+        s.bind(('', 0))
+        port[0] = s.getsockname()[1]
+        s.close()
+    dist.broadcast_object_list(port, src=0)
+    _STORE = dist.TCPStore(host, int(port[0]), world, is_master=(rank == 0),
+                           timeout=timedelta(seconds=300), wait_for_workers=False)
+    dist.barrier()
+    return _STORE
 
 
 def split_batches(n_reads, batch_size):
-    """[(lo, hi), ...] contiguous read ranges of at most batch_size reads"""
-    return [(lo, min(lo + batch_size, n_reads)) for lo in range(0, n_reads, batch_size)]
+    """[(start, stop), ...] fixed-size batches over range(n_reads)"""
+    return [(a, min(a + batch_size, n_reads)) for a in range(0, n_reads, batch_size)]
 
 
-def default_store():
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return None
-    from torch.distributed import distributed_c10d
-    return distributed_c10d._get_default_store()
+class BatchQueue(object):
+    """Iterator over the batch indices this rank draws from the shared counter.
+
+    Every rank must construct its queues in the same order (the n-th queue of a process talks to
+    the n-th counter); a counter is used once, so calling the same job function twice never sees
+    a stale, already exhausted counter."""
+
+    def __init__(self, n_batches, key=None):
+        global _N_QUEUES
+        self.n_batches = int(n_batches)
+        self._dist = _dist()
+        self._local = 0
+        self.drawn = []
+        if self._dist is not None and self._dist.get_world_size() > 1:
+            self._store = _queue_store()
+            self._key = 'tombo_amd/queue/%d/%s' % (_N_QUEUES, key if key is not None else '')
+            _N_QUEUES += 1
+        else:
+            self._store = None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._store is None:
+            b = self._local
+            self._local += 1
+        else:
+            b = self._store.add(self._key, 1) - 1   # atomic fetch-and-add on the store
+        if b >= self.n_batches:
+            raise StopIteration
+        self.drawn.append(b)
+        return b
 
 
-def resquiggle_sharded(map_results, process_batch, batch_size=2048, gather=True, queue_key=None):
-    """Run `process_batch(list_of_map_results) -> list_of_results` over all reads, batches pulled
-    dynamically by every rank.  Returns the full ordered result list on rank 0 (None elsewhere)
-    when `gather`, else {batch_index: results} of this rank.
+def run_sharded(n_batches, load_batch, process_batch, sink=None, queue_key=None):
+    """Process batches 0..n_batches-1 across the ranks of the default process group.
 
-    With the engine: process_batch = lambda mrs: resquiggle_batch(mrs, std_ref, params, ...).
+    load_batch(b)           -> the batch (only called on the rank that drew b)
+    process_batch(batch)    -> its result
+    sink(b, result)         -> consume / ship the result (default: keep it)
+    Returns {b: result} of the batches this rank processed (empty values when a sink took them).
     """
-    import torch.distributed as dist
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    ranges = split_batches(len(map_results), batch_size)
-    key = queue_key or 'tombo_amd/next_batch/%d' % len(map_results)
-    q = BatchQueue(len(ranges), default_store() if distributed else None, key)
-    mine = {}
-    for b in q:
-        lo, hi = ranges[b]
-        mine[b] = process_batch(map_results[lo:hi])
-    if not gather:
-        return mine
-    if not distributed:
-        parts = [mine]
-    else:
-        parts = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
-        dist.gather_object(mine, parts, dst=0)
-        if dist.get_rank() != 0:
-            return None
-    merged = {}
-    for p in parts:
-        merged.update(p)
-    out = []
-    for b in range(len(ranges)):
-        out.extend(merged[b])
+    out = {}
+    for b in BatchQueue(n_batches, key=queue_key):
+        res = process_batch(load_batch(b))
+        if sink is not None:
+            sink(b, res)
+            res = None
+        out[b] = res
     return out
 
 
-def local_device():
-    """HIP ordinal of this process (one process per GPU)."""
-    return int(os.environ.get('LOCAL_RANK', '0'))
+def resquiggle_sharded(map_results, process_batch, batch_size=4096, gather=True, queue_key=None):
+    """List-based convenience form (small jobs, tests): `map_results` is the full read list,
+    known to every rank; `process_batch(list_of_reads) -> list_of_results`.
+
+    gather=True:  rank 0 returns the ordered result list (others None); the per-batch results
+                  travel as pickled objects, which is fine for boundaries of a few thousand reads
+                  and wrong for a million -- large jobs use `run_sharded` with a sink.
+    gather=False: every rank returns {batch_index: results} of its own batches.
+    """
+    batches = split_batches(len(map_results), batch_size)
+    mine = run_sharded(len(batches), lambda b: map_results[batches[b][0]:batches[b][1]],
+                       process_batch, queue_key=queue_key)
+    if not gather:
+        return mine
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return [r for b in range(len(batches)) for r in mine[b]]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)
+    if rank != 0:
+        return None
+    merged = {}
+    for part in gathered:
+        merged.update(part)
+    missing = [b for b in range(len(batches)) if b not in merged]
+    if missing:
+        raise RuntimeError('work queue lost batches %r' % (missing,))
+    return [r for b in range(len(batches)) for r in merged[b]]
