@@ -112,49 +112,60 @@ def cpu_model():
     return 'unknown'
 
 
+_CPU_CTX = {}
+
+
+def _cpu_one(i):
+    """one read through the oracle (forked worker processes see _CPU_CTX copy-on-write)"""
+    import oracle
+    c = _CPU_CTX
+    r = oracle.resquiggle_read(c['raws'][i], c['seqs'][i], c['means'], c['sds'], c['p'], c['o'],
+                               stall_ints=c['st'][i], samp_ind=c['sis'].get(i))
+    return r['status'] == 0
+
+
 def cpu_baseline(seqs, raws, params, model, n_bases, samp_name, stalls, n_single, n_per_core):
     """The CPU restatement (oracle/, kind "port") on bounded samples of the same workload: one
-    thread, then one thread per host core (the oracle's C entry point holds no global state and
-    ctypes releases the GIL).  Reported baseline only; the oracle is never on the measured path."""
+    process, then one process per host core (forked before any HIP state exists; threads under a
+    profiler, where forking deadlocks).  Reported baseline only; the oracle is never on the
+    measured path."""
     import oracle
-    from concurrent.futures import ThreadPoolExecutor
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
-    p = oracle.make_params(params)
-    o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
-                         sig_match_thresh=SIG_MATCH_THRESH[samp_name])
-    st = stalls if stalls is not None else [None] * len(raws)
-    sis = {}
-    rng = np.random.RandomState(7)
-
-    def samp(i):
-        nb = int(n_bases[i])
-        if nb > 1000 and i not in sis:
-            sis[i] = rng.choice(nb, 1000, replace=False)
-        return sis.get(i)
-
-    def one(i):
-        r = oracle.resquiggle_read(raws[i], seqs[i], model.level_means, model.level_sds, p, o,
-                                   stall_ints=st[i], samp_ind=sis.get(i))
-        return r['status'] == 0
     n1 = min(n_single, len(raws))
     cores = os.cpu_count() or 1
     nall = min(max(n_per_core * cores, cores), len(raws)) if cores > 1 else 0
-    for i in range(max(n1, nall)):
-        samp(i)
-    one(0)  # page in
+    rng = np.random.RandomState(7)
+    sis = {i: rng.choice(int(n_bases[i]), 1000, replace=False)
+           for i in range(max(n1, nall)) if n_bases[i] > 1000}
+    _CPU_CTX.update(raws=raws, seqs=seqs, means=model.level_means, sds=model.level_sds,
+                    p=oracle.make_params(params),
+                    o=oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
+                                       sig_match_thresh=SIG_MATCH_THRESH[samp_name]),
+                    st=stalls if stalls is not None else [None] * len(raws), sis=sis)
+    _cpu_one(0)  # page in
     t0 = time.perf_counter()
-    ok1 = sum(one(i) for i in range(n1))
+    ok1 = sum(_cpu_one(i) for i in range(n1))
     dt1 = time.perf_counter() - t0
     legs = [dict(value=round(n1 / dt1, 3), unit='reads/s', cores=1, kind='port',
                  sample='%d of the same reads through oracle/ (C restatement, 1 thread), %d ok' % (n1, ok1))]
     if cores > 1:
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            okn = sum(ex.map(one, range(nall)))
-        dtn = time.perf_counter() - t0
+        if _under_profiler():
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(cores) as ex:
+                t0 = time.perf_counter()
+                okn = sum(ex.map(_cpu_one, range(nall)))
+                dtn = time.perf_counter() - t0
+        else:
+            import multiprocessing as mp
+            with mp.get_context('fork').Pool(cores) as pool:
+                pool.map(_cpu_one, range(cores))      # workers up, library paged in
+                t0 = time.perf_counter()
+                okn = sum(pool.map(_cpu_one, range(nall), chunksize=1))
+                dtn = time.perf_counter() - t0
         legs.append(dict(value=round(nall / dtn, 3), unit='reads/s', cores=cores, kind='port',
-                         sample='%d of the same reads through oracle/, %d threads (one per host '
-                                'core), %d ok' % (nall, cores, okn)))
+                         sample='%d of the same reads through oracle/, %d worker processes (one per '
+                                'host core incl. SMT), %d ok' % (nall, cores, okn)))
+    _CPU_CTX.clear()
     return legs
 
 
@@ -456,7 +467,7 @@ def main():
         # warm-up: every slot sees the largest batch once (buffers sized, code paged in); the
         # transfer rate of one isolated upload is taken on the way
         big = max(range(len(pool)), key=lambda k: in_bytes[k])
-        for _ in range(a.slots):
+        for _ in range(2 * a.slots):   # both output sets of every slot get their pinned arrays
             pipe.submit(pool[big])
         pipe.flush()
         eng0 = pipe.slots[0].eng
@@ -470,16 +481,21 @@ def main():
         queue = sharding.BatchQueue(n_stream)
         barrier()
         t0 = time.perf_counter()
-        cnt = dict(reads=0, ok=0, out=0, moved=0)
+        cnt = dict(reads=0, ok=0, out=0, moved=0, submit_s=0.0, nb=0)
+        est = np.zeros(32)
 
         def consume(res):
             cnt['reads'] += res.n
+            cnt['nb'] += 1
+            est[:] += res.stage_ms
             cnt['ok'] += int((res.results['status'] == 0).sum())
             cnt['out'] += res.results.nbytes + res.segs.nbytes + (0 if res.norm is None else res.norm.nbytes)
         for b in queue:
             k = b % len(pool)
             cnt['moved'] += in_bytes[k]
+            ts0 = time.perf_counter()
             done = pipe.submit(pool[k])
+            cnt['submit_s'] += time.perf_counter() - ts0
             if done is not None:
                 consume(done)
         for done in pipe.flush():
@@ -500,6 +516,9 @@ def main():
             'in_GB_per_10k_reads': round(cnt['moved'] / max(cnt['reads'], 1) * 1e4 / 1e9, 3),
             'out_GB_per_10k_reads': round(cnt['out'] / max(cnt['reads'], 1) * 1e4 / 1e9, 3),
             'h2d_GBps': round(in_bytes[big] / th2d / 1e9, 2),
+            'host_s_in_submit': round(cnt['submit_s'], 4),
+            'stage_ms_per_batch': {k: round(float(v) / max(cnt['nb'], 1), 3) for k, v in
+                                   zip(_native.STAGE_NAMES, est[:16]) if v > 0},
             'pinned_pool_build_s': round(t_pin, 2)}
         pipe.close()
 

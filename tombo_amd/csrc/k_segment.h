@@ -608,13 +608,26 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     const i64 need_eq = num_cpts - c_gt;
     i64 before = a_gt;    // rank of the last pick in the argsort order
     if (need_eq < c_eq || a_eq > 1) {
-        // exact ties on the threshold score (never with continuous input): priority falls to
-        // the higher index; resolve sequentially, recount, and redo the compaction
-        if (tid == 0) {
-            i64 thr = 0, left = need_eq;
-            for (i64 p = ns - 1; p >= 0; p--)
-                if (st[p] == 1 && s[p] == tval) { thr = p; if (--left == 0) break; }
-            s_idx_thr = thr;
+        // exact ties on the threshold score (the rule on quantised DAC input, never with continuous
+        // pA): priority falls to the higher index, so the picks at the threshold score are the
+        // need_eq highest-index taken positions with that score.  Every thread counts them in a
+        // contiguous slice; a suffix sum over the slices finds the slice holding the need_eq-th
+        // from the top, whose owner walks it backwards.
+        const i64 chunk = (ns + SEL_NT - 1) / SEL_NT;
+        const i64 p0 = (i64)tid * chunk, p1 = p0 + chunk < ns ? p0 + chunk : ns;
+        i64 mine = 0;
+        for (i64 p = p0; p < p1; p++) mine += st[p] == 1 && s[p] == tval;
+        i64 *cnts = (i64 *)sm.raw8; // SEL_NT counts (the select scratch is idle here)
+        __syncthreads();
+        cnts[tid] = mine;
+        if (tid == 0) s_idx_thr = 0;
+        __syncthreads();
+        i64 above = 0; // ties in the slices above mine
+        for (int t = tid + 1; t < SEL_NT; t++) above += cnts[t];
+        if (mine > 0 && above < need_eq && need_eq <= above + mine) {
+            i64 left = need_eq - above;
+            for (i64 p = p1 - 1; p >= p0; p--)
+                if (st[p] == 1 && s[p] == tval && --left == 0) { s_idx_thr = p; break; }
         }
         __syncthreads();
         const i64 idx_thr = s_idx_thr; // lowest-index pick at the threshold score

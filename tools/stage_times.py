@@ -1,0 +1,68 @@
+"""Per-stage GPU time of one resident batch (development aid).
+
+    python tools/stage_times.py [--reads N] [--bases B] [--bandwidth W] [--dac] [--dtype i16|f32|f64]
+                                [--rna] [--repeat K]
+
+--dac quantises the synthetic pA to int16 DAC values first (tie-heavy change-point scores);
+--dtype picks the sample type handed to the engine."""
+import os
+import sys
+import argparse
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reads', type=int, default=4096)
+    ap.add_argument('--bases', type=int, default=10000)
+    ap.add_argument('--bandwidth', type=int, default=500)
+    ap.add_argument('--dac', action='store_true')
+    ap.add_argument('--dtype', default='f64')
+    ap.add_argument('--rna', action='store_true')
+    ap.add_argument('--repeat', type=int, default=3)
+    ap.add_argument('--skip-norm-out', action='store_true')
+    a = ap.parse_args()
+    from tombo_amd import _native, tombo_stats as ts, tombo_helper as th
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    sn = 'RNA' if a.rna else 'DNA'
+    samp = th.seqSampleType(sn, a.rna)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=a.bandwidth)
+    if a.bandwidth <= 100:
+        params = params._replace(band_bound_thresh=10)
+    bases = np.full(a.reads, a.bases, np.int64)
+    seqs, raws, stalls, dacs, stalls_dac = bench.make_reads(bases, 1000003, min(32, os.cpu_count() or 8), sn, a.dac)
+    src, st = (dacs, stalls_dac) if a.dac else (raws, stalls)
+    dt = {'i16': np.int16, 'f32': np.float32, 'f64': np.float64}[a.dtype]
+    src = [r.astype(dt) for r in src]
+    rng = np.random.RandomState(1)
+    si = np.stack([rng.choice(a.bases, 1000, replace=False) for _ in range(a.reads)]) if a.bases > 1000 else None
+    eng = _native.Engine(0)
+    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+    eng.upload(_native.make_params(params),
+               _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[sn],
+                                 skip_norm_out=a.skip_norm_out),
+               src, seqs, samp_ind=si, stall_ints=st if a.rna else None)
+    eng.run()
+    acc = np.zeros(32)
+    for _ in range(a.repeat):
+        eng.run()
+        acc += eng.get(_native.GET_KERNEL_MS)
+    acc /= a.repeat
+    out = eng.download(want_norm=False)
+    print('reads %d bases %d W %d dac %s dtype %s: ok %d' % (a.reads, a.bases, a.bandwidth, a.dac, a.dtype,
+                                                           int((out['status'] == 0).sum())))
+    print('  '.join('%s %.2f' % (k, v) for k, v in zip(_native.STAGE_NAMES, acc[:16]) if v > 0.004))
+    path = eng.get(_native.GET_PATH)
+    print('start calls: %s' % np.bincount(path[:, 3], minlength=3).tolist())
+    if os.environ.get('TBA_DBG_PHASES'):
+        d = eng.get(_native.GET_DEBUG_COUNTERS)
+        print('dbg mean', ' '.join('%.0f' % x for x in d.mean(axis=0)))
+
+
+if __name__ == '__main__':
+    main()
