@@ -297,6 +297,9 @@ def main():
                          'out, or skipped')
     ap.add_argument('--stream-batch', type=int, default=4096, help='reads per streamed batch')
     ap.add_argument('--slots', type=int, default=3, help='engine slots per GPU of the streaming pipeline')
+    ap.add_argument('--resident-split', type=int, default=1,
+                    help='resident phase: cut the batch into this many sub-batches, each on its own '
+                         'engine / stream (kernels of different sub-batches overlap)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes behind roofline.traffic')
     ap.add_argument('--pmc-reads', type=int, default=1024, help='reads of the counter passes')
     ap.add_argument('--pmc-child', default=None, help=argparse.SUPPRESS)
@@ -313,10 +316,17 @@ def main():
     elif a.preset == 'cfg4':
         samp_name, a.bases, a.bandwidth = 'RNA', 3000, 500
     longtail = a.preset == 'longtail'
+    if longtail and a.reads == 10000:
+        a.reads = 16000   # enough work per pass to hide the serial time of a 100 kb read
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # stdout carries exactly one line, the JSON of rank 0: library chatter written to fd 1 (gloo /
+    # RCCL banners, HIP warnings) is sent to stderr for the rest of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # synthetic input first: worker processes must be forked before HIP is initialised
     from tombo_amd import _native, planner, sharding, streaming, tombo_stats as ts, tombo_helper as th
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
@@ -354,9 +364,16 @@ def main():
     ndev = max(torch.cuda.device_count(), 1)
     dev = local_rank % ndev
     torch.cuda.set_device(dev)
+    red_dev = 'cuda'
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+        if ndev >= world:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+        else:
+            # fewer GPUs than ranks (a development box): the ranks share devices, which RCCL
+            # refuses; the barrier / max-over-ranks then go over gloo
+            dist.init_process_group('gloo')
+            red_dev = 'cpu'
 
     def barrier():
         if dist is not None:
@@ -366,7 +383,7 @@ def main():
     def reduce(x, op):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device='cuda')
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -386,9 +403,13 @@ def main():
     probe.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
     free_b, total_b = probe.device_mem()
     if longtail:
-        plan = planner.plan_batches(n_raw, seq_len, p, o, model.kmer_width, 0.22 * free_b)
+        # several batches resident at once, each on its own stream: the one-wave-per-read kernels
+        # of the batch holding the 100 kb reads run for ~0.2 s, the other batches fill the machine
+        tot = planner.exact_bytes(n_raw, seq_len, p, o, model.kmer_width)
+        plan = planner.plan_batches(n_raw, seq_len, p, o, model.kmer_width,
+                                    min(0.2 * free_b, max(tot / 6.0, 2e9)))
     else:
-        plan = [np.arange(a.reads)]
+        plan = [x for x in np.array_split(np.arange(a.reads), max(1, a.resident_split)) if len(x)]
     engines = [probe] + [_native.Engine(dev) for _ in plan[1:]]
     t_up = time.perf_counter()
     up_bytes = 0
@@ -615,8 +636,7 @@ def main():
                                        all_cores=cpu_legs[1] if len(cpu_legs) > 1 else None,
                                        reference_cython='see BASELINE.md (tools/time_reference.py: the '
                                                         'reference Cython path vs this port on the build host)')
-        print(json.dumps(res))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

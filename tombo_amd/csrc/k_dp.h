@@ -144,6 +144,15 @@ __device__ __forceinline__ double readlane_f64(double x, int sel)
     return __hiloint2double(hi, lo);
 }
 
+// v_max_f64 without the canonicalising self-max the fmax builtin puts in front of it (both
+// operands are results of adds / maxes here, never signalling NaNs)
+__device__ __forceinline__ double max_f64_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Previous-row access without memory: every lane keeps its CPL cells of the previous row in
 // registers; the cells a row needs are that row shifted by the (wave-uniform) band offset, i.e. a
 // compile-time register renaming per offset plus a few wave_shl DPP moves for the cells that come
@@ -174,18 +183,16 @@ __device__ __forceinline__ void cand_row(const double (&Q)[CPL], double left,
         const double d = A[j] + z[j];
         const double s = A[j + 1] - skip_pen;
         bool take_s = s > d;
-        if (j == 0) take_s = lane0 ? first_is_skip : take_s; // band cell 0: skip xor diag
-        cv[j] = take_s ? s : d;
+        if (j == 0) {
+            take_s = lane0 ? first_is_skip : take_s; // band cell 0: skip xor diag
+            cv[j] = take_s ? s : d;
+        } else {
+            // the larger of the two IS the selected one (equal values: either), so one v_max_f64
+            // replaces the two 32-bit selects; the move flag still comes from the strict compare
+            cv[j] = max_f64_raw(s, d);
+        }
         tk[j] = take_s;
     }
-}
-// v_max_f64 without the canonicalising self-max the fmax builtin puts in front of it (both
-// operands are results of adds / maxes here, never signalling NaNs)
-__device__ __forceinline__ double max_f64_raw(double a, double b)
-{
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
 }
 // Q <- Q shifted by S cells (S <= CPL); returns the cell just left of the new Q[0]
 template <int CPL, int S>

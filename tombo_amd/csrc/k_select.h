@@ -407,6 +407,221 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
     return block_median_fe(flat_elems(val, n), n, lo, hi, sm, lo_mid, hi_mid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// np.median through a sampled window: ONE pass over the data instead of the bucket select's two.
+// Every thread holds WS_PER strided samples in registers; a histogram of the sample gives a value
+// window [t1, t2) around the sample quantiles 0.5 -/+ dq that holds the two middle ranks of the
+// full set with near certainty; the pass counts the elements below t1 and appends the ones inside
+// the window to `list` (global scratch, >= cap doubles); the middle order statistics are then
+// selected exactly among the listed values.  Count and list are exact, so the result is the
+// reference's np.median bit for bit; when the window misses a middle rank, or the list
+// overflows (massive ties), the caller falls back to block_median_fast.  All threads call;
+// returns true on success with *lo_mid / *hi_mid = the two middle order statistics.
+#define WS_PER 16                 // samples per thread (SEL_NT * WS_PER in all)
+template <class F>
+__device__ bool block_median_window(F val, i64 n, const double (&samp)[WS_PER], double *list,
+                                    i64 cap, BucketSmem *sm, double *lo_mid, double *hi_mid)
+{
+    const int tid = threadIdx.x;
+    __shared__ double s_t[2];
+    __shared__ int s_ok;
+    __shared__ u32 s_nl;
+    // range of the sample
+    double mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < WS_PER; q++) { mn = samp[q] < mn ? samp[q] : mn; mx = samp[q] > mx ? samp[q] : mx; }
+    for (int mm = 32; mm >= 1; mm >>= 1) {
+        double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
+        mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { sm->redd[2 * (tid >> 6)] = mn; sm->redd[2 * (tid >> 6) + 1] = mx; }
+    for (int b = tid; b < BS_NB; b += SEL_NT) sm->hist[b] = 0;
+    if (tid == 0) { s_ok = 0; s_nl = 0; }
+    __syncthreads();
+    mn = sm->redd[0]; mx = sm->redd[1];
+    for (int w = 1; w < SEL_NT / 64; w++) {
+        mn = sm->redd[2 * w] < mn ? sm->redd[2 * w] : mn;
+        mx = sm->redd[2 * w + 1] > mx ? sm->redd[2 * w + 1] : mx;
+    }
+    if (!(mx > mn)) return false;                    // constant sample: no window to speak of
+    const double hsc = (double)BS_NB / (mx - mn);
+    if (!(hsc < 1e300)) return false;
+#pragma unroll
+    for (int q = 0; q < WS_PER; q++) atomicAdd(&sm->hist[bs_bucket(samp[q], mn, hsc)], 1u);
+    __syncthreads();
+    if (tid < 64) { // wave 0: the buckets of the sample ranks (0.5 -/+ dq) m
+        const double m = (double)(SEL_NT * WS_PER);
+        const double dq = 4.0 * sqrt(0.25 / m) + 0.002;
+        const i64 r1 = (i64)((0.5 - dq) * m), r2 = (i64)((0.5 + dq) * m);
+        const int per = BS_NB / 64;
+        i64 c = 0;
+        for (int q = 0; q < per; q++) c += sm->hist[tid * per + q];
+        i64 inc = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            i64 t = shfl_i64(inc, tid - d < 0 ? 0 : tid - d);
+            if (tid >= d) inc += t;
+        }
+        i64 acc = inc - c;
+        for (int q = 0; q < per; q++) {
+            const i64 nx = acc + sm->hist[tid * per + q];
+            const int b = tid * per + q;
+            // first bucket whose cumulative count exceeds the rank
+            if (acc <= r1 && r1 < nx) s_t[0] = b == 0 ? -INFINITY : mn + (double)b / hsc;
+            if (acc <= r2 && r2 < nx) { s_t[1] = b == BS_NB - 1 ? INFINITY : mn + (double)(b + 1) / hsc; s_ok = 1; }
+            acc = nx;
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return false;
+    const double t1 = s_t[0], t2 = s_t[1];
+    // the pass: count below the window, list the window (wave-aggregated append)
+    i64 c_lo = 0;
+    const int lane = tid & 63;
+    for (i64 base = 0; base < n; base += SEL_NT) {
+        const i64 i = base + tid;
+        const bool ok = i < n;
+        const double v = ok ? val(i) : 0.0;
+        c_lo += ok && v < t1;
+        const bool in = ok && v >= t1 && v < t2;
+        const u64 m = __ballot(in);
+        if (m) {
+            u32 b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&s_nl, (u32)__popcll(m));
+            b0 = __shfl(b0, 0, 64);
+            const u32 pos = b0 + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < cap) list[pos] = v;
+        }
+    }
+    c_lo = block_sum_i64(c_lo, &sm->rad);
+    __threadfence_block();
+    __syncthreads();
+    const i64 n_c = s_nl;
+    const i64 k_lo = (n - 1) / 2 - c_lo, k_hi = n / 2 - c_lo;
+    if (n_c > cap || k_lo < 0 || k_hi >= n_c) return false;
+    // bucket range for the list: the window, clamped to something finite
+    const double span = mx - mn;
+    const double lo = t1 > mn - span ? t1 : mn - span, hi = t2 < mx + span ? t2 : mx + span;
+    const double a = block_kth([&](i64 k) { return list[k]; }, n_c, k_lo, lo, hi, sm);
+    const int found = sm->found;
+    const double nxt = sm->next;
+    __syncthreads();
+    double b = a;
+    if (k_hi != k_lo) {
+        if (found & 2) b = nxt;
+        else { b = block_kth([&](i64 k) { return list[k]; }, n_c, k_hi, lo, hi, sm); __syncthreads(); }
+    }
+    *lo_mid = a; *hi_mid = b;
+    return true;
+}
+
+// Exact medians of int16 samples from ONE counting pass: hist[v - base] over a window of
+// BS_NB consecutive integer values placed around the sample (DAC values of a read span a few
+// hundred to a thousand levels).  Returns false when a middle rank falls outside the window
+// (the caller falls back to the generic select).  On success: *xlo / *xhi = middle order
+// statistics of x, and -- given shift2 = 2 * median, an integer -- *dlo / *dhi = middle order
+// statistics of |x - median| (from the same histogram: a deviation e/2 collects the bins at
+// (shift2 -/+ e) / 2).  Counting only: exact.
+template <class XS>
+__device__ bool block_int_medians(XS x, i64 n, int vmin_s, int vmax_s, BucketSmem *sm,
+                                  double *xlo, double *xhi, double *dlo, double *dhi)
+{
+    const int tid = threadIdx.x;
+    __shared__ i64 s_k[4];
+    __shared__ int s_okk;
+    if (vmax_s - vmin_s >= BS_NB - 128) return false;
+    const int base = vmin_s - (BS_NB - (vmax_s - vmin_s + 1)) / 2;  // sample range centred
+    for (int b = tid; b < BS_NB; b += SEL_NT) sm->hist[b] = 0;
+    if (tid == 0) s_okk = 0;
+    __syncthreads();
+    i64 below = 0, above = 0;
+    for (i64 i = tid; i < n; i += SEL_NT) {
+        const int b = (int)x[i] - base;
+        if (b < 0) below++;
+        else if (b >= BS_NB) above++;
+        else atomicAdd(&sm->hist[b], 1u);
+    }
+    below = block_sum_i64(below, &sm->rad);
+    above = block_sum_i64(above, &sm->rad);
+    __syncthreads();
+    const i64 k_lo = (n - 1) / 2, k_hi = n / 2;
+    if (k_lo < below || k_hi >= n - above) return false;
+    // inclusive prefix over the bins, kept in cand[] as doubles (counts < 2^53: exact); 8 bins
+    // per thread + wave / block scan
+    {
+        const int per = BS_NB / SEL_NT; // 8
+        i64 loc[BS_NB / SEL_NT];
+        i64 c = 0;
+#pragma unroll
+        for (int q = 0; q < per; q++) { c += sm->hist[tid * per + q]; loc[q] = c; }
+        i64 inc = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            i64 t = shfl_i64(inc, (tid & 63) - d < 0 ? 0 : (tid & 63) - d);
+            if ((tid & 63) >= d) inc += t;
+        }
+        __syncthreads();
+        if ((tid & 63) == 63) sm->rad.red[tid >> 6] = (u64)inc;
+        __syncthreads();
+        i64 off = below;
+        for (int w = 0; w < (tid >> 6); w++) off += (i64)sm->rad.red[w];
+        const i64 exc = off + inc - c;
+#pragma unroll
+        for (int q = 0; q < per; q++) {
+            const i64 lo_c = exc + (q ? loc[q - 1] : 0), hi_c = exc + loc[q];
+            if (lo_c <= k_lo && k_lo < hi_c) s_k[0] = base + tid * per + q;
+            if (lo_c <= k_hi && k_hi < hi_c) s_k[1] = base + tid * per + q;
+        }
+    }
+    __syncthreads();
+    const i64 vlo = s_k[0], vhi = s_k[1];
+    *xlo = (double)vlo; *xhi = (double)vhi;
+    // deviations from the median (vlo + vhi) / 2 (n even) or vlo (n odd), in half units:
+    // e(v) = |2 v - shift2|, same parity as shift2; t-th candidate e_t = par + 2 t
+    const i64 shift2 = (n & 1) ? 2 * vlo : vlo + vhi;
+    const int par = (int)(shift2 & 1);
+    // count of candidate t: bins (shift2 - e) / 2 and (shift2 + e) / 2; out-of-window values have
+    // the largest deviations and only matter if a middle rank reaches them (-> fail)
+    {
+        const int per = BS_NB / SEL_NT;
+        i64 loc[BS_NB / SEL_NT];
+        i64 c = 0;
+#pragma unroll
+        for (int q = 0; q < per; q++) {
+            const i64 e = par + 2 * (i64)(tid * per + q);
+            const i64 a = (shift2 - e) / 2 - base, b2 = (shift2 + e) / 2 - base;
+            i64 cnt = 0;
+            if (a >= 0 && a < BS_NB) cnt += sm->hist[a];
+            if (e != 0 && b2 >= 0 && b2 < BS_NB) cnt += sm->hist[b2];
+            c += cnt; loc[q] = c;
+        }
+        i64 inc = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            i64 t = shfl_i64(inc, (tid & 63) - d < 0 ? 0 : (tid & 63) - d);
+            if ((tid & 63) >= d) inc += t;
+        }
+        __syncthreads();
+        if ((tid & 63) == 63) sm->rad.red[tid >> 6] = (u64)inc;
+        __syncthreads();
+        i64 off = 0;
+        for (int w = 0; w < (tid >> 6); w++) off += (i64)sm->rad.red[w];
+        const i64 exc = off + inc - c;
+        i64 tot = 0;
+        for (int w = 0; w < SEL_NT / 64; w++) tot += (i64)sm->rad.red[w];
+        if (tid == 0) s_okk = (tot == n - below - above) && k_hi < tot; // every in-window bin reached
+#pragma unroll
+        for (int q = 0; q < per; q++) {
+            const i64 lo_c = exc + (q ? loc[q - 1] : 0), hi_c = exc + loc[q];
+            const i64 e = par + 2 * (i64)(tid * per + q);
+            if (lo_c <= k_lo && k_lo < hi_c) s_k[2] = e;
+            if (lo_c <= k_hi && k_hi < hi_c) s_k[3] = e;
+        }
+    }
+    __syncthreads();
+    if (!s_okk) return false;
+    *dlo = (double)s_k[2] / 2.0; *dhi = (double)s_k[3] / 2.0;
+    return true;
+}
+
 
 // c_new_means-style segment means, wave-cooperative: a wavefront takes 64 consecutive segments,
 // pulls the samples they span (one contiguous range) into its LDS slice with coalesced loads, and

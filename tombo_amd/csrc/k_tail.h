@@ -611,6 +611,7 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const D
 // keeps them in its LDS slice and sums every base from there.  The bases tile the trimmed
 // signal exactly (segs[0] = 0, segs[B] = norm_len), so every sample is written once.
 // grid: (blocks, reads)
+template <bool WRITE> // WRITE = false: skip_norm_out batch, the final signal is not materialised
 __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const DevParams *dp,
     const double *norm, double *norm_out, const i64 *segs, const double *ref_means,
     const double *ref_sds, double *absz)
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
     const double *x = norm + r.raw_off + r.read_start;
-    double *y = norm_out != nullptr ? norm_out + r.raw_off : nullptr; // NULL: skip_norm_out batch
+    double *y = WRITE ? norm_out + r.raw_off : nullptr;
     const i64 *sg = segs + r.seg_off;
     const bool skip = dp->o.skip_seq_scaling != 0;
     const double ca = r.ts[2], cb = r.ts[3];
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
             __builtin_amdgcn_wave_barrier();
             for (i64 k = lane; k < span; k += 64) {
                 const double v = skip ? x[lo + k] : (x[lo + k] - ca) / cb; // resquiggle.py:1190
-                if (y) y[lo + k] = v;
+                if (WRITE) y[lo + k] = v;
                 lds[k] = v;
             }
             __builtin_amdgcn_wave_barrier();
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
         } else {
             for (i64 j = a; j < b; j++) {
                 const double v = skip ? x[j] : (x[j] - ca) / cb;
-                if (y) y[j] = v;
+                if (WRITE) y[j] = v;
                 s += v;
             }
         }

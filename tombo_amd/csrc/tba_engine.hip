@@ -560,7 +560,10 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 13 rescale + score
     if (ON(TBA_STAGE_RESCALE)) {
-        k_rescale_absz<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->hp.o.skip_norm_out ? nullptr : e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
+        if (e->hp.o.skip_norm_out)
+            k_rescale_absz<false><<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), nullptr, e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
+        else
+            k_rescale_absz<true><<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
         k_final_score<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, e->d_absz.as<double>());
     }
     MARK(); // 14 end
