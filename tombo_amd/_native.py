@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtombo_amd.so')
+# TBA_LIB_PATH: an alternative build of the same library (profiling builds with
+# -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS, A/B comparisons of a kernel variant)
+LIB_PATH = os.environ.get('TBA_LIB_PATH') or os.path.join(_HERE, 'libtombo_amd.so')
 CSRC = os.path.join(_HERE, 'csrc')
 i64, f64, i32 = C.c_int64, C.c_double, C.c_int32
 

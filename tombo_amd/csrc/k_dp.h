@@ -97,20 +97,6 @@ __device__ __forceinline__ double wave_max_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-// a / b for a row-constant divisor, bit-identical to IEEE division: y = RN(1/b) comes from one
-// true division per row, q0 = RN(a*y) is within 2 ulp, one residual correction makes it
-// faithful, a second one rounds correctly (Markstein: q faithful, y = RN(1/b), r = a - b*q exact
-// => RN(q + r*y) = RN(a/b)).  Results that underflow are far below the 1e-17 granularity of the
-// z_shift they are subtracted from.  tests/test_gpu_kernel_abi.py checks it against true division.
-__device__ __forceinline__ double div_by_recip(double a, double b, double y)
-{
-    double q = a * y;
-    double e = __builtin_fma(-b, q, a);
-    q = __builtin_fma(e, y, q);
-    e = __builtin_fma(-b, q, a);
-    return __builtin_fma(e, y, q);
-}
-
 // bytes of packed 2-bit moves per lane per row: 4 cells per byte, so a row is plainly linear
 // (cell b -> byte b/4, bits 2*(b%4)) and 16*CPL bytes long
 __host__ __device__ constexpr int mv_bpl(int cpl) { return cpl / 4; } // (whole bytes: cpl % 4 == 0)

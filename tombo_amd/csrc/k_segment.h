@@ -10,9 +10,18 @@
 // RT: the raw sample type at the boundary (double, float, or the int16 DAC values of the FAST5
 // file, resquiggle.py:1397); widening to float64 is exact, so every pass sees the values the
 // reference sees after its own int16 -> float64 promotion.
+// The read's `norm` slice serves as scratch (window lists) until the final pass writes the signal;
+// write_norm == 0: only the scale values are produced.
+// Medians: int16 input -> one counting pass (block_int_medians); float input -> one pass per
+// median through a sampled window (block_median_window); short reads and every failure of the
+// fast forms -> the generic bucket select (two passes per median).
+template <class RT> struct raw_is_int { static constexpr bool value = false; };
+template <> struct raw_is_int<int16_t> { static constexpr bool value = true; };
+#define NORM_WINDOW_MIN 16384 // below this the generic select is cheap anyway
+
 template <class RT>
 __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevParams *dp,
-    const RT *raw, double *norm, const double *sv_in, int mode)
+    const RT *raw, double *norm, const double *sv_in, int mode, int write_norm)
 {
     __shared__ BucketSmem sm;
     ReadState &r = rs[blockIdx.x];
@@ -35,11 +44,15 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         use_sv = true; // get_scale_values_from_events result, tombo_stats.py:217-233
         shift = r.shift; scale = r.scale; have_lims = true; lo = r.lower; hi = r.upper;
     } else {
-        // Bucket-select medians (k_select.h).  Their first bucket range is only a guess -- the
-        // select clamps outside values into the end buckets and refines -- so it comes from 512
-        // samples instead of a min / max pass over the signal.
+        // strided sample, kept in registers: range guess for the selects and window steering
+        double samp[WS_PER];
         double smn = INFINITY, smx = -INFINITY;
-        { const double v = x[(n * (i64)tid) / SEL_NT]; smn = v; smx = v; }
+#pragma unroll
+        for (int q = 0; q < WS_PER; q++) {
+            const i64 si = (n * (i64)(q * SEL_NT + tid)) / (SEL_NT * WS_PER);
+            samp[q] = x[si];
+            smn = samp[q] < smn ? samp[q] : smn; smx = samp[q] > smx ? samp[q] : smx;
+        }
         for (int mm = 32; mm >= 1; mm >>= 1) {
             double a = shfl_xor_f64(smn, mm), b2 = shfl_xor_f64(smx, mm);
             smn = a < smn ? a : smn; smx = b2 > smx ? b2 : smx;
@@ -55,12 +68,42 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         double span = smx - smn;
         span = span > 0 ? span : 1.0;
         mn = smn - span; mx = smx + span;
-        shift = block_median_fast([&](i64 i) { return x[i]; }, n, mn, mx, &sm, &xlo, &xhi);
+        bool have_med = false;
+        if constexpr (raw_is_int<RT>::value) {
+            // both medians from one counting pass (the deviations of the scale are ranked from the
+            // same histogram once the median is known)
+            if (n >= 4096 && block_int_medians(x, n, (int)smn, (int)smx, &sm, &xlo, &xhi, &dlo, &dhi)) {
+                shift = (n & 1) ? xlo : (xlo + xhi) / 2.0;
+                have_med = true;
+                if (!o.has_const_scale) { scale = (n & 1) ? dlo : (dlo + dhi) / 2.0; have_dev = true; }
+            }
+            __syncthreads();
+        } else if (n >= NORM_WINDOW_MIN) {
+            // (the window list lives in the read's norm slice, written only by the final pass)
+            if (block_median_window([&](i64 i) { return x[i]; }, n, samp, y, n, &sm, &xlo, &xhi)) {
+                shift = (n & 1) ? xlo : (xlo + xhi) / 2.0;
+                have_med = true;
+            }
+            __syncthreads();
+        }
+        if (!have_med)
+            shift = block_median_fast([&](i64 i) { return x[i]; }, n, mn, mx, &sm, &xlo, &xhi);
         if (o.has_const_scale) scale = o.const_scale;
-        else {
-            const double a = mx - shift, b2 = shift - mn;
-            scale = block_median_fast([&](i64 i) { return fabs(x[i] - shift); }, n, 0.0,
-                                      a > b2 ? a : b2, &sm, &dlo, &dhi);
+        else if (!have_dev) {
+            bool done = false;
+            if (!raw_is_int<RT>::value && n >= NORM_WINDOW_MIN) {
+                double ds[WS_PER];
+#pragma unroll
+                for (int q = 0; q < WS_PER; q++) ds[q] = fabs(samp[q] - shift);
+                done = block_median_window([&](i64 i) { return fabs(x[i] - shift); }, n, ds, y, n, &sm, &dlo, &dhi);
+                if (done) scale = (n & 1) ? dlo : (dlo + dhi) / 2.0;
+                __syncthreads();
+            }
+            if (!done) {
+                const double a = mx - shift, b2 = shift - mn;
+                scale = block_median_fast([&](i64 i) { return fabs(x[i] - shift); }, n, 0.0,
+                                          a > b2 ? a : b2, &sm, &dlo, &dhi);
+            }
             have_dev = true;
         }
     }
@@ -91,14 +134,16 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         hi = med + (mad * o.outlier_thresh);
         have_lims = true;
     }
-    if (have_lims) {
-        // c_apply_outlier_thresh, _c_helper.pyx:73-87
-        for (i64 i = tid; i < n; i += SEL_NT) {
-            const double v = (x[i] - shift) / scale;
-            y[i] = v > hi ? hi : (v < lo ? lo : v);
+    if (write_norm) {
+        if (have_lims) {
+            // c_apply_outlier_thresh, _c_helper.pyx:73-87
+            for (i64 i = tid; i < n; i += SEL_NT) {
+                const double v = (x[i] - shift) / scale;
+                y[i] = v > hi ? hi : (v < lo ? lo : v);
+            }
+        } else {
+            for (i64 i = tid; i < n; i += SEL_NT) y[i] = (x[i] - shift) / scale;
         }
-    } else {
-        for (i64 i = tid; i < n; i += SEL_NT) y[i] = (x[i] - shift) / scale;
     }
     if (tid == 0) {
         r.shift = shift; r.scale = scale; r.lower = lo; r.upper = hi;

@@ -417,7 +417,11 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
 // reference's np.median bit for bit; when the window misses a middle rank, or the list
 // overflows (massive ties), the caller falls back to block_median_fast.  All threads call;
 // returns true on success with *lo_mid / *hi_mid = the two middle order statistics.
-#define WS_PER 16                 // samples per thread (SEL_NT * WS_PER in all)
+#ifndef WS_PER
+#define WS_PER 4  // samples per thread (SEL_NT * WS_PER in all: one per ~3 cache lines of a 10 kb
+                  // read; 16 per thread touch every line -- most of a pass -- for a window half
+                  // as wide: 8.5 vs 6.5 ms on the 10k x 10 kb batch)
+#endif
 template <class F>
 __device__ bool block_median_window(F val, i64 n, const double (&samp)[WS_PER], double *list,
                                     i64 cap, BucketSmem *sm, double *lo_mid, double *hi_mid)
@@ -618,6 +622,10 @@ __device__ bool block_int_medians(XS x, i64 n, int vmin_s, int vmax_s, BucketSme
     }
     __syncthreads();
     if (!s_okk) return false;
+    // values outside the window deviate more than anything inside only up to the distance of
+    // the nearer window edge: a middle rank beyond that cannot be ranked from the histogram
+    if (below > 0 && (shift2 - s_k[3]) / 2 < (i64)base) return false;
+    if (above > 0 && (shift2 + s_k[3]) / 2 > (i64)base + BS_NB - 1) return false;
     *dlo = (double)s_k[2] / 2.0; *dhi = (double)s_k[3] / 2.0;
     return true;
 }

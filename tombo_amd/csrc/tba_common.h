@@ -70,6 +70,20 @@ struct RawSamples {
     __device__ __forceinline__ RawSamples operator+(i64 k) const { return RawSamples{p + k}; }
 };
 
+// a / b for a row-constant divisor, bit-identical to IEEE division: y = RN(1/b) comes from one
+// true division per row, q0 = RN(a*y) is within 2 ulp, one residual correction makes it
+// faithful, a second one rounds correctly (Markstein: q faithful, y = RN(1/b), r = a - b*q exact
+// => RN(q + r*y) = RN(a/b)).  Results that underflow are far below the 1e-17 granularity of the
+// z_shift they are subtracted from.  tests/test_gpu_kernel_abi.py checks it against true division.
+__device__ __forceinline__ double div_by_recip(double a, double b, double y)
+{
+    double q = a * y;
+    double e = __builtin_fma(-b, q, a);
+    q = __builtin_fma(e, y, q);
+    e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, y, q);
+}
+
 // order-preserving map double -> u64 (ascending); no NaNs on this path
 __device__ __forceinline__ u64 f64_key(double x)
 {

@@ -490,10 +490,10 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     const bool rna = P.use_t_test_seg != 0;
     MARK(); // 0 normalize
     const int rdt = e->raw_dtype;
-    if (ON(TBA_STAGE_SEGMENT) && !rna)
-        RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0)));
-    MARK(); // 1 cumsum
     const bool fused_scores = 2 * P.running_stat_width <= 64; // cumsum + scores in one kernel
+    if (ON(TBA_STAGE_SEGMENT) && !rna)
+        RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0, 1)));
+    MARK(); // 1 cumsum
     if (ON(TBA_STAGE_SEGMENT) && !rna) {
         if (fused_scores) k_cumsum_scores<<<(unsigned)((n + CS_READS - 1) / CS_READS), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
         else k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
@@ -510,7 +510,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
             RAW_DISPATCH(rdt, (k_event_means<RT><<<dim3(gE, nb), 256, 0, s>>>(rs, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0)));
             k_rna_event_scale<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_evm.as<double>());
-            RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1)));
+            RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1, 1)));
         }
     }
     MARK(); // 4 event means
