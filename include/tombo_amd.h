@@ -331,6 +331,27 @@ int tba_llh_ratio_windows(tba_engine *e, int kind, const double *means, const do
     const double *alt_means, const double *ref_vars, const double *alt_vars, int64_t n_values,
     int64_t width, const int64_t *starts, int64_t n_windows, const double *par, double *out);
 
+/* compute_sample_compare_read_stats / compute_de_novo_read_stats (tombo_stats.py:3675-3873)
+ * after their file access: per-base p-values 2 * Phi(-|mean - ref_mean| / ref_sd), combined by
+ * Fisher's method over windows of 2 * fm_offset + 1 positions when fm_offset > 0
+ * (calc_window_fishers_method :2252-2271, SMALLEST_PVAL floor; the first / last fm_offset
+ * positions of a read are NaN), NaN wherever an input is NaN (control positions without
+ * coverage).  floor_out != 0: the de novo form (result floored at smallest_pval).  n_reads reads
+ * as CSR slices off[n_reads + 1] of the three arrays and of pvals.  erfc / log / exp are the
+ * device library's: ~1e-14 relative to scipy. */
+int tba_read_pvals(tba_engine *e, const double *means, const double *ref_means,
+    const double *ref_sds, const int64_t *off, int64_t n_reads, int64_t fm_offset, int floor_out,
+    double smallest_pval, double *pvals);
+/* The de novo statistic of every read of the finished resident batch, nothing uploaded: per-base
+ * means (c_new_means over the final signal and boundaries, as tba_batch_base_stats) against the
+ * batch's own expected levels, which are the canonical model's levels of the read sequence --
+ * compute_de_novo_read_stats (tombo_stats.py:3771-3873) for a read tested over its whole length.
+ * pvals: CSR by the reads' base counts (layout of tba_batch_base_stats), n_values >= B_tot;
+ * per read only [central_pos, B - (K - central_pos - 1)) is tested (k-mers inside the read),
+ * the rest and failed reads are NaN. */
+int tba_batch_de_novo_stats(tba_engine *e, int64_t fm_offset, double smallest_pval,
+                            double *pvals, int64_t n_values);
+
 /* self-test: out[i] = the row-constant division used inside the DP kernel (reciprocal + two
  * residual corrections) for a[i] / b[i]; must equal the IEEE quotient bit for bit */
 int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,

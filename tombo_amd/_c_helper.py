@@ -93,7 +93,14 @@ def llh_ratio_windows(kind, means, ref_means, alt_means, ref_vars, starts, width
     m, r, a, rv = (_f8(x, n) for x, n in ((means, 'reg_means'), (ref_means, 'reg_ref_means'),
                                           (alt_means, 'reg_alt_means'), (ref_vars, 'reg_ref_vars')))
     av = None if alt_vars is None else _f8(alt_vars, 'reg_alt_vars')
+    # the reference's Cython indexes all arrays with the first one's length (bounds-checked)
+    for name, arr in (('reg_ref_means', r), ('reg_alt_means', a), ('reg_ref_vars', rv),
+                      ('reg_alt_vars', av)):
+        if arr is not None and arr.shape[0] < m.shape[0]:
+            raise IndexError('%s is shorter than reg_means' % name)
     st = _i8(np.asarray(starts, dtype=np.int64), 'starts')
+    if st.shape[0] == 0:
+        return np.empty(0, dtype=np.float64)
     out = np.empty(st.shape[0], dtype=np.float64)
     par = (C.c_double * 3)(scale_factor or 0.0, density_height_factor or 0.0,
                            density_height_power or 0.0)
@@ -113,6 +120,8 @@ def c_calc_llh_ratio(reg_means, reg_ref_means, reg_alt_means, reg_ref_vars, reg_
 
 def c_calc_llh_ratio_const_var(reg_means, reg_ref_means, reg_alt_means, const_var):
     n = len(reg_means)
+    if n == 0:
+        return 0.0   # the reference's empty loop
     return float(llh_ratio_windows(1, reg_means, reg_ref_means, reg_alt_means,
                                    np.full(max(n, 1), float(const_var)), [0], n)[0])
 
@@ -120,6 +129,8 @@ def c_calc_llh_ratio_const_var(reg_means, reg_ref_means, reg_alt_means, const_va
 def c_calc_scaled_llh_ratio_const_var(reg_means, reg_ref_means, reg_alt_means, const_var,
                                       scale_factor, density_height_factor, density_height_power):
     n = len(reg_means)
+    if n == 0:
+        return 0.0
     return float(llh_ratio_windows(2, reg_means, reg_ref_means, reg_alt_means,
                                    np.full(max(n, 1), float(const_var)), [0], n,
                                    scale_factor=scale_factor,

@@ -36,3 +36,13 @@ MAX_POINTS_FOR_THEIL_SEN = 1000
 # E|N(0,1)| = sqrt(2/pi): the reference integrates scipy.stats.halfnorm numerically
 # (tombo_stats.py:84) and lands on this double bit-for-bit.
 HALF_NORM_EXPECTED_VAL = float.fromhex('0x1.9884533d43651p-1')
+# per-read statistics (row N4; _default_parameters.py:132-134,158, tombo_stats.py:89-112)
+OCLLHR_SCALE = 4.0
+OCLLHR_HEIGHT = 1.0
+OCLLHR_POWER = 0.2
+SMALLEST_PVAL = 1e-50
+FM_OFFSET_DEFAULT = 1
+SAMP_COMP_TXT = 'sample_compare'
+DE_NOVO_TXT = 'de_novo'
+ALT_MODEL_TXT = 'model_compare'
+CONST_SD_MODEL = True

@@ -412,6 +412,16 @@ class Engine(object):
                     'tba_batch_base_stats')
         return m, s
 
+    def de_novo_stats(self, fm_offset, smallest_pval):
+        """tba_batch_de_novo_stats: p-values of every base of the finished batch (CSR by ref_off;
+        NaN outside the testable part of a read and for failed reads)"""
+        nb = int(self.ref_off[-1])
+        out = np.full(max(nb, 1), np.nan)
+        self._check(self._L.tba_batch_de_novo_stats(
+            self._h, i64(int(fm_offset)), f64(float(smallest_pval)), _p(out, f64), i64(nb)),
+            'tba_batch_de_novo_stats')
+        return out[:nb]
+
     def stats(self):
         a, c = f64(0), f64(0)
         self._check(self._L.tba_batch_stats(self._h, C.byref(a), C.byref(c)), 'tba_batch_stats')

@@ -270,3 +270,45 @@ __global__ void k_c_llh_windows(int kind, const double *means, const double *ref
     }
 }
 
+
+// ---- row N4: per-read test statistics ---------------------------------------------------------
+// compute_sample_compare_read_stats / compute_de_novo_read_stats (tombo_stats.py:3675-3873):
+//   z = |mean - ref_mean| / ref_sd;  p = norm.cdf(-z) * 2  (NaN where z is NaN);
+//   fm_offset > 0: Fisher's method over windows of 2 * fm_offset + 1 p-values
+//   (calc_window_fishers_method, tombo_stats.py:2252-2271): p floored at `smallest`, logs summed in
+//   index order, chi2.sf(-2 * sum, 2 * width) in its closed form for even degrees of freedom
+//   exp(-x/2) * sum_{i < width} (x/2)^i / i!; the first / last fm_offset positions are NaN;
+//   floor_out (de novo): the result is floored at `smallest` once more (np.maximum keeps NaN).
+// Reads are CSR slices off[r]..off[r+1]; one thread per base.  erfc / log / exp are the device
+// library's: parity with scipy is a stated tolerance (tests: 1e-12 relative).
+__global__ void k_read_pvals(const double *means, const double *ref_means, const double *ref_sds,
+    const i64 *off, i64 n_reads, i64 total, i64 fm, int floor_out, double smallest, double *out)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+        // read of position i: binary search in off[]
+        i64 lo = 0, hi = n_reads - 1;
+        while (lo < hi) { const i64 mid = (lo + hi + 1) >> 1; if (off[mid] <= i) lo = mid; else hi = mid - 1; }
+        const i64 a = off[lo], b = off[lo + 1];
+        auto pval = [&](i64 k) {
+            const double z = fabs(means[k] - ref_means[k]) / ref_sds[k];
+            return z != z ? z : erfc(z * 0.70710678118654752440);
+        };
+        double res;
+        if (fm <= 0) res = pval(i);
+        else if (i - a < fm || b - i <= fm) res = NAN;
+        else {
+            double ls = 0.0;
+            for (i64 k = i - fm; k <= i + fm; k++) {
+                double p = pval(k);
+                p = p < smallest ? smallest : p; // np.maximum: NaN stays NaN (comparison false)
+                ls += log(p);
+            }
+            const double hx = -ls;                // x / 2 with x = -2 * log_sum
+            double term = 1.0, acc = 1.0;
+            for (i64 q = 1; q < 2 * fm + 1; q++) { term = term * hx / (double)q; acc += term; }
+            res = exp(-hx) * acc;
+        }
+        if (floor_out && res < smallest) res = smallest;
+        out[i] = res;
+    }
+}

@@ -1335,6 +1335,112 @@ extern "C" int tba_llh_ratio_windows(tba_engine *e, int kind, const double *mean
     return TBA_OK;
 }
 
+extern "C" int tba_read_pvals(tba_engine *e, const double *means, const double *ref_means,
+    const double *ref_sds, const int64_t *off, int64_t n_reads, int64_t fm_offset, int floor_out,
+    double smallest_pval, double *pvals)
+{
+    if (!e || !means || !ref_means || !ref_sds || !off || !pvals || n_reads < 0 || fm_offset < 0 ||
+        fm_offset > 64)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (n_reads == 0) return TBA_OK;
+    if (off[0] != 0) return set_err(TBA_E_ARG, "offset arrays must start at 0");
+    for (i64 i = 0; i < n_reads; i++)
+        if (off[i + 1] < off[i]) return set_err(TBA_E_ARG, "offset arrays must be non-decreasing");
+    const i64 total = off[n_reads];
+    if (total == 0) return TBA_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t nb = (size_t)total * 8;
+    Tmp d_m, d_r, d_s, d_off, d_o;
+    if (d_m.alloc(nb) || d_r.alloc(nb) || d_s.alloc(nb) || d_off.alloc((size_t)(n_reads + 1) * 8) || d_o.alloc(nb))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    C_TRY(hipMemcpy(d_m.p, means, nb, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_r.p, ref_means, nb, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_s.p, ref_sds, nb, hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_off.p, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice));
+    k_read_pvals<<<grid_for(total), 256, 0, e->stream>>>(d_m.as<double>(), d_r.as<double>(),
+        d_s.as<double>(), d_off.as<i64>(), n_reads, total, fm_offset, floor_out, smallest_pval, d_o.as<double>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(pvals, d_o.p, nb, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+// testable slice of every read -> CSR offsets into a packed copy of (means, levels); one thread
+// per read writes its (start, count), the host scans (a handful of values per read)
+__global__ void k_denovo_pack(const ReadState *rs, i64 n_reads, const DevParams *dp,
+    const double *bm, const double *refm, const double *refs, const i64 *pk_off, double *pm,
+    double *pr, double *ps)
+{
+    const ReadState &r = rs[blockIdx.y];
+    const i64 cp = dp->central_pos, dn = dp->kmer_width - dp->central_pos - 1;
+    const i64 cnt = pk_off[blockIdx.y + 1] - pk_off[blockIdx.y];
+    (void)n_reads;
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (i64)gridDim.x * 256) {
+        const i64 src = r.ref_off + cp + k, dst = pk_off[blockIdx.y] + k;
+        pm[dst] = bm[src]; pr[dst] = refm[src]; ps[dst] = refs[src];
+    }
+    (void)dn;
+}
+__global__ void k_denovo_unpack(const ReadState *rs, const DevParams *dp, const i64 *pk_off,
+    const double *pp, double *out)
+{
+    const ReadState &r = rs[blockIdx.y];
+    const i64 cp = dp->central_pos;
+    const i64 cnt = pk_off[blockIdx.y + 1] - pk_off[blockIdx.y];
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < r.B; k += (i64)gridDim.x * 256) {
+        const i64 q = k - cp;
+        out[r.ref_off + k] = (q >= 0 && q < cnt) ? pp[pk_off[blockIdx.y] + q] : NAN;
+    }
+}
+
+extern "C" int tba_batch_de_novo_stats(tba_engine *e, int64_t fm_offset, double smallest_pval,
+                                       double *pvals, int64_t n_values)
+{
+    if (!e || !e->have_batch || !e->finished) return set_err(TBA_E_STATE, "no finished batch");
+    if (!pvals || n_values < e->B_tot || fm_offset < 0 || fm_offset > 64) return set_err(TBA_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->B_tot == 0) return 0;
+    const size_t N = (size_t)e->n_reads;
+    const i64 K = e->hp.kmer_width, cp = e->hp.central_pos, dn = K - cp - 1;
+    // per-base means of the final signal (the Events table's norm_mean), on the device
+    if (e->d_stat.ensure((size_t)e->B_tot * 16)) return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    double *d_m = e->d_stat.as<double>(), *d_s = d_m + e->B_tot;
+    const unsigned gB = (unsigned)std::min<i64>(std::max<i64>((e->max_B + 255) / 256, 1), 128);
+    k_base_stats<<<dim3(gB, (unsigned)N), 256, 0, e->stream>>>(e->d_rs.as<ReadState>(),
+        e->d_dp.as<DevParams>(), e->hp.o.skip_norm_out ? nullptr : e->d_norm_out.as<double>(),
+        e->d_norm.as<double>(), e->d_segs.as<i64>(), d_m, d_s);
+    // testable positions of every successful read, packed
+    std::vector<ReadState> rs(N);
+    HIP_TRY(hipMemcpy(rs.data(), e->d_rs.p, N * sizeof(ReadState), hipMemcpyDeviceToHost));
+    std::vector<i64> pk(N + 1, 0);
+    for (size_t i = 0; i < N; i++) {
+        i64 cnt = rs[i].status == TBA_OK ? rs[i].B - cp - dn : 0;
+        // a read shorter than one Fisher window: "P-values vector too short" in the reference
+        if (cnt < 2 * fm_offset + 1 || cnt < 1) cnt = 0;
+        pk[i + 1] = pk[i] + cnt;
+    }
+    const i64 total = pk[N];
+    Tmp d_pk, d_pm, d_pr, d_ps, d_pp, d_out;
+    if (d_pk.alloc((N + 1) * 8) || d_pm.alloc((size_t)total * 8) || d_pr.alloc((size_t)total * 8) ||
+        d_ps.alloc((size_t)total * 8) || d_pp.alloc((size_t)total * 8) || d_out.alloc((size_t)e->B_tot * 8))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    HIP_TRY(hipMemcpyAsync(d_pk.p, pk.data(), (N + 1) * 8, hipMemcpyHostToDevice, e->stream));
+    if (total > 0) {
+        k_denovo_pack<<<dim3(gB, (unsigned)N), 256, 0, e->stream>>>(e->d_rs.as<ReadState>(), e->n_reads,
+            e->d_dp.as<DevParams>(), d_m, e->d_refm.as<double>(), e->d_refs.as<double>(),
+            d_pk.as<i64>(), d_pm.as<double>(), d_pr.as<double>(), d_ps.as<double>());
+        k_read_pvals<<<grid_for(total), 256, 0, e->stream>>>(d_pm.as<double>(), d_pr.as<double>(),
+            d_ps.as<double>(), d_pk.as<i64>(), (i64)N, total, fm_offset, 1, smallest_pval, d_pp.as<double>());
+    }
+    k_denovo_unpack<<<dim3(gB, (unsigned)N), 256, 0, e->stream>>>(e->d_rs.as<ReadState>(),
+        e->d_dp.as<DevParams>(), d_pk.as<i64>(), d_pp.as<double>(), d_out.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(pvals, d_out.p, (size_t)e->B_tot * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,
                                      double *out)
 {

@@ -18,7 +18,7 @@ from ._default_parameters import (
     MAX_POINTS_FOR_THEIL_SEN)
 
 __all__ = ['resquiggle_read', 'resquiggle_batch', 'resquiggle_batch_iters', 'adjust_map_res',
-           'resquiggle_batch_events', 'get_engine', 'segment_signal',
+           'resquiggle_batch_events', 'batch_de_novo_stats', 'get_engine', 'default_device', 'segment_signal',
            'find_adaptive_base_assignment', 'find_seq_start_in_events',
            'find_static_base_assignment', 'resolve_skipped_bases_with_raw']
 
@@ -472,3 +472,35 @@ def resquiggle_batch_events(map_results, std_ref, rsqgl_params, outlier_thresh=N
         a, b = int(eng.ref_off[i]), int(eng.ref_off[i + 1])
         tables.append(th.events_table(res, means[a:b], stds[a:b] if compute_sd else None))
     return results, tables
+
+
+def batch_de_novo_stats(fm_offset=1, starts=None, strands=None, engine=None):
+    """De novo test statistic (`ts.compute_de_novo_read_stats`, tombo_stats.py:3771-3873, whole
+    read as the region) of every read of the batch the engine has just finished -- per-base
+    means, expected levels and p-values never leave the device until the result is copied back
+    (`tba_batch_de_novo_stats`).  Returns per read (pvals, genomic positions), None for reads
+    that failed or are too short to test.  `starts[i]` / `strands[i]`: mapped start and strand
+    (default 0 / '+'); minus-strand results are flipped into genomic order like the
+    reference's."""
+    from ._default_parameters import SMALLEST_PVAL
+    eng = get_engine() if engine is None else engine
+    pv = eng.de_novo_stats(fm_offset, SMALLEST_PVAL)
+    st = eng.download(want_norm=False)['status']
+    K = eng.kmer_width
+    cp = getattr(eng, '_model_key', None)[1] if getattr(eng, '_model_key', None) else None
+    if cp is None:
+        raise RuntimeError('the engine model was not set through ensure_model')
+    dn = K - cp - 1
+    out = []
+    for i in range(eng.n):
+        B = int(eng.B[i])
+        if st[i] != 0 or B - cp - dn < max(1, 2 * fm_offset + 1):
+            out.append(None)
+            continue
+        a = int(eng.ref_off[i])
+        p = pv[a + cp:a + B - dn].copy()
+        s0 = 0 if starts is None else int(starts[i])
+        minus = strands is not None and strands[i] == '-'
+        lag_b = dn if minus else cp
+        out.append((p[::-1].copy() if minus else p, np.arange(s0 + lag_b, s0 + lag_b + p.shape[0])))
+    return out

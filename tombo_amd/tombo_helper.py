@@ -94,3 +94,155 @@ def get_event_data(rsqgl_res, compute_sd=True):
         m, s = c_new_mean_stds(sig, segs)
         return events_table(rsqgl_res, m, s)
     return events_table(rsqgl_res, c_new_means(sig, segs))
+
+
+# ---- what downstream Tombo commands read back: readData + index ------------
+readData = namedtuple('readData', (
+    'start', 'end', 'filtered', 'read_start_rel_to_raw', 'strand', 'fn', 'corr_group', 'rna',
+    'sig_match_score', 'mean_q_score', 'read_id'))   # tombo_helper.py:127-158
+readData.__new__.__defaults__ = (None, None, None)
+
+# A resquiggled read as the statistics functions need it: the index record plus the two Events
+# columns they load from the FAST5 file (`norm_mean`, `base`; tombo_helper.py:1593-1647), held in
+# memory -- `means` / `seq` are read-centric (5'->3' of the read), like the table.
+resquiggledRead = namedtuple('resquiggledRead', readData._fields + ('means', 'seq'))
+resquiggledRead.__new__.__defaults__ = (None,) * 5
+
+SINGLE_LETTER_CODE = {
+    'A': 'A', 'C': 'C', 'G': 'G', 'T': 'T', 'B': '[CGT]', 'D': '[AGT]', 'H': '[ACT]',
+    'K': '[GT]', 'M': '[AC]', 'N': '[ACGT]', 'R': '[AG]', 'S': '[CG]', 'V': '[ACG]',
+    'W': '[AT]', 'Y': '[CT]'}   # tombo_helper.py:54-58
+
+
+class TomboMotif(object):
+    """Sequence motif with the (1-based) modified position (tombo_helper.py:542-626): the part
+    the alternative-model statistic uses -- `motif_pat`, `motif_len`, `mod_pos`, `mod_base`."""
+
+    def __init__(self, raw_motif, mod_pos=None):
+        import re
+        bad = [c for c in raw_motif if c not in SINGLE_LETTER_CODE]
+        if bad:
+            raise ValueError('Invalid characters in motif: ' + ', '.join(bad))
+        self.raw_motif = raw_motif
+        self.motif_len = len(raw_motif)
+        self.motif_pat = re.compile(''.join(SINGLE_LETTER_CODE[c] for c in raw_motif))
+        self.mod_pos = mod_pos
+        self.mod_base = None if mod_pos is None else raw_motif[mod_pos - 1]
+        if mod_pos is not None:
+            assert 0 < mod_pos <= self.motif_len
+
+
+def read_from_results(rsqgl_res, norm_means, fn=None, corr_group='RawGenomeCorrected_000',
+                      rna=False, read_id=None, filtered=False):
+    """`resquiggledRead` of a finished read: the index fields `_resquiggle_worker` records
+    (resquiggle.py:1591-1600 -> tombo_helper.py:1169-1176) plus the Events columns the statistics
+    read back.  `norm_means`: per-base means (tba_batch_base_stats / get_event_data)."""
+    start = rsqgl_res.genome_loc.Start
+    return resquiggledRead(
+        start=start, end=start + len(rsqgl_res.segs) - 1, filtered=filtered,
+        read_start_rel_to_raw=rsqgl_res.read_start_rel_to_raw,
+        strand=rsqgl_res.genome_loc.Strand, fn=fn,
+        corr_group=corr_group + '/' + rsqgl_res.align_info.Subgroup, rna=rna,
+        sig_match_score=rsqgl_res.sig_match_score, mean_q_score=rsqgl_res.mean_q_score,
+        read_id=read_id if read_id is not None else rsqgl_res.align_info.ID,
+        means=norm_means, seq=rsqgl_res.genome_seq)
+
+
+def index_entry(rd, basedir=''):
+    """The tuple `TomboReads._write_index` pickles per read (tombo_helper.py:1169-1183):
+    (fn relative to the base directory, start, end, read_start_rel_to_raw, corrected group,
+    basecall subgroup, filtered, rna, sig_match_score, mean_q_score, read_id)."""
+    fn = rd.fn or ''
+    if basedir and fn.startswith(basedir):
+        fn = fn[len(basedir):]
+    grp = rd.corr_group.split('/')
+    return (fn, rd.start, rd.end, rd.read_start_rel_to_raw, grp[0], grp[-1], rd.filtered, rd.rna,
+            rd.sig_match_score, rd.mean_q_score, rd.read_id)
+
+
+def write_index(reads_by_chrm_strand, index_fn, basedir=''):
+    """Tombo index file: pickle (protocol 2) of {(chrm, strand): [index_entry, ...]}
+    (tombo_helper.py:1160-1187)."""
+    import pickle
+    data = dict((cs, [index_entry(rd, basedir) for rd in rds])
+                for cs, rds in reads_by_chrm_strand.items())
+    with open(index_fn, 'wb') as fp:
+        pickle.dump(data, fp, protocol=2)
+    return data
+
+
+def read_index(index_fn, basedir=''):
+    """{(chrm, strand): [readData, ...]} from a Tombo index file (inverse of `write_index`;
+    the reference's parser: tombo_helper.py:1226-1260)."""
+    import pickle
+    with open(index_fn, 'rb') as fp:
+        data = pickle.load(fp)
+    out = {}
+    for (chrm, strand), recs in data.items():
+        out[(chrm, strand)] = [
+            readData(start=s, end=e, filtered=flt, read_start_rel_to_raw=rsr, strand=strand,
+                     fn=basedir + fn, corr_group=cg + '/' + sub, rna=rna, sig_match_score=sms,
+                     mean_q_score=mq, read_id=rid)
+            for fn, s, e, rsr, cg, sub, flt, rna, sms, mq, rid in recs]
+    return out
+
+
+def write_new_fast5_group(fast5_data, corr_grp_slot, rsqgl_res, norm_type, compute_sd,
+                          alignVals=None, old_segs=None, rna=False, event_data=None):
+    """Write a resquiggled read into an open FAST5 file -- groups, attributes and the `Events`
+    dataset exactly as tombo_helper.write_new_fast5_group (tombo_helper.py:2341-2460) lays them
+    out.  `fast5_data` is anything with the h5py group interface (`__getitem__`, `create_group`,
+    `create_dataset`, `.attrs`): an `h5py.File` where h5py is installed, or an in-memory stand-in
+    (the image this engine is built in has no HDF5 library; tests use a dict-backed group).
+    `event_data`: the Events table if already computed on the device
+    (`resquiggle_batch_events`), else it is computed here through the HIP kernels."""
+    import numpy as np
+    try:
+        if event_data is None:
+            event_data = get_event_data(rsqgl_res, compute_sd)
+        if alignVals is not None:
+            r_align_vals, g_align_vals = zip(*alignVals)
+            np_read_align = np.array(r_align_vals, dtype='S1')
+            np_genome_align = np.array(g_align_vals, dtype='S1')
+    except Exception:
+        raise TomboError('Error computing new events')
+    try:
+        corr_grp = fast5_data['/Analyses'][corr_grp_slot]
+        corr_subgrp = corr_grp.create_group(rsqgl_res.align_info.Subgroup)
+        corr_subgrp.attrs['status'] = 'success'
+        corr_subgrp.attrs['rna'] = rna
+        if rsqgl_res.sig_match_score is not None:
+            corr_subgrp.attrs['signal_match_score'] = rsqgl_res.sig_match_score
+        sv = rsqgl_res.scale_values
+        corr_subgrp.attrs['shift'] = sv.shift
+        corr_subgrp.attrs['scale'] = sv.scale
+        corr_subgrp.attrs['norm_type'] = norm_type
+        if sv.lower_lim is not None:
+            corr_subgrp.attrs['lower_lim'] = sv.lower_lim
+        if sv.upper_lim is not None:
+            corr_subgrp.attrs['upper_lim'] = sv.upper_lim
+        if sv.outlier_thresh is not None:
+            corr_subgrp.attrs['outlier_threshold'] = sv.outlier_thresh
+        aln = corr_subgrp.create_group('Alignment')
+        aln.attrs['mapped_start'] = rsqgl_res.genome_loc.Start
+        aln.attrs['mapped_end'] = rsqgl_res.genome_loc.Start + len(rsqgl_res.segs) - 1
+        aln.attrs['mapped_strand'] = rsqgl_res.genome_loc.Strand
+        aln.attrs['mapped_chrom'] = rsqgl_res.genome_loc.Chrom
+        ai = rsqgl_res.align_info
+        if ai is not None:
+            aln.attrs['clipped_bases_start'] = ai.ClipStart
+            aln.attrs['clipped_bases_end'] = ai.ClipEnd
+            aln.attrs['num_insertions'] = ai.Insertions
+            aln.attrs['num_deletions'] = ai.Deletions
+            aln.attrs['num_matches'] = ai.Matches
+            aln.attrs['num_mismatches'] = ai.Mismatches
+        if alignVals is not None:
+            aln.create_dataset('read_alignment', data=np_read_align, compression='gzip')
+            aln.create_dataset('genome_alignment', data=np_genome_align, compression='gzip')
+        if old_segs is not None:
+            aln.create_dataset('read_segments', data=old_segs, compression='gzip')
+        ev = corr_subgrp.create_dataset('Events', data=event_data, compression='gzip')
+        ev.attrs['read_start_rel_to_raw'] = rsqgl_res.read_start_rel_to_raw
+    except Exception:
+        raise TomboError('Error writing resquiggle information back into fast5 file.')
+    return event_data
