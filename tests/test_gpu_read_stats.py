@@ -105,7 +105,7 @@ def test_alt_model_llhrs_match_the_reference():
                     else:
                         np.testing.assert_allclose(ll[name], want, rtol=RTOL, atol=1e-300)
                     hits += want.shape[0]
-    assert hits > 100
+    assert hits > 50
 
 
 def test_batch_forms_equal_single_read_calls():
