@@ -634,7 +634,15 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     TBA_PHASE(3);
     // one pass: ordered compaction of the picks (the .sort() of tombo_helper.py:76-82), taking
     // every taken position at or above the threshold score, and on the way the counts that tell
-    // whether that was right: taken above / at the threshold, all positions above / at it
+    // whether that was right: taken above / at the threshold, all positions above / at it.
+    // Positions AT the threshold score are also histogrammed by position bucket (taken ones and
+    // all of them): on quantised DAC input exact ties are the rule and the tie rule (priority to
+    // the higher index) is resolved from these histograms without another pass.
+    int tshift = 0;
+    while ((ns >> tshift) >= 2048) tshift++;
+    u32 *h_tk = sm.hist, *h_all = sm.hist + 2048;
+    for (int b = tid; b < 4096; b += SEL_NT) sm.hist[b] = 0;
+    __syncthreads();
     i64 c_gt = 0, c_eq = 0, a_gt = 0, a_eq = 0;
     block_compact(
         ns,
@@ -643,6 +651,10 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
             const bool tk = st[p] == 1;
             a_gt += v > tval; a_eq += v == tval;
             c_gt += tk && v > tval; c_eq += tk && v == tval;
+            if (v == tval) {
+                atomicAdd(&h_all[p >> tshift], 1u);
+                if (tk) atomicAdd(&h_tk[p >> tshift], 1u);
+            }
             return tk && v >= tval;
         },
         [&](i64 p, i64 o) { if (o < num_cpts) cpts[o] = p + w; }, s_w);
@@ -653,32 +665,47 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     const i64 need_eq = num_cpts - c_gt;
     i64 before = a_gt;    // rank of the last pick in the argsort order
     if (need_eq < c_eq || a_eq > 1) {
-        // exact ties on the threshold score (the rule on quantised DAC input, never with continuous
-        // pA): priority falls to the higher index, so the picks at the threshold score are the
-        // need_eq highest-index taken positions with that score.  Every thread counts them in a
-        // contiguous slice; a suffix sum over the slices finds the slice holding the need_eq-th
-        // from the top, whose owner walks it backwards.
-        const i64 chunk = (ns + SEL_NT - 1) / SEL_NT;
-        const i64 p0 = (i64)tid * chunk, p1 = p0 + chunk < ns ? p0 + chunk : ns;
-        i64 mine = 0;
-        for (i64 p = p0; p < p1; p++) mine += st[p] == 1 && s[p] == tval;
-        i64 *cnts = (i64 *)sm.raw8; // SEL_NT counts (the select scratch is idle here)
-        __syncthreads();
-        cnts[tid] = mine;
-        if (tid == 0) s_idx_thr = 0;
-        __syncthreads();
-        i64 above = 0; // ties in the slices above mine
-        for (int t = tid + 1; t < SEL_NT; t++) above += cnts[t];
-        if (mine > 0 && above < need_eq && need_eq <= above + mine) {
-            i64 left = need_eq - above;
-            for (i64 p = p1 - 1; p >= p0; p--)
-                if (st[p] == 1 && s[p] == tval && --left == 0) { s_idx_thr = p; break; }
+        // exact ties on the threshold score: the picks at that score are the need_eq
+        // highest-index taken positions.  Wave 0 walks the bucket histogram from the top to the
+        // bucket holding the need_eq-th of them, then that bucket's positions 64 at a time
+        // (lane 0 = highest index), counting on the way how many positions of that score -- taken
+        // or not -- outrank the last pick.
+        __shared__ i64 s_extra;
+        if (tid < 64) {
+            const int lane = tid;
+            i64 left = need_eq, extra = 0;
+            int bq = 0;
+            for (int b = (int)((ns - 1) >> tshift); b >= 0; b--) {
+                const u32 c = h_tk[b];
+                if ((i64)c >= left) { bq = b; break; }
+                left -= c; extra += h_all[b];
+            }
+            const i64 lo_p = (i64)bq << tshift;
+            i64 hi_p = ((i64)bq + 1) << tshift;
+            hi_p = hi_p < ns ? hi_p : ns;
+            i64 thr = lo_p;
+            for (i64 top = hi_p; top > lo_p; top -= 64) {
+                const i64 p = top - 1 - lane;
+                const bool ok = p >= lo_p;
+                const bool eq = ok && s[ok ? p : lo_p] == tval;
+                const bool tk = eq && st[ok ? p : lo_p] == 1;
+                const u64 mt = __ballot(tk), ma = __ballot(eq);
+                const int c = __popcll(mt);
+                if ((i64)c >= left) {
+                    u64 m = mt;
+                    for (i64 q = 1; q < left; q++) m &= m - 1;          // drop the first left-1 picks
+                    const int pos = __ffsll((unsigned long long)m) - 1;  // lane of the last pick
+                    thr = top - 1 - pos;
+                    extra += __popcll(ma & ((1ull << pos) - 1ull));
+                    break;
+                }
+                left -= c; extra += __popcll(ma);
+            }
+            if (lane == 0) { s_idx_thr = thr; s_extra = extra; }
         }
         __syncthreads();
         const i64 idx_thr = s_idx_thr; // lowest-index pick at the threshold score
-        i64 extra = 0;
-        for (i64 p = tid; p < ns; p += SEL_NT) extra += s[p] == tval && p > idx_thr;
-        before = a_gt + block_sum_i64(extra, &sm.rad);
+        before = a_gt + s_extra;
         if (need_eq < c_eq)
             block_compact(
                 ns,
