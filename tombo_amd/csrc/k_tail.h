@@ -182,8 +182,23 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
 // get_deletion_windows (resquiggle.py:462-498) + per-window scratch sizing; one thread per read.
 // win[3*k..] = (start, end, scratch offset inside the read's slice); r.n_win, r.skip_off (need,
 // turned into an arena offset by k_scan_skip).
+// Windows of at least SKIP_WAVE_MIN positions (bases x admissible interval) whose interval is at
+// most SKIP_WAVE_LEN samples are resolved by a whole wavefront out of LDS (k_skip_dp_wave): the
+// kernel time of the lane-per-window form is the serial walk of its LARGEST window (RNA: mean 3.5 k
+// positions per read, but 28 k in the largest window of a 10 k-read batch).  win[3k+2] = -1 marks
+// them; the rest keep their offset inside the read's slice of the global scratch arena.
+// Two LDS classes (interval length, flag words); windows of a class are queued in a global list
+// (skipq: [0] / [1] = entries of the small / big list, [2] / [3] = next entry to hand out) that a
+// fixed grid of wavefronts drains, so no workgroup is launched per read.
+#define SKIP_WAVE_MIN 512
+#define SKIP_LEN_S 320
+#define SKIP_BITS_S 128
+#define SKIP_LEN_B 1280
+#define SKIP_BITS_B 1024 // u64 words of traceback flags (n * ceil(len / 64))
+
 __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp,
-    const i64 *dp_segs, i64 *win_scratch)
+    const i64 *dp_segs, i64 *segs_out, i64 *win_scratch, i64 *skipq, i32 *list_s, i32 *list_b,
+    i64 list_cap)
 {
     (void)n_reads;
     ReadState &r = rs[blockIdx.x];
@@ -193,6 +208,8 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
     const i64 m = dp->p.raw_min_obs_per_base;
     const i64 n_segs = r.B + 1;
     const i64 *ds = dp_segs + r.seg_off;
+    // the resolved boundaries start as a copy; the window kernels overwrite their interiors
+    for (i64 i = lane; i < n_segs; i += 64) segs_out[r.seg_off + i] = ds[i];
     // skipped bases (diff(segs) == 0), found by all lanes, kept in order behind the window area
     i64 *dels = win_scratch + 3 * r.seg_off + 2 * n_segs;
     i64 n_del = 0;
@@ -253,11 +270,266 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
         const i64 L = ds[e] - ds[s];
         const i64 len = L - (n - 1) * m;
         if (len <= 0 || n < 2) { r.status = TBA_INTERNAL; return; }
+        const i64 fw = n * ((len + 63) / 64);
+        int cls = -1;
+        if (n * len >= SKIP_WAVE_MIN) {
+            // (L = len + (n - 1) m must fit the staged signal, n the staged levels)
+            const bool fits = (n - 1) * m <= 512 && n <= 256;
+            if (fits && len <= SKIP_LEN_S && fw <= SKIP_BITS_S) cls = 0;
+            else if (fits && len <= SKIP_LEN_B && fw <= SKIP_BITS_B) cls = 1;
+        }
+        if (cls >= 0) { // queue for k_skip_dp_wave (a full list leaves the window to the lane form)
+            const i64 pos = (i64)atomicAdd((unsigned long long *)&skipq[cls], 1ull);
+            if (pos < list_cap) {
+                i32 *lst = cls == 0 ? list_s : list_b;
+                lst[2 * pos] = (i32)blockIdx.x; lst[2 * pos + 1] = (i32)i;
+                w3[3 * i + 2] = -1;
+                continue;
+            }
+        }
         w3[3 * i + 2] = acc;
         acc += raw_window_need(n, len);
     }
     r.n_win = nw;
     r.skip_off = acc;
+}
+
+// raw-signal DP of one (large) window by one WAVEFRONT out of LDS.  Same arithmetic, in the same
+// order, as raw_window_dp (c_reg_z_scores -> raw_forward_pass / c_base_forward_pass ->
+// raw_traceback / c_base_traceback).  What is independent per signal position -- the z-scores of a
+// base, the lag search and the diagonal source of every position (pyx:127-140), the traceback
+// comparison of adjacent rows -- is spread over the 64 lanes; the two serial chains (np.cumsum,
+// the stay recurrence) run on lane 0 out of registers, eight positions per LDS round trip.  Only
+// two forward rows are live: the traceback's test "previous base's score > this base's score"
+// (pyx:176-180) is evaluated for every position when a row is finished and kept as one bit.
+template <int LEN, int BITS>
+struct SkipWaveSmem {
+    double row[2][LEN];            // forward scores of the previous / current base
+    double za[LEN], zb[LEN], cuma[LEN], cumb[LEN], dg[LEN];
+    i32 la[LEN], lb[LEN];          // last-diagonal counters
+    u64 bits[BITS];                // row b, word w: bits[b * words + w]
+    double sg[LEN + 512];          // the window's signal (L = len + (n - 1) m)
+    double mu[256], sd[256];       // expected level / sd of the window's bases
+};
+#ifdef TBA_SKIP_STATS
+#define SKP(i_) do { const i64 t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) skp[i_] += t_ - tl_; tl_ = __builtin_readcyclecounter(); } while (0)
+#else
+#define SKP(i_) do { } while (0)
+#endif
+template <int LEN, int BITS>
+__device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double *means,
+    const double *sds, i64 n, i64 m, bool winsor, double mh, SkipWaveSmem<LEN, BITS> &S, i64 *new_segs
+#ifdef TBA_SKIP_STATS
+    , i64 *skp
+#endif
+    )
+{
+    const int lane = threadIdx.x;
+#ifdef TBA_SKIP_STATS
+    i64 tl_ = __builtin_readcyclecounter();
+#endif
+    if (n < 2) return TBA_INTERNAL;
+    const i64 len = L - (n - 1) * m;
+    if (len <= m || len > LEN) return TBA_INTERNAL; // (the planner's windows always have len > 2 m)
+    const i64 words = (len + 63) / 64;
+    if (n * words > BITS) return TBA_INTERNAL;
+    double *zp = S.za, *zc = S.zb, *cum = S.cuma, *cumn = S.cumb;
+    i32 *pl = S.la, *bl = S.lb;
+    if (L > LEN + 512 || n > 256) return TBA_INTERNAL;
+    // the whole window's signal and levels come into LDS in one go (all loads in flight together:
+    // one global round trip per window instead of one per base)
+    for (i64 k = lane; k < L; k += 64) S.sg[k] = sig[k];
+    for (i64 k = lane; k < n; k += 64) { S.mu[k] = means[k]; S.sd[k] = sds[k]; }
+    for (i64 k = lane; k < len; k += 64) pl[k] = (i32)m;
+    __syncthreads();
+    auto zrow = [&](i64 base, double *z) { // c_base_z_scores, pyx:17-32
+        const double *x = S.sg + base * m;
+        const double mu = S.mu[base], sd = S.sd[base];
+        for (i64 k = lane; k < len; k += 64) {
+            double v = (x[k] - mu) / sd;
+            if (v > 0) v = -v;
+            if (winsor && v < -mh) v = -mh;
+            z[k] = v;
+        }
+    };
+    zrow(0, zp);
+    __syncthreads();
+    if (lane == 0) { // first row: np.cumsum (resquiggle.py:352-361) = the cumulative z-scores too
+        double acc = 0;
+        for (i64 k0 = 0; k0 < len; k0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = zp[k0 + u < len ? k0 + u : len - 1];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { acc = k0 + u == 0 ? t[u] : acc + t[u]; t[u] = acc; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (k0 + u < len) { S.row[0][k0 + u] = t[u]; cum[k0 + u] = t[u]; }
+        }
+    }
+    int bad = 0;
+    for (i64 i = 1; i < n; i++) { // c_base_forward_pass, pyx:99-163
+        const double *pf = S.row[(i - 1) & 1];
+        double *bf = S.row[i & 1];
+        SKP(3);
+        zrow(i, zc);
+        __syncthreads();
+        SKP(4);
+        // cum = np.cumsum of the previous base's scores (left by the previous row's walk)
+        const i64 k_last = len - m < len - 1 ? len - m : len - 1; // pos <= pe, k = pos - b_s < len
+        for (i64 k = 1 + lane; k <= k_last; k += 64) { // diagonal sources
+            i64 lag = 1;
+            for (;;) {
+                const i64 idx = k + m - lag;
+                if (idx < 0 || idx >= len) { bad = 1; break; }
+                if (pl[idx] + lag <= m) lag++;
+                else break;
+            }
+            if (bad) break;
+            const i64 di = k + m - lag;
+            double diag = pf[di];
+            if (lag > 1) diag += cum[k + m - 1] - cum[di];
+            S.dg[k] = diag;
+        }
+        __syncthreads();
+        SKP(5);
+        if (lane == 0) { // the stay recurrence, and on the way this base's cumulative z-scores
+            double stay_run = zc[0] + pf[m - 1];
+            double csum = zc[0];
+            i32 bl_run = 1;
+            bf[0] = stay_run; bl[0] = 1; cumn[0] = csum;
+            // branch-free: a lone lane pays dearly for every exec-mask branch, so the two forms of
+            // a step (inside / past the previous base's interval, pyx:142-161) and the end of the
+            // row are selects.  Past the interval best = stay_run, i.e. zv + stay_run: the
+            // reference's running sum with the operands swapped (addition commutes exactly).
+            for (i64 k0 = 1; k0 < len; k0 += 8) {
+                double dv[8], zv[8], cv[8];
+                i32 lv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const i64 k = k0 + u < len ? k0 + u : len - 1;
+                    dv[u] = S.dg[k <= k_last ? k : k_last]; zv[u] = zc[k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const i64 k = k0 + u;
+                    const bool in = k < len;
+                    const bool take = k <= k_last && dv[u] > stay_run;
+                    const double best = take ? dv[u] : stay_run;
+                    const i32 nd = take ? 1 : bl_run + 1;
+                    const double ns_ = zv[u] + best, nc_ = csum + zv[u];
+                    stay_run = in ? ns_ : stay_run;
+                    bl_run = in ? nd : bl_run;
+                    csum = in ? nc_ : csum;
+                    dv[u] = stay_run; lv[u] = bl_run; cv[u] = csum;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const i64 k = k0 + u < len ? k0 + u : len - 1; // (tail lanes rewrite the last slot)
+                    bf[k] = dv[u]; bl[k] = lv[u]; cumn[k] = cv[u];
+                }
+            }
+        }
+        if (__syncthreads_or(bad)) return TBA_INTERNAL;
+        SKP(6);
+        // traceback test of this base: position sp <-> j = sp - cs - 1 in this row, j + m in the
+        // previous one; bit j = previous[j + m] > this[j]
+        for (i64 w0 = 0; w0 < words; w0++) {
+            const i64 j = w0 * 64 + lane;
+            const bool f = j + m < len && pf[j + m < len ? j + m : 0] > bf[j < len ? j : 0];
+            const u64 mk = __ballot(f);
+            if (lane == 0) S.bits[i * words + w0] = mk;
+        }
+        __syncthreads();
+        i32 *t = pl; pl = bl; bl = t;
+        double *tz = zp; zp = zc; zc = tz;
+        tz = cum; cum = cumn; cumn = tz;
+        SKP(7);
+    }
+    int rc = TBA_OK;
+    if (lane == 0) { // raw_traceback / c_base_traceback, pyx:165-182
+        // The reference walks sp down from sig_start: the first m - 1 positions and those with
+        // sp - 1 >= next_end are passed over, then the first position with sp <= curr_start or
+        // with the flag set is returned.  Same result without the walk: start at
+        // min(sig_start - (m - 1), next_end); at or below curr_start -> that position; else the
+        // highest set flag at or below it (word-wise), else curr_start.
+        i64 sig_start = (n - 1) * m + len - 1;
+        for (i64 b = n - 1; b >= 1; b--) {
+            const i64 cs = b * m, ne = (b - 1) * m + len;
+            i64 st = sig_start - (m - 1);
+            st = st < ne ? st : ne;
+            i64 found;
+            if (st < 0) { rc = TBA_INTERNAL; break; }
+            if (st <= cs) found = st;
+            else {
+                found = cs;
+                const u64 *bw = S.bits + b * words;
+                i64 j = st - cs - 1; // highest candidate flag
+                for (i64 w0 = j >> 6; w0 >= 0; w0--) {
+                    u64 v = bw[w0];
+                    if (w0 == (j >> 6) && (j & 63) != 63) v &= (1ull << ((j & 63) + 1)) - 1ull;
+                    if (v) { found = cs + 1 + w0 * 64 + (63 - __clzll((long long)v)); break; }
+                }
+            }
+            new_segs[b - 1] = found;
+            sig_start = found - 1;
+        }
+    }
+    return __syncthreads_or(rc != TBA_OK) ? TBA_INTERNAL : TBA_OK;
+}
+
+// drains one window queue: a fixed grid of one-wavefront workgroups, each fetching the next
+// queued (read, window) until the list is empty
+template <int LEN, int BITS, int CLS>
+__global__ __launch_bounds__(64) void k_skip_dp_wave(ReadState *rs, const DevParams *dp,
+    const double *norm, const double *ref_means, const double *ref_sds, const i64 *dp_segs,
+    i64 *segs, const i64 *win_scratch, i64 *skipq, const i32 *list, i64 list_cap)
+{
+    __shared__ SkipWaveSmem<LEN, BITS> S;
+    __shared__ i64 s_id;
+    const tba_params &P = dp->p;
+    const i64 m = P.raw_min_obs_per_base;
+    i64 total = skipq[CLS];
+    total = total < list_cap ? total : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_id = (i64)atomicAdd((unsigned long long *)&skipq[2 + CLS], 1ull);
+        __syncthreads();
+        const i64 id = s_id;
+        if (id >= total) break;
+        ReadState &r = rs[list[2 * id]];
+        const i64 i = list[2 * id + 1];
+        const i64 *ds = dp_segs + r.seg_off;
+        i64 *out = segs + r.seg_off;
+        const double *sig = norm + r.raw_off + r.read_start;
+        const i64 *w3 = win_scratch + 3 * r.seg_off;
+        const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
+        const i64 sig_start = ds[s], sig_end = ds[e];
+        int rc = TBA_OK;
+#ifdef TBA_SKIP_STATS
+        const i64 t0_ = __builtin_readcyclecounter();
+#endif
+        if (sig_start < 0 || sig_end > r.norm_len) rc = TBA_INTERNAL;
+        else {
+            rc = raw_window_dp_wave<LEN, BITS>(sig + sig_start, sig_end - sig_start,
+                                               ref_means + r.ref_off + s, ref_sds + r.ref_off + s, n, m,
+                                               P.do_winsorize_z != 0, P.max_half_z_score, S, out + s + 1
+#ifdef TBA_SKIP_STATS
+                                               , r.dbg
+#endif
+                                               );
+            if (rc == TBA_OK)
+                for (i64 k = threadIdx.x; k < n - 1; k += 64) out[s + 1 + k] += sig_start;
+        }
+        // (every failure of the window DP is the same "unexpected error" status)
+        if (rc != TBA_OK && threadIdx.x == 0) r.status = rc;
+#ifdef TBA_SKIP_STATS
+        if (threadIdx.x == 0) {
+            atomicAdd((unsigned long long *)&r.dbg[0], 1ull);
+            atomicAdd((unsigned long long *)&r.dbg[1], (unsigned long long)(__builtin_readcyclecounter() - t0_));
+            atomicAdd((unsigned long long *)&r.dbg[2], (unsigned long long)(n * (sig_end - sig_start - (n - 1) * m)));
+        }
+#endif
+    }
 }
 
 // rq.resolve_skipped_bases_with_raw window loop + final checks (resquiggle.py:500-538).
@@ -277,11 +549,13 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
     const double *sig = norm + r.raw_off + r.read_start; // norm_signal[read_start:...]
     const i64 n_norm = r.norm_len;
     const double *mu = ref_means + r.ref_off, *sd = ref_sds + r.ref_off;
-    for (i64 i = lane; i < n_segs; i += 64) out[i] = ds[i];
-    __syncthreads();
+    // (out already holds the copy of dp_segs made by k_skip_plan, with the interiors of the large
+    // windows resolved by k_skip_dp_wave; what is left here are the other windows, one per lane
+    // over global scratch, and the final checks)
     const i64 *w3 = win_scratch + 3 * r.seg_off;
     int rc = TBA_OK;
     for (i64 i = lane; i < r.n_win; i += 64) {
+        if (w3[3 * i + 2] < 0) continue;
         const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
         const i64 sig_start = ds[s], sig_end = ds[e];
         if (sig_start < 0 || sig_end > n_norm) { rc = TBA_INTERNAL; break; }

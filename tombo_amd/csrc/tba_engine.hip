@@ -83,6 +83,7 @@ struct tba_engine {
     int raw_dtype = TBA_RAW_F64;
     PinBuf h_rs, h_dp;            // ReadState[n] / DevParams as uploaded (pinned)
     DevBuf d_res, d_segs32;       // packed results of tba_batch_download_async
+    DevBuf d_skipq;               // window queues of k_skip_dp_wave
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_bm, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
@@ -93,7 +94,7 @@ struct tba_engine {
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_bm, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32};
+                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq};
         for (DevBuf *b : all) b->release();
         h_rs.release();
         h_dp.release();
@@ -307,6 +308,7 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     BUF(d_dscr, (size_t)z.skip_arena * 8);
     if (z.wide_w) BUF(d_wide, (size_t)WIDE_BLOCKS * 2 * (size_t)z.wide_w * 8);
     if (z.n_stall > 0) BUF(d_stall, (size_t)z.n_stall * 16);
+    BUF(d_skipq, 64 + 2 * (N * 32 + 4096) * 8);
     BUF(d_res, N * sizeof(tba_read_result));
     BUF(d_segs32, (Bt + N) * 4);
 #undef BUF
@@ -549,8 +551,15 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 11 skip resolve
     if (ON(TBA_STAGE_SKIP)) {
-        k_skip_plan<<<nb, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_win.as<i64>());
+        // window queues of the wave-per-window kernels: counters + two (read, window) lists
+        const i64 qcap = n * 32 + 4096;
+        i64 *skipq = e->d_skipq.as<i64>();
+        i32 *list_s = (i32 *)(skipq + 8), *list_b = list_s + 2 * qcap;
+        HIP_TRY(hipMemsetAsync(skipq, 0, 64, s));
+        k_skip_plan<<<nb, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, list_s, list_b, qcap);
         k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
+        k_skip_dp_wave<SKIP_LEN_S, SKIP_BITS_S, 0><<<2048, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, list_s, qcap);
+        k_skip_dp_wave<SKIP_LEN_B, SKIP_BITS_B, 1><<<512, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, list_b, qcap);
         k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
     }
     MARK(); // 12 theil-sen

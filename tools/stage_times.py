@@ -62,6 +62,8 @@ def main():
     if os.environ.get('TBA_DBG_PHASES'):
         d = eng.get(_native.GET_DEBUG_COUNTERS)
         print('dbg mean', ' '.join('%.0f' % x for x in d.mean(axis=0)))
+        print('dbg sum ', ' '.join('%.0f' % x for x in d.sum(axis=0)))
+        print('dbg max ', ' '.join('%.0f' % x for x in d.max(axis=0)))
 
 
 if __name__ == '__main__':
