@@ -5,9 +5,11 @@
 // find_seq_start_in_events, _get_masked_start_fwd_pass, find_static_base_assignment,
 // find_adaptive_base_assignment (resquiggle.py:547-1050).
 //
-// Layout: the two live band rows sit in LDS (transposed so that both "my CPL cells" and
-// "previous row shifted by the band offset" are conflict-free); each lane owns CPL contiguous
-// band cells in registers.  Cell update (pyx:213-234): v[b] = max(stay, diag, skip) with
+// Layout: each lane owns CPL contiguous band cells and keeps its cells of the previous row in
+// registers; the cells a row needs from it ("previous row shifted by the band offset") are a
+// compile-time register renaming per offset plus a few DPP moves for the cells of the next lane
+// (cand_row), no LDS round trip.  LDS only holds a ring of the read's event means around the band.
+// Cell update (pyx:213-234): v[b] = max(stay, diag, skip) with
 // stay = (v[b-1] - stay_pen) + z[b] serial along the row.  The diag/skip candidates are
 // independent per cell; the stay chain is resolved *exactly* by a monotone fixed-point sweep:
 // every lane walks its CPL cells from a guessed incoming value (-inf first), lanes exchange

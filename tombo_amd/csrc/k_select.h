@@ -44,7 +44,7 @@ __device__ void block_select(F f, i64 n, i64 k, SelectSmem *sm)
     if (tid == 0) { sm->prefix = 0; sm->k = k; sm->n_less = 0; sm->n_eq = 0; }
     __syncthreads();
     for (int pass = 7; pass >= 0; pass--) {
-        sm->hist[tid & 255] = 0; // SEL_NT == 256
+        sm->hist[tid & 255] = 0; // (SEL_NT >= 256 threads clear the 256 bins)
         __syncthreads();
         const u64 prefix = sm->prefix;
         const int sh = 8 * pass;
