@@ -203,3 +203,82 @@ def test_planner_cuts_by_memory_and_orders_by_length():
     plan2 = planner.plan_batches(S, L, p, o, 6, budget, np.int16, sort=False)
     assert np.array_equal(np.concatenate(plan2), np.arange(3000))
     assert planner.exact_bytes(S, L, p, o, 6, np.int16) < planner.exact_bytes(S, L, p, o, 6, np.float64)
+
+
+def test_stream_pipeline_slot_logic_with_stub_engines(monkeypatch):
+    """host logic of streaming.StreamPipeline without a GPU: slots are used round-robin, a slot's
+    previous batch is finished before it is reused, results come back in submission order and the
+    two output sets of a slot alternate (a handed-out result is not overwritten by the next batch
+    of its slot)"""
+    import numpy as np
+    from tombo_amd import streaming, _native, tombo_stats as ts, tombo_helper as th
+
+    log = []
+
+    class StubEngine(object):
+        n_made = 0
+
+        def __init__(self, device):
+            self.id = StubEngine.n_made
+            StubEngine.n_made += 1
+            self.kmer_width = 6
+
+        def ensure_model(self, m):
+            pass
+
+        def upload_packed(self, p, o, raw, raw_off, seq, seq_off, **kw):
+            self.n = len(raw_off) - 1
+            self.raw_off = np.asarray(raw_off)
+            self.seg_off = np.arange(self.n + 1) * 3
+            self.n_raw_total = int(raw_off[-1])
+            self.tag = int(raw[0])
+            log.append(('up', self.id, self.tag))
+
+        def enqueue(self):
+            log.append(('run', self.id, self.tag))
+
+        def download_async(self, results=None, segs32=None, segs64=None, norm=None):
+            self._out = (results, segs32)
+            results['status'][:self.n] = 0
+            results['read_start_rel_to_raw'][:self.n] = self.tag   # "computed" at enqueue time
+            segs32[:int(self.seg_off[-1])] = self.tag
+
+        def sync(self):
+            log.append(('sync', self.id, self.tag))
+
+        def get(self, what):
+            return np.zeros(32, np.float32)
+
+        def close(self):
+            pass
+
+    class StubPinned(object):
+        def __init__(self, shape, dtype):
+            self.a = np.zeros(shape, dtype)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(_native, 'Engine', StubEngine)
+    monkeypatch.setattr(_native, 'PinnedArray', StubPinned)
+    samp = th.seqSampleType('DNA', False)
+    params = ts.load_resquiggle_parameters(samp)
+    pipe = streaming.StreamPipeline(None, params, n_slots=2, device=0, outlier_thresh=5.0)
+    batches = [streaming.ReadBatch(np.full(4, t, np.int16), np.array([0, 2, 4]), np.zeros(8, np.uint8),
+                                   np.array([0, 4, 8]), tag=t) for t in range(5)]
+    held = []
+    for res in pipe.run(batches):
+        held.append(res)
+        # every result still shows its own batch, also the ones handed out earlier that are at
+        # most n_slots batches old
+        for r in held[-2:]:
+            assert int(r.results['read_start_rel_to_raw'][0]) == r.tag
+            assert int(r.segs[0]) == r.tag
+    assert [r.tag for r in held] == [0, 1, 2, 3, 4]
+    ups = [e for e in log if e[0] == 'up']
+    assert [e[1] for e in ups] == [0, 1, 0, 1, 0]                  # round-robin over two slots
+    # a slot is synced (its old batch finished) before it is uploaded again
+    for k, e in enumerate(log):
+        if e[0] == 'up' and e[2] >= 2:
+            assert ('sync', e[1], e[2] - 2) in log[:k]
+    pipe.close()
