@@ -209,13 +209,28 @@ __global__ __launch_bounds__(256) void k_scores_dna(const ReadState *rs, const D
 // about one memory round trip, 32 reads x 128 samples per workgroup keep enough of them in
 // flight (measured against 64 x 64 tiles, an LDS-only barrier and separate load / store waves:
 // all slower).
-#define CS_READS 32
+// Reads per workgroup: a template parameter, chosen per launch (cs_reads_for).  A workgroup's LDS
+// is CS_READS x 3.6 KB: 32 reads = 115 KB = one workgroup per CU (8 192 reads per round of
+// workgroups), 20 reads = 72 KB = two per CU (10 240 per round).  The kernel is latency bound -- a
+// round costs n_steps memory round trips whatever its width -- so what counts is the number of
+// rounds: the 10 000-read batch is 2 rounds at 32 (the second 22 % full: 7.1 ms) and 1 at 20
+// (3.3 ms); a 4 096-read batch is one round either way and the wider workgroup, alone on its
+// CU, is faster (2.4 vs 3.7 ms).  (Normalising the raw samples inside the loaders, so that
+// k_normalize needs no final pass, was measured twice: 7 -> 19 ms at 32 reads (spills), 3.3 ->
+// 8.2 ms at 20 (float64 input; 15 ms for int16) against 2.8 ms saved in k_normalize.)
 #define CS_CHUNK 128
 #define CS_STRIDE (CS_CHUNK + 1)
-#define CS_UNITS 22 // half rows per loader wave: 3 x 22 >= 2 x CS_READS, even so halves pair up
+__host__ inline int cs_reads_for(i64 n_reads)
+{
+    const i64 r32 = (n_reads + 8191) / 8192, r20 = (n_reads + 10239) / 10240;
+    return r20 < r32 ? 20 : 32;
+}
+template <int CS_READS>
 __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 n_reads,
     const DevParams *dp, const double *__restrict__ norm, double *__restrict__ score)
 {
+    // half rows per loader wave: 3 x CS_UNITS >= 2 x CS_READS, even so halves pair up
+    constexpr int CS_UNITS = (((2 * CS_READS + 2) / 3) + 1) & ~1;
     __shared__ double tile[3][CS_READS * CS_STRIDE];
     __shared__ double halo[CS_READS * 64]; // row q: the 2w sums before the tile being stored
     __shared__ i64 s_off[CS_READS], s_n[CS_READS];

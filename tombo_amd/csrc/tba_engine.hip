@@ -497,7 +497,10 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0, 1)));
     MARK(); // 1 cumsum
     if (ON(TBA_STAGE_SEGMENT) && !rna) {
-        if (fused_scores) k_cumsum_scores<<<(unsigned)((n + CS_READS - 1) / CS_READS), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
+        if (fused_scores) {
+            if (cs_reads_for(n) == 20) k_cumsum_scores<20><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
+            else k_cumsum_scores<32><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
+        }
         else k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
     }
     MARK(); // 2 scores
@@ -1125,7 +1128,7 @@ static int c_valid_cpts(tba_engine *e, const double *sig, int64_t n, int64_t min
     hipStream_t s = e->stream;
     const unsigned g = grid_for(n) > 128 ? 128 : grid_for(n);
     if (!ttest && 2 * width <= 64) { // the batch pipeline's fused form
-        k_cumsum_scores<<<1, 256, 0, s>>>(d_rs.as<ReadState>(), 1, d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
+        k_cumsum_scores<32><<<1, 256, 0, s>>>(d_rs.as<ReadState>(), 1, d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
     } else if (!ttest) {
         k_cumsum<<<1, 64, 0, s>>>(d_rs.as<ReadState>(), 1, d_sig.as<double>(), d_csum.as<double>());
         k_scores_dna<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_csum.as<double>(), d_score.as<double>());
