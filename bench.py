@@ -295,7 +295,7 @@ def main():
                     help='end-to-end (host in -> host out) measurement: int16 in / records + '
                          'int32 boundaries out, float64 in / float64 signal + int64 boundaries '
                          'out, or skipped')
-    ap.add_argument('--stream-batch', type=int, default=4096, help='reads per streamed batch')
+    ap.add_argument('--stream-batch', type=int, default=5000, help='reads per streamed batch')
     ap.add_argument('--slots', type=int, default=3, help='engine slots per GPU of the streaming pipeline')
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
