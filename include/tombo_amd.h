@@ -63,6 +63,8 @@ enum {
 enum { TBA_E_ARG = -1, TBA_E_HIP = -2, TBA_E_NOMEM = -3, TBA_E_STATE = -4 };
 
 #define TBA_MAX_BAND 3072 /* widest DP band (cells per row) the wave-per-read kernel carries */
+#define TBA_MAX_BATCH_READS 65535 /* reads per batch (a launch-grid dimension); longer lists are
+                                     cut into batches by the host (tombo_amd/planner.py) */
 
 /* th.resquiggleParams (tombo/tombo_helper.py:173-198) */
 typedef struct {

@@ -179,3 +179,29 @@ def test_failed_upload_does_not_leave_forced_event_counts_armed():
                [ts.encode_seq(seq)])
     eng.run_stages(_native.STAGE_SEGMENT, _native.STAGE_SEGMENT)
     assert int(eng.get(_native.GET_N_CPTS)[0]) == int(eng.num_events[0]) != 7
+
+
+def test_long_read_lists_are_cut_and_oversized_batches_refused():
+    """more reads than one batch may hold (a launch-grid dimension): resquiggle_batch cuts the
+    list on its own, the raw engine call refuses"""
+    from tombo_amd import _native, resquiggle as rq, planner, synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    base = [synth.synth_map_res(model, 150, 9000 + i, **synth.DNA_SYNTH) for i in range(8)]
+    n = planner.MAX_READS + 700
+    mrs = [base[i % 8] for i in range(n)]
+    res = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp)
+    assert len(res) == n
+    ref = rq.resquiggle_batch(base, model, params, outlier_thresh=5.0, seq_samp_type=samp)
+    for i in (0, 5, planner.MAX_READS - 1, planner.MAX_READS, n - 1):
+        a, b = res[i], ref[i % 8]
+        assert isinstance(a, Exception) == isinstance(b, Exception)
+        if not isinstance(a, Exception):
+            np.testing.assert_array_equal(a.segs, b.segs)
+            assert a.sig_match_score == b.sig_match_score
+    eng = rq.get_engine(0)
+    raws = [np.zeros(64)] * 65536
+    seqs = [np.zeros(8, np.uint8)] * 65536
+    with pytest.raises(_native.EngineError):
+        eng.upload(_native.make_params(params), _native.make_opts(), raws, seqs)

@@ -346,6 +346,8 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
     if (!e || !p || !o || n_reads <= 0 || !raw || !raw_off || !seq || !seq_off)
         return set_err(TBA_E_ARG, "bad batch arguments");
     if (raw_dtype < TBA_RAW_F64 || raw_dtype > TBA_RAW_I16) return set_err(TBA_E_ARG, "unknown raw dtype");
+    // several kernels index the read with the y dimension of the grid
+    if (n_reads > TBA_MAX_BATCH_READS) return set_err(TBA_E_ARG, "more than TBA_MAX_BATCH_READS reads in one batch");
     if (!e->have_model) return set_err(TBA_E_STATE, "tba_set_model has not been called");
     if (p->bandwidth < 2 || p->running_stat_width < 1 || p->min_obs_per_base < 1 ||
         p->raw_min_obs_per_base < 1 || p->mean_obs_per_event < 1 || p->start_n_bases < 1)

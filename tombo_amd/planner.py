@@ -69,11 +69,12 @@ def exact_bytes(n_raw, seq_len, params, opts, kmer_width, raw_dtype=np.float64):
     return out.value
 
 
+MAX_READS = 16384   # reads per batch (the engine's hard limit is TBA_MAX_BATCH_READS = 65535)
 _FIXED = 512 << 20  # arenas' constant slack (moves 64 MB + skip 256 MB + rounding)
 
 
 def plan_batches(n_raw, seq_len, params, opts, kmer_width, mem_budget, raw_dtype=np.float64,
-                 max_reads=16384, sort=True):
+                 max_reads=MAX_READS, sort=True):
     """Cut reads 0..n-1 into batches.
 
     params / opts: `_native.Params` / `_native.Opts` of the job; mem_budget: device bytes one

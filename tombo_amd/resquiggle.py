@@ -81,7 +81,7 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                  len(mr.raw_signal if all_raw_signals is None or all_raw_signals[i] is None
                      else all_raw_signals[i]) for i, mr in enumerate(map_results)]
         seq_len = [len(mr.genome_seq) for mr in map_results]
-        if planner.exact_bytes(n_raw, seq_len, p_, o_, K) > mem_budget:
+        if n > planner.MAX_READS or planner.exact_bytes(n_raw, seq_len, p_, o_, K) > mem_budget:
             # consecutive cuts (sort=False): the Theil-Sen subsamples are drawn from the global
             # RNG in read order, exactly as for one big batch
             parts = planner.plan_batches(n_raw, seq_len, p_, o_, K, mem_budget, sort=False)
