@@ -187,18 +187,22 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
 // kernel time of the lane-per-window form is the serial walk of its LARGEST window (RNA: mean 3.5 k
 // positions per read, but 28 k in the largest window of a 10 k-read batch).  win[3k+2] = -1 marks
 // them; the rest keep their offset inside the read's slice of the global scratch arena.
-// Two LDS classes (interval length, flag words); windows of a class are queued in a global list
-// (skipq: [0] / [1] = entries of the small / big list, [2] / [3] = next entry to hand out) that a
-// fixed grid of wavefronts drains, so no workgroup is launched per read.
-#define SKIP_WAVE_MIN 512
+// Three LDS classes (interval length, flag words); windows of a class are queued in a global list
+// (skipq: [c] = entries of the list of class c, [4 + c] = next entry to hand out) that a fixed
+// grid of wavefronts drains, so no workgroup is launched per read.
+// smallest window (positions) handed to the wave form.  Only used for raw_min_obs_per_base > 1
+// (RNA): the lane form's DNA fast path (recurrence in a register, windows of a few hundred
+// positions, ~55 per read) is faster than queueing (3.4 vs 3.9 ms per 10 k reads)
+#define SKIP_WAVE_MIN 256
 #define SKIP_LEN_S 320
 #define SKIP_BITS_S 128
+#define SKIP_LEN_M 640
+#define SKIP_BITS_M 384
 #define SKIP_LEN_B 1280
 #define SKIP_BITS_B 1024 // u64 words of traceback flags (n * ceil(len / 64))
 
 __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp,
-    const i64 *dp_segs, i64 *segs_out, i64 *win_scratch, i64 *skipq, i32 *list_s, i32 *list_b,
-    i64 list_cap)
+    const i64 *dp_segs, i64 *segs_out, i64 *win_scratch, i64 *skipq, i32 *lists, i64 list_cap)
 {
     (void)n_reads;
     ReadState &r = rs[blockIdx.x];
@@ -272,16 +276,17 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
         if (len <= 0 || n < 2) { r.status = TBA_INTERNAL; return; }
         const i64 fw = n * ((len + 63) / 64);
         int cls = -1;
-        if (n * len >= SKIP_WAVE_MIN) {
+        if (m > 1 && n * len >= SKIP_WAVE_MIN) {
             // (L = len + (n - 1) m must fit the staged signal, n the staged levels)
             const bool fits = (n - 1) * m <= 512 && n <= 256;
             if (fits && len <= SKIP_LEN_S && fw <= SKIP_BITS_S) cls = 0;
-            else if (fits && len <= SKIP_LEN_B && fw <= SKIP_BITS_B) cls = 1;
+            else if (fits && len <= SKIP_LEN_M && fw <= SKIP_BITS_M) cls = 1;
+            else if (fits && len <= SKIP_LEN_B && fw <= SKIP_BITS_B) cls = 2;
         }
         if (cls >= 0) { // queue for k_skip_dp_wave (a full list leaves the window to the lane form)
             const i64 pos = (i64)atomicAdd((unsigned long long *)&skipq[cls], 1ull);
             if (pos < list_cap) {
-                i32 *lst = cls == 0 ? list_s : list_b;
+                i32 *lst = lists + 2 * list_cap * cls;
                 lst[2 * pos] = (i32)blockIdx.x; lst[2 * pos + 1] = (i32)i;
                 w3[3 * i + 2] = -1;
                 continue;
@@ -397,36 +402,41 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
             double csum = zc[0];
             i32 bl_run = 1;
             bf[0] = stay_run; bl[0] = 1; cumn[0] = csum;
-            // branch-free: a lone lane pays dearly for every exec-mask branch, so the two forms of
-            // a step (inside / past the previous base's interval, pyx:142-161) and the end of the
-            // row are selects.  Past the interval best = stay_run, i.e. zv + stay_run: the
-            // reference's running sum with the operands swapped (addition commutes exactly).
-            for (i64 k0 = 1; k0 < len; k0 += 8) {
+            // A lone lane pays for every dependent instruction (~10 cycles each) and dearly for
+            // every exec-mask branch, so a step is kept to: best = max(diag, stay) (the selected
+            // value of "diag > stay ? diag : stay"; the strict compare only feeds the counter,
+            // off the critical chain), stay = z + best.  Past the previous base's interval
+            // (pyx:151-161) the diagonal is -inf: best = stay, i.e. z + stay -- the reference's
+            // running sum with the operands swapped (addition commutes exactly).  Full batches of
+            // eight positions first, the remainder one by one.
+            i64 k0 = 1;
+            for (; k0 + 8 <= len; k0 += 8) {
                 double dv[8], zv[8], cv[8];
                 i32 lv[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const i64 k = k0 + u < len ? k0 + u : len - 1;
+                    const i64 k = k0 + u;
                     dv[u] = S.dg[k <= k_last ? k : k_last]; zv[u] = zc[k];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const i64 k = k0 + u;
-                    const bool in = k < len;
-                    const bool take = k <= k_last && dv[u] > stay_run;
-                    const double best = take ? dv[u] : stay_run;
-                    const i32 nd = take ? 1 : bl_run + 1;
-                    const double ns_ = zv[u] + best, nc_ = csum + zv[u];
-                    stay_run = in ? ns_ : stay_run;
-                    bl_run = in ? nd : bl_run;
-                    csum = in ? nc_ : csum;
+                    const double d = k0 + u <= k_last ? dv[u] : -INFINITY;
+                    const bool take = d > stay_run;
+                    stay_run = zv[u] + max_f64_raw(d, stay_run);
+                    bl_run = take ? 1 : bl_run + 1;
+                    csum = csum + zv[u];
                     dv[u] = stay_run; lv[u] = bl_run; cv[u] = csum;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const i64 k = k0 + u < len ? k0 + u : len - 1; // (tail lanes rewrite the last slot)
-                    bf[k] = dv[u]; bl[k] = lv[u]; cumn[k] = cv[u];
-                }
+                for (int u = 0; u < 8; u++) { bf[k0 + u] = dv[u]; bl[k0 + u] = lv[u]; cumn[k0 + u] = cv[u]; }
+            }
+            for (i64 k = k0; k < len; k++) {
+                const double d = k <= k_last ? S.dg[k] : -INFINITY, zv = zc[k];
+                const bool take = d > stay_run;
+                stay_run = zv + max_f64_raw(d, stay_run);
+                bl_run = take ? 1 : bl_run + 1;
+                csum = csum + zv;
+                bf[k] = stay_run; bl[k] = bl_run; cumn[k] = csum;
             }
         }
         if (__syncthreads_or(bad)) return TBA_INTERNAL;
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(64) void k_skip_dp_wave(ReadState *rs, const DevPar
     total = total < list_cap ? total : list_cap;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_id = (i64)atomicAdd((unsigned long long *)&skipq[2 + CLS], 1ull);
+        if (threadIdx.x == 0) s_id = (i64)atomicAdd((unsigned long long *)&skipq[4 + CLS], 1ull);
         __syncthreads();
         const i64 id = s_id;
         if (id >= total) break;

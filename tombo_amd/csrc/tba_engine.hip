@@ -308,7 +308,7 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     BUF(d_dscr, (size_t)z.skip_arena * 8);
     if (z.wide_w) BUF(d_wide, (size_t)WIDE_BLOCKS * 2 * (size_t)z.wide_w * 8);
     if (z.n_stall > 0) BUF(d_stall, (size_t)z.n_stall * 16);
-    BUF(d_skipq, 64 + 2 * (N * 32 + 4096) * 8);
+    BUF(d_skipq, 64 + 3 * (N * 32 + 4096) * 8);
     BUF(d_res, N * sizeof(tba_read_result));
     BUF(d_segs32, (Bt + N) * 4);
 #undef BUF
@@ -556,15 +556,20 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 11 skip resolve
     if (ON(TBA_STAGE_SKIP)) {
-        // window queues of the wave-per-window kernels: counters + two (read, window) lists
+        // window queues of the wave-per-window kernels: counters + three (read, window) lists
         const i64 qcap = n * 32 + 4096;
         i64 *skipq = e->d_skipq.as<i64>();
-        i32 *list_s = (i32 *)(skipq + 8), *list_b = list_s + 2 * qcap;
+        i32 *lists = (i32 *)(skipq + 8);
         HIP_TRY(hipMemsetAsync(skipq, 0, 64, s));
-        k_skip_plan<<<nb, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, list_s, list_b, qcap);
+        k_skip_plan<<<nb, 64, 0, s>>>(rs, n, dp, e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, lists, qcap);
         k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
-        k_skip_dp_wave<SKIP_LEN_S, SKIP_BITS_S, 0><<<2048, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, list_s, qcap);
-        k_skip_dp_wave<SKIP_LEN_B, SKIP_BITS_B, 1><<<512, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, list_b, qcap);
+#define SKIP_WAVE_ARGS(c_) rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, lists + 2 * qcap * (c_), qcap
+        if (P.raw_min_obs_per_base > 1) { // (k_skip_plan queues nothing otherwise)
+            k_skip_dp_wave<SKIP_LEN_S, SKIP_BITS_S, 0><<<2048, 64, 0, s>>>(SKIP_WAVE_ARGS(0));
+            k_skip_dp_wave<SKIP_LEN_M, SKIP_BITS_M, 1><<<1024, 64, 0, s>>>(SKIP_WAVE_ARGS(1));
+            k_skip_dp_wave<SKIP_LEN_B, SKIP_BITS_B, 2><<<512, 64, 0, s>>>(SKIP_WAVE_ARGS(2));
+        }
+#undef SKIP_WAVE_ARGS
         k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
     }
     MARK(); // 12 theil-sen
