@@ -198,7 +198,7 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
 #define SKIP_BITS_S 128
 #define SKIP_LEN_M 640
 #define SKIP_BITS_M 384
-#define SKIP_LEN_B 1280
+#define SKIP_LEN_B 1792
 #define SKIP_BITS_B 1024 // u64 words of traceback flags (n * ceil(len / 64))
 
 __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp,
