@@ -948,27 +948,36 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, cons
             const i64 rr = r0 - k;
             if (rr < 1 || rc != TBA_OK) continue;
             const i64 bp64 = cur_ev - stv[k];
-            if (bp64 >= Wi || bp64 < -Wi) { rc = TBA_INTERNAL; continue; }
             int bp = (int)bp64, m = 0;
-            bool done = false;
+            // Fast form, branch-free (a wave of 16 lanes on its own SIMD pays ~10 cycles per
+            // dependent instruction and much more per exec-mask branch): the position lies in
+            // the 64-cell window (4 dwords of 16 two-bit moves); per dword, independently, the
+            // highest non-stay move at or below the position (dwords above it are masked out,
+            // dwords below it count in full), then the highest dword that has one.
             const int lc = bp - 16 * wb;                // position inside the window
-            if (bp >= 0 && lc >= 0 && lc < 64) {
-                const u64 lo = ((u64)win[k].y << 32) | win[k].x, hi = ((u64)win[k].w << 32) | win[k].z;
-                int f = -1;
-                if (lc >= 32) { f = mv_find_le(hi, lc - 32); if (f >= 0) f += 32; }
-                if (f < 0) f = mv_find_le(lo, lc >= 32 ? 31 : lc);
-                if (f >= 0) {
-                    const u64 wsel = f >= 32 ? hi : lo;
-                    m = (int)((wsel >> (2 * (f & 31))) & 3);
-                    bp = 16 * wb + f;
-                    done = true;
-                } else if (wb > 0) {
-                    bp = 16 * wb - 1;                   // everything in the window was a stay
-                } else {
-                    bp = -1;                            // ran off the row start: wrap-around below
-                }
+            const bool in_win = bp64 < Wi && bp64 >= 0 && lc >= 0 && lc < 64;
+            const int d = lc >> 4, q = lc & 15;
+            const u32 wv[4] = {win[k].x, win[k].y, win[k].z, win[k].w};
+            int fi[4], mi[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 mk = i < d ? 0xffffffffu : (i == d ? (0xffffffffu >> (30 - 2 * q)) : 0u);
+                const u32 x = wv[i] & mk;
+                const u32 nz = (x | (x >> 1)) & 0x55555555u;
+                fi[i] = nz ? (31 - __clz((int)nz)) >> 1 : -1;
+                mi[i] = (int)((wv[i] >> (2 * (fi[i] & 15))) & 3u);
             }
-            if (!done) { // cell-by-cell walk with direct loads (python wrap-around of a negative index kept)
+            int f = fi[0], mf = mi[0];
+            f = fi[1] >= 0 ? 16 + fi[1] : f;  mf = fi[1] >= 0 ? mi[1] : mf;
+            f = fi[2] >= 0 ? 32 + fi[2] : f;  mf = fi[2] >= 0 ? mi[2] : mf;
+            f = fi[3] >= 0 ? 48 + fi[3] : f;  mf = fi[3] >= 0 ? mi[3] : mf;
+            const bool fast = in_win && f >= 0;
+            if (fast) { bp = 16 * wb + f; m = mf; }
+            if (__builtin_expect(!fast, 0)) {
+                // outside the window, or nothing but stays down to its start: the reference's
+                // cell-by-cell walk with direct loads (python wrap-around of a negative index kept)
+                if (bp64 >= Wi || bp64 < -Wi) { rc = TBA_INTERNAL; continue; }
+                if (in_win) bp = wb > 0 ? 16 * wb - 1 : -1; // everything in the window was a stay
                 const unsigned char *row = mv + rr * rowb;
 #define MVG(b_) ({ int bb_ = (b_) < 0 ? (b_) + Wi : (b_); (int)((row[bb_ >> 2] >> (2 * (bb_ & 3))) & 3); })
                 m = MVG(bp);
