@@ -631,6 +631,24 @@ __device__ bool block_int_medians(XS x, i64 n, int vmin_s, int vmax_s, BucketSme
 }
 
 
+// sum of p[j0 .. j1) in index order (c_new_means adds sample by sample), the LDS loads issued eight
+// at a time: the adds are the only dependent chain (a plain loop waits one LDS round trip per
+// sample, which is what bounded the RNA segment kernels: 15-sample events, 43-sample bases)
+__device__ __forceinline__ double seq_sum_lds(const double *p, i64 j0, i64 j1)
+{
+    double s = 0;
+    i64 j = j0;
+    for (; j + 8 <= j1; j += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = p[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += t[u];
+    }
+    for (; j < j1; j++) s += p[j];
+    return s;
+}
+
 // c_new_means-style segment means, wave-cooperative: a wavefront takes 64 consecutive segments,
 // pulls the samples they span (one contiguous range) into its LDS slice with coalesced loads, and
 // every lane then sums its own segment out of LDS -- sequentially, in sample order, like the
@@ -665,7 +683,7 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
             __builtin_amdgcn_wave_barrier(); // the previous group's lanes are done with the slice
             for (i64 k = lane; k < span; k += 64) lds[k] = x[lo + k];
             __builtin_amdgcn_wave_barrier();
-            for (i64 j = a - lo; j < b - lo; j++) s += lds[j];
+            s = seq_sum_lds(lds, a - lo, b - lo);
         } else {
             for (i64 j = a; j < b; j++) s += x[j];
         }

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const D
         const double len = (double)(b - a);
         double s = 0, v = 0, m;
         if (staged) { // (an LDS and a global pointer must not share one variable: flat apertures)
-            for (i64 j = a - lo; j < b - lo; j++) s += lds[j];
+            s = seq_sum_lds(lds, a - lo, b - lo);
             m = s / len;
             for (i64 j = a - lo; j < b - lo; j++) { const double d = lds[j] - m; v += d * d; }
         } else {
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
                 lds[k] = v;
             }
             __builtin_amdgcn_wave_barrier();
-            for (i64 j = a - lo; j < b - lo; j++) s += lds[j];
+            s = seq_sum_lds(lds, a - lo, b - lo);
         } else {
             for (i64 j = a; j < b; j++) {
                 const double v = skip ? x[j] : (x[j] - ca) / cb;
