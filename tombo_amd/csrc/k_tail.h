@@ -593,23 +593,6 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
     }
 }
 
-// c_new_means over base boundaries: means of sig[read_start + segs[i] : read_start + segs[i+1]]
-// grid: (blocks, reads)
-__global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const double *sig,
-    const i64 *segs, double *base_means)
-{
-    const ReadState &r = rs[blockIdx.y];
-    if (r.status != TBA_OK) return;
-    const double *x = sig + r.raw_off + r.read_start;
-    const i64 *sg = segs + r.seg_off;
-    double *bm = base_means + r.ref_off;
-    constexpr int CAP = 768; // 64 bases of ~9 samples
-    __shared__ double s_seg[4 * CAP];
-    const int wave = threadIdx.x >> 6;
-    wave_segment_sums<CAP>(x, sg, r.B, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
-                      [&](i64 i, double s, i64 len) { bm[i] = s / (double)len; });
-}
-
 // ts.calc_kmer_fitted_shift_scale(method='theil_sen') (tombo_stats.py:401-450) with
 // c_compute_slopes (_c_helper.pyx:362-377): median of all pairwise slopes, then median
 // intercept.  One workgroup per read; the (<= 1000) points sit in LDS, the n(n-1)/2 slopes are
@@ -618,8 +601,12 @@ __global__ __launch_bounds__(256) void k_base_means(const ReadState *rs, const d
 #define TSW_SAMPLE_DIST 128 // distances in the window sample
 #define TSW_MIN_POINTS 256  // below this the generic two-pass select is cheap anyway
 #define TSW_REL 1e-5        // guard band of the approximate classification (see below)
+// The per-base means the fit needs (ts.compute_base_means = c_new_means, _c_helper.pyx:59-71,
+// over the resolved boundaries) are computed here, for the <= 1000 sampled bases only: a thread
+// sums its base's samples in order and divides once -- a read of 10 000 bases touches a tenth of
+// its signal instead of all of it (the separate k_base_means pass of round 1: 2.7 ms, RNA 9 ms).
 __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevParams *dp,
-    const double *base_means, const double *ref_means, const i64 *samp_ind, double *scratch)
+    const double *norm, const i64 *segs, const double *ref_means, const i64 *samp_ind, double *scratch)
 {
     __shared__ BucketSmem sm;
     __shared__ u32 s_ncand;
@@ -630,7 +617,15 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     if (r.status != TBA_OK) return;
     if (dp->o.skip_seq_scaling) return;
     const int tid = threadIdx.x;
-    const double *bm = base_means + r.ref_off, *mu = ref_means + r.ref_off;
+    const double *mu = ref_means + r.ref_off;
+    const double *x = norm + r.raw_off + r.read_start;
+    const i64 *sg = segs + r.seg_off;
+    auto base_mean = [&](i64 k) { // c_new_means: sequential sum, one divide
+        const i64 a = sg[k], b = sg[k + 1];
+        double acc = 0;
+        for (i64 j = a; j < b; j++) acc += x[j];
+        return acc / (double)(b - a);
+    };
     i64 n = r.B;
     if (n > MAX_TS_POINTS) {
         if (samp_ind == nullptr) { if (tid == 0) r.status = TBA_INTERNAL; return; }
@@ -640,11 +635,11 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
         for (i64 i = tid; i < n; i += SEL_NT) {
             i64 k = si[i];
             if (k < 0 || k >= r.B) { bad = true; k = 0; }
-            s_ev[i] = bm[k]; s_md[i] = mu[k];
+            s_ev[i] = base_mean(k); s_md[i] = mu[k];
         }
         if (__syncthreads_or(bad)) { if (tid == 0) r.status = TBA_INTERNAL; return; }
     } else {
-        for (i64 i = tid; i < n; i += SEL_NT) { s_ev[i] = bm[i]; s_md[i] = mu[i]; }
+        for (i64 i = tid; i < n; i += SEL_NT) { s_ev[i] = base_mean(i); s_md[i] = mu[i]; }
         __syncthreads();
     }
     const i64 ns = n * (n - 1) / 2;

@@ -86,13 +86,13 @@ struct tba_engine {
     DevBuf d_skipq;               // window queues of k_skip_dp_wave
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
-        d_win, d_bm, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
+        d_win, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
         d_moves, d_dscr, d_wide, d_stat;
     void release_all()
     {
         DevBuf *all[] = {&d_rs, &d_dp, &d_kmeans, &d_ksds, &d_raw, &d_norm, &d_norm_out, &d_csum,
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
-                         &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_bm, &d_absz,
+                         &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
                          &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq};
         for (DevBuf *b : all) b->release();
@@ -297,7 +297,6 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     BUF(d_dpsegs, (Bt + N) * 8);
     BUF(d_segs, (Bt + N) * 8);
     BUF(d_win, (Bt + N) * 24);
-    BUF(d_bm, Bt * 8);
     BUF(d_absz, Bt * 8);
     BUF(d_sv_in, N * 32);
     BUF(d_samp, N * MAX_TS_POINTS * 8);
@@ -582,8 +581,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 12 theil-sen
     if (ON(TBA_STAGE_RESCALE)) {
-        k_base_means<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_bm.as<double>());
-        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_bm.as<double>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr, e->d_csum.as<double>());
+        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr, e->d_csum.as<double>());
     }
     MARK(); // 13 rescale + score
     if (ON(TBA_STAGE_RESCALE)) {
