@@ -775,8 +775,10 @@ __global__ __launch_bounds__(SEL_NT) void k_remove_stalls(ReadState *rs, i64 n_r
 // c_new_means (_c_helper.pyx:59-71) over the event boundaries: sequential sum, one divide.
 // grid: (blocks, reads)
 template <class RT>
-__global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const RT *sig,
-    const i64 *valid_cpts, double *event_means, int from_raw_limit)
+// scale_events != 0: only the events ts.get_scale_values_from_events looks at are needed (the
+// first min(rna_scale_num_events, int(frac * n_cpts)) - 1, tombo_stats.py:220-224).
+__global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const DevParams *dp,
+    const RT *sig, const i64 *valid_cpts, double *event_means, int scale_events)
 {
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
@@ -784,7 +786,14 @@ __global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const 
     const i64 *c = valid_cpts + r.ev_off;
     double *em = event_means + r.ev_off;
     i64 n = r.n_cpts - 1;
-    (void)from_raw_limit;
+    if (scale_events) {
+        const tba_opts &o = dp->o;
+        i64 ne = o.rna_scale_num_events;
+        if ((double)r.n_cpts * o.rna_scale_max_frac_events < (double)ne)
+            ne = (i64)((double)r.n_cpts * o.rna_scale_max_frac_events);
+        if (ne > r.n_cpts) ne = r.n_cpts;
+        n = ne - 1 < n ? (ne - 1 > 0 ? ne - 1 : 0) : n;
+    }
     constexpr int CAP = 448; // 64 events of ~5 samples
     __shared__ double s_seg[4 * CAP];
     const int wave = threadIdx.x >> 6;
