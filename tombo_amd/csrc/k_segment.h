@@ -27,6 +27,7 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
     const int tid = threadIdx.x;
+    TBA_PHASE_T0(2);
     const i64 n = r.n_raw;
     const RawSamples<RT> x{raw + r.raw_off};
     double *y = norm + r.raw_off;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
         double span = smx - smn;
         span = span > 0 ? span : 1.0;
         mn = smn - span; mx = smx + span;
+        TBA_PHASE(2, 0);
         bool have_med = false;
         if constexpr (raw_is_int<RT>::value) {
             // both medians from one counting pass (the deviations of the scale are ranked from the
@@ -78,73 +80,92 @@ __global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevPa
                 if (!o.has_const_scale) { scale = (n & 1) ? dlo : (dlo + dhi) / 2.0; have_dev = true; }
             }
             __syncthreads();
-        } else if (n >= NORM_WINDOW_MIN) {
-            // (the window list lives in the read's norm slice, written only by the final pass)
-            if (block_median_window([&](i64 i) { return x[i]; }, n, samp, y, n, &sm, &xlo, &xhi)) {
-                shift = (n & 1) ? xlo : (xlo + xhi) / 2.0;
-                have_med = true;
-            }
-            __syncthreads();
         }
-        if (!have_med)
-            shift = block_median_fast([&](i64 i) { return x[i]; }, n, mn, mx, &sm, &xlo, &xhi);
-        if (o.has_const_scale) scale = o.const_scale;
-        else if (!have_dev) {
+        // Up to three medians over the signal, one call site (a loop the compiler must not unroll:
+        // three inlined copies of the selects cost 40 VGPRs and a workgroup per CU):
+        //   what 0: np.median(x) -> shift;   what 1: np.median(|x - shift|) -> scale (mad);
+        //   what 2: np.median(|norm - np.median(norm)|) -> the outlier limits of the normalised
+        //           signal (c_apply_outlier_thresh's caller, tombo_stats.py:560-570).
+        // Each first tries the one-pass sampled window (the window list lives in the read's norm
+        // slice, which is only written by the final pass), then the generic two-pass select.
+        // RNA with scale_values=None and no event scaling normalises without an outlier threshold.
+        const bool thresh = o.has_outlier_thresh && !(mode == 1 && !o.has_const_scale);
+        double med = 0, mad = 0;
+#pragma nounroll
+        for (int what = 0; what < 3; what++) {
+            if (what == 0 && have_med) continue;
+            if (what == 1) {
+                if (o.has_const_scale) { scale = o.const_scale; continue; }
+                if (have_dev) continue;
+            }
+            if (what == 2) {
+                if (!thresh) break;
+                // np.median(norm): x -> (x - shift) / scale is monotone, so the middle order
+                // statistics of the normalised signal are the images of the raw ones found above
+                // (same two values the reference averages; for a negative const scale they swap
+                // places, the sum does not care)
+                const double ylo = (xlo - shift) / scale, yhi = (xhi - shift) / scale;
+                med = (n & 1) ? ylo : (ylo + yhi) / 2.0;
+                if (have_dev && med == 0.0 && scale > 0) {
+                    // |norm - 0| = RN(|x - shift| / scale) is a monotone image of the deviations
+                    // the scale was just selected from, so its middle order statistics are the
+                    // images of theirs: no pass over the signal (med is exactly 0 for every odd
+                    // length and for the even ones whose two middle samples sit symmetrically
+                    // around the shift; float input of even length rarely does: med is a few
+                    // 1e-16 there and the deviations have to be ranked again)
+                    const double m_lo = dlo / scale, m_hi = dhi / scale;
+                    mad = (n & 1) ? m_lo : (m_lo + m_hi) / 2.0;
+                    break;
+                }
+            }
+            auto of = [&](double xv) {
+                return what == 0 ? xv : (what == 1 ? fabs(xv - shift) : fabs((xv - shift) / scale - med));
+            };
+            auto val = [&](i64 i) { return of(x[i]); };
+            double a_lo = 0, a_hi = 0, res = 0;
             bool done = false;
             if (!raw_is_int<RT>::value && n >= NORM_WINDOW_MIN) {
                 double ds[WS_PER];
 #pragma unroll
-                for (int q = 0; q < WS_PER; q++) ds[q] = fabs(samp[q] - shift);
-                done = block_median_window([&](i64 i) { return fabs(x[i] - shift); }, n, ds, y, n, &sm, &dlo, &dhi);
-                if (done) scale = (n & 1) ? dlo : (dlo + dhi) / 2.0;
+                for (int q = 0; q < WS_PER; q++) ds[q] = of(samp[q]);
+                done = block_median_window(val, n, ds, y, n, &sm, &a_lo, &a_hi);
+                if (done) res = (n & 1) ? a_lo : (a_lo + a_hi) / 2.0;
                 __syncthreads();
             }
-            if (!done) {
-                const double a = mx - shift, b2 = shift - mn;
-                scale = block_median_fast([&](i64 i) { return fabs(x[i] - shift); }, n, 0.0,
-                                          a > b2 ? a : b2, &sm, &dlo, &dhi);
+            if (!done) { // bucket range: anything works, a good guess saves refinement levels
+                double rhi = mx;
+                if (what == 1) { const double a = mx - shift, b2 = shift - mn; rhi = a > b2 ? a : b2; }
+                if (what == 2) { const double e0 = of(mn), e1 = of(mx); rhi = e0 > e1 ? e0 : e1; }
+                res = block_median_fast(val, n, what == 0 ? mn : 0.0, rhi, &sm, &a_lo, &a_hi);
             }
-            have_dev = true;
+            if (what == 0) { shift = res; xlo = a_lo; xhi = a_hi; have_med = true; }
+            else if (what == 1) { scale = res; dlo = a_lo; dhi = a_hi; have_dev = true; }
+            else mad = res;
+            TBA_PHASE(2, 1 + what);
+        }
+        if (thresh) {
+            lo = med - (mad * o.outlier_thresh);
+            hi = med + (mad * o.outlier_thresh);
+            have_lims = true;
         }
     }
     // The normalised signal is written once, at the end: the passes in between recompute
     // (x - shift) / scale on the fly (same operation, same bits).
-    // RNA with scale_values=None and no event scaling normalises without an outlier threshold
-    bool thresh = !use_sv && o.has_outlier_thresh && !(mode == 1 && !o.has_const_scale);
-    if (thresh) {
-        // np.median(norm): x -> (x - shift) / scale is monotone, so the middle order statistics of
-        // the normalised signal are the images of the raw ones found above (same two values the
-        // reference averages; for a negative const scale they swap places, the sum does not care)
-        const double ylo = (xlo - shift) / scale, yhi = (xhi - shift) / scale;
-        const double med = (n & 1) ? ylo : (ylo + yhi) / 2.0;
-        double mad;
-        if (have_dev && med == 0.0 && scale > 0) {
-            // |norm - 0| = RN(|x - shift| / scale) is a monotone image of the deviations the
-            // scale was just selected from, so its middle order statistics are the images of
-            // theirs: no pass over the signal (med is exactly 0 for every odd length and for the
-            // even ones whose two middle samples sit symmetrically around the shift)
-            const double m_lo = dlo / scale, m_hi = dhi / scale;
-            mad = (n & 1) ? m_lo : (m_lo + m_hi) / 2.0;
-        } else {
-            const double e0 = fabs((mn - shift) / scale - med), e1 = fabs((mx - shift) / scale - med);
-            mad = block_median_fast(
-                [&](i64 i) { return fabs((x[i] - shift) / scale - med); }, n, 0.0, e0 > e1 ? e0 : e1, &sm);
-        }
-        lo = med - (mad * o.outlier_thresh);
-        hi = med + (mad * o.outlier_thresh);
-        have_lims = true;
-    }
+    TBA_PHASE(2, 3);
     if (write_norm) {
         if (have_lims) {
             // c_apply_outlier_thresh, _c_helper.pyx:73-87
-            for (i64 i = tid; i < n; i += SEL_NT) {
-                const double v = (x[i] - shift) / scale;
+            block_stream<4>(n, [&](i64 i) { return x[i]; }, [&](i64 i, double xv) {
+                const double v = (xv - shift) / scale;
                 y[i] = v > hi ? hi : (v < lo ? lo : v);
-            }
+            });
         } else {
-            for (i64 i = tid; i < n; i += SEL_NT) y[i] = (x[i] - shift) / scale;
+            block_stream<4>(n, [&](i64 i) { return x[i]; },
+                            [&](i64 i, double xv) { y[i] = (xv - shift) / scale; });
         }
     }
+    TBA_PHASE(2, 4);
+    TBA_PHASE_END(2);
     if (tid == 0) {
         r.shift = shift; r.scale = scale; r.lower = lo; r.upper = hi;
         r.has_lims = have_lims ? 1 : 0;
@@ -384,13 +405,27 @@ __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const
             s[pos] = ttest_score<0>(x + pos, (int)w);
         return;
     }
-    const int span = 256 + 2 * (int)w;
-    for (i64 p0 = (i64)blockIdx.x * 256; p0 < ns; p0 += (i64)gridDim.x * 256) {
+    // the samples of the NEXT step are fetched into registers before this step's windows are
+    // evaluated (the load latency hides behind the ~150 float64 operations of a score)
+    const int span = 256 + 2 * (int)w, tid = threadIdx.x;
+    const bool second = tid + 256 < span; // the 2w samples past the 256: first threads, 2nd load
+    const i64 step = (i64)gridDim.x * 256;
+    double v0 = 0.0, v1 = 0.0;
+    auto fetch = [&](i64 p0) {
+        const i64 q0 = p0 + tid, q1 = p0 + tid + 256;
+        v0 = q0 < r.n_raw ? x[q0] : 0.0;
+        v1 = second && q1 < r.n_raw ? x[q1] : 0.0;
+    };
+    i64 p0 = (i64)blockIdx.x * 256;
+    if (p0 < ns) fetch(p0);
+    for (; p0 < ns; p0 += step) {
         __syncthreads();
-        for (int k = threadIdx.x; k < span; k += 256) { const i64 q = p0 + k; tile[k] = q < r.n_raw ? x[q] : 0.0; }
+        tile[tid] = v0;
+        if (second) tile[tid + 256] = v1;
         __syncthreads();
-        const i64 pos = p0 + threadIdx.x;
-        if (pos < ns) s[pos] = w == 12 ? ttest_score<12>(tile + threadIdx.x, 12) : ttest_score<0>(tile + threadIdx.x, (int)w);
+        if (p0 + step < ns) fetch(p0 + step);
+        const i64 pos = p0 + tid;
+        if (pos < ns) s[pos] = w == 12 ? ttest_score<12>(tile + tid, 12) : ttest_score<0>(tile + tid, (int)w);
     }
 }
 
@@ -522,28 +557,47 @@ __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *de
             U = w_andn(w_andn(U, nT), nS);
             if (__ballot((nS.lo | nS.hi | nT.lo | nT.hi) != 0) == 0) break;
         }
-        // core lanes 1..62 -> one state byte per position
-        for (int g = 1; g < 63; g++) {
+        // core lanes 1..62 -> one state byte per position, taken scores -> dense list.  The
+        // slot of every taken position is known up front (prefix of the per-word counts: one
+        // counter bump per tile), and the scores of four groups are fetched before they are used.
+        const int cl = (lane >= 1 && lane < 63) ? __popc(T.lo) + __popc(T.hi) : 0;
+        int inc = cl;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        const int excl = inc - cl;
+        const int total = __builtin_amdgcn_readlane(inc, 63);
+        u32 dbase = 0;
+        if (total) { // (taken bits only ever sit on valid positions)
+            if (lane == 0) dbase = atomicAdd(n_dense, (u32)total);
+            dbase = (u32)__builtin_amdgcn_readfirstlane((int)dbase);
+        }
+        auto out_group = [&](int g, double v) {
             const u32 tl = __builtin_amdgcn_readlane((int)T.lo, g), th = __builtin_amdgcn_readlane((int)T.hi, g);
             const u32 sl = __builtin_amdgcn_readlane((int)S.lo, g), sh = __builtin_amdgcn_readlane((int)S.hi, g);
             const i64 p = g0 + 64 * g + lane;
             const u32 tb = lane < 32 ? (tl >> lane) & 1u : (th >> (lane - 32)) & 1u;
             const u32 sb = lane < 32 ? (sl >> lane) & 1u : (sh >> (lane - 32)) & 1u;
             if (p < ns) st[p] = (unsigned char)(tb | (sb << 1));
-            const u32 cnt = __popc(tl) + __popc(th); // taken bits only ever sit on valid positions
-            if (cnt) {
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(n_dense, cnt);
-                base = __shfl(base, 0, 64);
-                if (tb) {
-                    const u32 below = lane < 32 ? __popc(tl & ((1u << lane) - 1u))
-                                                : __popc(tl) + __popc(th & ((1u << (lane - 32)) - 1u));
-                    const double v = s[p];
-                    dense[base + below] = v;
-                    mn = v < mn ? v : mn; mx = v > mx ? v : mx;
-                }
+            if (tb) {
+                const u32 below = lane < 32 ? __popc(tl & ((1u << lane) - 1u))
+                                            : __popc(tl) + __popc(th & ((1u << (lane - 32)) - 1u));
+                dense[dbase + (u32)__builtin_amdgcn_readlane(excl, g) + below] = v;
+                mn = v < mn ? v : mn; mx = v > mx ? v : mx;
             }
+        };
+        auto score_at = [&](int g) { const i64 p = g0 + 64 * g + lane; return s[p < ns ? p : ns - 1]; };
+        int g = 1;
+        for (; g + 3 < 63; g += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = score_at(g + u);
+#pragma unroll
+            for (int u = 0; u < 4; u++) out_group(g + u, v[u]);
         }
+        for (; g < 63; g++) out_group(g, score_at(g));
         if (lane >= 1 && lane < 63) left += __popc(U.lo) + __popc(U.hi);
     }
     return left;
@@ -575,7 +629,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     // A position is only decided from neighbours that are themselves decided, so every decision
     // made here is final; positions whose dependency chain leaves the tile stay undecided (0)
     // and are finished by the global rounds below (rare: chains are a few positions long).
-    TBA_PHASE_T0();
+    TBA_PHASE_T0(1);
     {
         i64 left_undecided = 0;
         if (tid == 0) s_ndense = 0;
@@ -589,7 +643,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
         }
         left_undecided = block_sum_i64(left_undecided, &sm.rad);
         had_leftovers = left_undecided > 0;
-        TBA_PHASE(0);
+        TBA_PHASE(1, 0);
         // Phase 2: global rounds for whatever the tiles could not settle
         for (i64 round = 0; left_undecided > 0 && round <= ns; round++) {
             i64 undecided = 0;
@@ -613,7 +667,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
             left_undecided = block_sum_i64(undecided, &sm.rad);
         }
     }
-    TBA_PHASE(1);
+    TBA_PHASE(1, 1);
     // taken scores -> dense array (+ their range): done by the tiles, unless some positions had
     // to be settled by the global rounds (then one ordered compaction pass redoes it)
     i64 n_taken;
@@ -624,7 +678,7 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     } else {
         mn = INFINITY; mx = -INFINITY;
         n_taken = block_compact(
-            ns, [&](i64 p) { return st[p] == 1; },
+            ns, [&](i64 p) { return st[p]; }, [&](i64, unsigned char t) { return t == 1; },
             [&](i64 p, i64 o) { double v = s[p]; dn[o] = v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; },
             s_w);
     }
@@ -641,12 +695,12 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
         mx = sm.redd[2 * q + 1] > mx ? sm.redd[2 * q + 1] : mx;
     }
     __syncthreads();
-    TBA_PHASE(2);
+    TBA_PHASE(1, 2);
     // score of the num_cpts-th best taken position (ascending rank n_taken - num_cpts)
     const double tval = block_kth([&](i64 i) { return dn[i]; }, n_taken, n_taken - num_cpts, mn,
                                   mx, &sm);
     __syncthreads();
-    TBA_PHASE(3);
+    TBA_PHASE(1, 3);
     // one pass: ordered compaction of the picks (the .sort() of tombo_helper.py:76-82), taking
     // every taken position at or above the threshold score, and on the way the counts that tell
     // whether that was right: taken above / at the threshold, all positions above / at it.
@@ -659,11 +713,12 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
     for (int b = tid; b < 4096; b += SEL_NT) sm.hist[b] = 0;
     __syncthreads();
     i64 c_gt = 0, c_eq = 0, a_gt = 0, a_eq = 0;
+    struct ScoreState { double v; unsigned char t; };
     block_compact(
-        ns,
-        [&](i64 p) {
-            const double v = s[p];
-            const bool tk = st[p] == 1;
+        ns, [&](i64 p) { return ScoreState{s[p], st[p]}; },
+        [&](i64 p, ScoreState e) {
+            const double v = e.v;
+            const bool tk = e.t == 1;
             a_gt += v > tval; a_eq += v == tval;
             c_gt += tk && v > tval; c_eq += tk && v == tval;
             if (v == tval) {
@@ -723,15 +778,16 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
         before = a_gt + s_extra;
         if (need_eq < c_eq)
             block_compact(
-                ns,
-                [&](i64 p) { if (st[p] != 1) return false; const double v = s[p]; return v > tval || (v == tval && p >= idx_thr); },
+                ns, [&](i64 p) { return ScoreState{s[p], st[p]}; },
+                [&](i64 p, ScoreState e) { return e.t == 1 && (e.v > tval || (e.v == tval && p >= idx_thr)); },
                 [&](i64 p, i64 o) { if (o < num_cpts) cpts[o] = p + w; }, s_w);
     }
     // the reference raises when rank + 1 >= num_cands (cand_idx is advanced past the pick before
     // the bound check, _c_helper.pyx:116-118)
     if (num_cpts > 1 && before + 1 >= num_cands) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
-    TBA_PHASE(4);
-    TBA_PHASE(5);
+    TBA_PHASE(1, 4);
+    TBA_PHASE(1, 5);
+    TBA_PHASE_END(1);
     if (tid == 0) { r.n_cpts = num_cpts; r.n_ev = num_cpts - 1; }
 }
 
@@ -754,9 +810,8 @@ __global__ __launch_bounds__(SEL_NT) void k_remove_stalls(ReadState *rs, i64 n_r
     i64 *tmp = (i64 *)(scratch + r.raw_off + blockIdx.x);
     const i64 ns = r.n_stall, n = r.n_cpts;
     const i64 out = block_compact(
-        n,
-        [&](i64 i) {
-            const i64 v = c[i];
+        n, [&](i64 i) { return c[i]; },
+        [&](i64, i64 v) {
             i64 lo = 0, hi = ns - 1; // first interval with end >= v, else the last one
             while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (st[2 * mid + 1] >= v) hi = mid; else lo = mid + 1; }
             return !(st[2 * lo] < v && v < st[2 * lo + 1]);

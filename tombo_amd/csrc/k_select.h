@@ -4,6 +4,54 @@
 #pragma once
 #include "tba_common.h"
 
+// Memory-level parallelism.  A `load -> use -> store` loop has ONE request per thread in flight:
+// at 32 waves per CU that is 16 KB per CU, i.e. 2.5-3 TB/s at the latency of a busy memory
+// system however simple the loop body (what bounded k_normalize, k_rescale_absz and
+// k_event_means in round 1).  The streaming loops below therefore issue U independent loads
+// first and only then consume them.
+//
+// block_stream: workgroup-strided pass over [0, n); body(i, load(i)) for every i (no collectives
+// inside body: the tail runs with part of the threads).
+template <int U, class Load, class Body>
+__device__ __forceinline__ void block_stream(i64 n, Load load, Body body)
+{
+    const i64 tid = threadIdx.x, nt = blockDim.x;
+    i64 base = 0;
+    for (; base + (i64)U * nt <= n; base += (i64)U * nt) {
+        decltype(load((i64)0)) v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = load(base + (i64)u * nt + tid);
+#pragma unroll
+        for (int u = 0; u < U; u++) body(base + (i64)u * nt + tid, v[u]);
+    }
+    for (i64 i = base + tid; i < n; i += nt) body(i, load(i));
+}
+
+// wave_stage: a wavefront copies x[lo .. lo + span), span <= 64 * NLD, into its LDS slice as
+// f(index, value); all loads of a lane go out before the first value is used (uniform branches:
+// span is made an SGPR).
+template <int NLD, class Sig, class F>
+__device__ __forceinline__ void wave_stage(Sig x, i64 lo, i64 span, double *lds, F f)
+{
+    const int lane = threadIdx.x & 63;
+    const int spn = __builtin_amdgcn_readfirstlane((int)span);
+    double v[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+        if (64 * u < spn) {
+            const int k = lane + 64 * u;
+            v[u] = x[lo + (k < spn ? k : spn - 1)];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+        if (64 * u < spn) {
+            const int k = lane + 64 * u;
+            if (k < spn) lds[k] = f(lo + k, v[u]);
+        }
+    }
+}
+
 #define SEL_NT 512 // threads per workgroup for every kernel that uses these helpers
 
 struct SelectSmem {
@@ -203,10 +251,19 @@ struct FlatElems {
     F val; i64 n;
     template <class V> __device__ void operator()(V visit) const
     {
-        for (i64 base = 0; base < n; base += SEL_NT) {
-            const i64 i = base + threadIdx.x;
-            const bool ok = i < n;
-            visit(ok ? val(i) : 0.0, ok);
+        constexpr int U = 4; // element loads in flight per thread (see block_stream)
+        for (i64 base = 0; base < n; base += (i64)U * SEL_NT) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const i64 i = base + (i64)u * SEL_NT + threadIdx.x;
+                v[u] = val(i < n ? i : n - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool ok = base + (i64)u * SEL_NT + threadIdx.x < n;
+                visit(ok ? v[u] : 0.0, ok);
+            }
         }
     }
 };
@@ -422,8 +479,8 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
                   // read; 16 per thread touch every line -- most of a pass -- for a window half
                   // as wide: 8.5 vs 6.5 ms on the 10k x 10 kb batch)
 #endif
-template <class F>
-__device__ bool block_median_window(F val, i64 n, const double (&samp)[WS_PER], double *list,
+template <int WU = 4, class F> // WU: element loads in flight per thread during the pass
+__device__ __forceinline__ bool block_median_window(F val, i64 n, const double (&samp)[WS_PER], double *list,
                                     i64 cap, BucketSmem *sm, double *lo_mid, double *hi_mid)
 {
     const int tid = threadIdx.x;
@@ -482,19 +539,33 @@ __device__ bool block_median_window(F val, i64 n, const double (&samp)[WS_PER], 
     // the pass: count below the window, list the window (wave-aggregated append)
     i64 c_lo = 0;
     const int lane = tid & 63;
-    for (i64 base = 0; base < n; base += SEL_NT) {
-        const i64 i = base + tid;
-        const bool ok = i < n;
-        const double v = ok ? val(i) : 0.0;
-        c_lo += ok && v < t1;
-        const bool in = ok && v >= t1 && v < t2;
-        const u64 m = __ballot(in);
-        if (m) {
+    // (WU loads in flight per thread, one list-counter bump per WU * 64 elements)
+    for (i64 base = 0; base < n; base += (i64)WU * SEL_NT) {
+        double v[WU];
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const i64 i = base + (i64)u * SEL_NT + tid;
+            v[u] = val(i < n ? i : n - 1);
+        }
+        u64 m[WU];
+        u32 tot = 0;
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const bool ok = base + (i64)u * SEL_NT + tid < n;
+            c_lo += ok && v[u] < t1;
+            m[u] = __ballot(ok && v[u] >= t1 && v[u] < t2);
+            tot += (u32)__popcll(m[u]);
+        }
+        if (tot) {
             u32 b0 = 0;
-            if (lane == 0) b0 = atomicAdd(&s_nl, (u32)__popcll(m));
+            if (lane == 0) b0 = atomicAdd(&s_nl, tot);
             b0 = __shfl(b0, 0, 64);
-            const u32 pos = b0 + (u32)__popcll(m & ((1ull << lane) - 1ull));
-            if (in && pos < cap) list[pos] = v;
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                const u32 pos = b0 + (u32)__popcll(m[u] & ((1ull << lane) - 1ull));
+                if (((m[u] >> lane) & 1ull) && pos < cap) list[pos] = v[u];
+                b0 += (u32)__popcll(m[u]);
+            }
         }
     }
     c_lo = block_sum_i64(c_lo, &sm->rad);
@@ -539,12 +610,12 @@ __device__ bool block_int_medians(XS x, i64 n, int vmin_s, int vmax_s, BucketSme
     if (tid == 0) s_okk = 0;
     __syncthreads();
     i64 below = 0, above = 0;
-    for (i64 i = tid; i < n; i += SEL_NT) {
-        const int b = (int)x[i] - base;
+    block_stream<8>(n, [&](i64 i) { return (int)x[i]; }, [&](i64, int xv) {
+        const int b = xv - base;
         if (b < 0) below++;
         else if (b >= BS_NB) above++;
         else atomicAdd(&sm->hist[b], 1u);
-    }
+    });
     below = block_sum_i64(below, &sm->rad);
     above = block_sum_i64(above, &sm->rad);
     __syncthreads();
@@ -681,7 +752,7 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
         double s = 0;
         if (span <= SEGW_CAP) {
             __builtin_amdgcn_wave_barrier(); // the previous group's lanes are done with the slice
-            for (i64 k = lane; k < span; k += 64) lds[k] = x[lo + k];
+            wave_stage<(SEGW_CAP + 63) / 64>(x, lo, span, lds, [](i64, double v) { return v; });
             __builtin_amdgcn_wave_barrier();
             s = seq_sum_lds(lds, a - lo, b - lo);
         } else {
@@ -693,37 +764,43 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
 
 // ordered stream compaction over [0, n): emit(i, out_index) for every i with pred(i), output
 // indices ascending in i.  All threads call; returns the number emitted.  s_w: >= SEL_NT/64 i64.
-// Every thread takes CB consecutive items per step (their predicate loads are issued together),
-// so a step covers CB * SEL_NT items and costs two workgroup barriers.
+// A step covers CB * SEL_NT items and costs two workgroup barriers; a wavefront takes CB * 64
+// consecutive items as CB rows of 64 (lane = column: coalesced loads), so the rank of an item
+// inside the wave comes from the row ballots alone (popcounts, no shuffle scan).
+// The predicate is split into load(i) -- the memory reads of item i, all CB of them issued
+// before the first is looked at -- and pred(i, loaded), which may have side effects (counters,
+// LDS histograms: those pin the loads of a one-piece predicate in program order, one memory
+// round trip per item).
 #define CB 8
-template <class Pred, class Emit>
-__device__ i64 block_compact(i64 n, Pred pred, Emit emit, i64 *s_w)
+template <class Load, class Pred, class Emit>
+__device__ i64 block_compact(i64 n, Load load, Pred pred, Emit emit, i64 *s_w)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 below = (1ull << lane) - 1ull;
     i64 run = 0;
     for (i64 base = 0; base < n; base += (i64)CB * SEL_NT) {
-        const i64 i0 = base + (i64)CB * tid;
-        u32 flags = 0;
+        const i64 i0 = base + (i64)w * (CB * 64) + lane;
+        decltype(load((i64)0)) ld[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) ld[k] = load(i0 + 64 * k < n ? i0 + 64 * k : n - 1);
+        u64 m[CB];
+        int cw = 0;
 #pragma unroll
         for (int k = 0; k < CB; k++) {
-            const i64 i = i0 + k;
-            flags |= (i < n && pred(i)) ? (1u << k) : 0u;
+            const i64 i = i0 + 64 * k;
+            m[k] = __ballot(i < n && pred(i, ld[k]));
+            cw += __popcll(m[k]);
         }
-        const int c = __popc(flags);
-        int inc = c; // inclusive scan of the per-thread counts inside the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        if (lane == 63) s_w[w] = inc;
+        if (lane == 0) s_w[w] = cw;
         __syncthreads();
         i64 off = 0, tot = 0;
         for (int q = 0; q < SEL_NT / 64; q++) { i64 cc = s_w[q]; off += q < w ? cc : 0; tot += cc; }
-        i64 o = run + off + (inc - c);
+        i64 o = run + off;
 #pragma unroll
-        for (int k = 0; k < CB; k++)
-            if (flags & (1u << k)) emit(i0 + k, o++);
+        for (int k = 0; k < CB; k++) {
+            if ((m[k] >> lane) & 1ull) emit(i0 + 64 * k, o + __popcll(m[k] & below));
+            o += __popcll(m[k]);
+        }
         run += tot;
         __syncthreads();
     }

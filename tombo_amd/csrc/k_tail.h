@@ -606,7 +606,8 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
 // sums its base's samples in order and divides once -- a read of 10 000 bases touches a tenth of
 // its signal instead of all of it (the separate k_base_means pass of round 1: 2.7 ms, RNA 9 ms).
 __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevParams *dp,
-    const double *norm, const i64 *segs, const double *ref_means, const i64 *samp_ind, double *scratch)
+    const double *norm, const i64 *segs, const double *ref_means, const i64 *samp_ind, double *scratch,
+    double *scratch2)
 {
     __shared__ BucketSmem sm;
     __shared__ u32 s_ncand;
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     if (r.status != TBA_OK) return;
     if (dp->o.skip_seq_scaling) return;
     const int tid = threadIdx.x;
+    TBA_PHASE_T0(3);
     const double *mu = ref_means + r.ref_off;
     const double *x = norm + r.raw_off + r.read_start;
     const i64 *sg = segs + r.seg_off;
@@ -644,6 +646,7 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     }
     const i64 ns = n * (n - 1) / 2;
     if (ns <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
+    TBA_PHASE(3, 0);
     // all n(n-1)/2 pairs by circular distance d: (i, (i+d) mod n) for d = 1..(n-1)/2, plus
     // (i, i + n/2) for i < n/2 when n is even; slope(i,j) == slope(j,i) bitwise.  The loops have
     // workgroup-uniform trip counts (the visitor ballots).
@@ -683,8 +686,8 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     //  1. a sample (TSW_SAMPLE_DIST evenly spread circular distances, approximate slopes) is
     //     histogrammed; the buckets at the sample quantiles 0.5 -/+ 4 sigma give a window
     //     [t1, t2) that holds the two middle ranks of ALL slopes with near certainty;
-    //  2. every pair is classified against the window by an approximate quotient
-    //     a * r, r = v_rcp_f64(b) refined by one Newton step (relative error far below TSW_REL):
+    //  2. every pair is classified against the window without a division (a sign(b) against
+    //     t |b|, the edges moved outwards by the relative guard band TSW_REL >> 2^-53):
     //     safely below t1 -> counted; safely above t2 -> nothing; inside the window or within
     //     the guard band of an edge -> (a, b) is appended to a list in global scratch;
     //  3. the list (a few thousand pairs) is divided exactly, classified exactly, and the middle
@@ -694,11 +697,25 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
     // form runs instead.
     double slope = 0;
     bool fast_done = false;
-    const i64 cap = r.n_raw / 2 < 12288 ? r.n_raw / 2 : 12288; // (a, b) pairs in my scratch slice
+    // (a, b) pairs in this read's slices of the csum and score buffers (n_raw doubles each)
+    const i64 cap1 = r.n_raw / 2, cap2 = scratch2 != nullptr ? r.n_raw / 2 : 0;
+    const i64 cap = cap1 + cap2 < 65536 ? cap1 + cap2 : 65536;
     if (n >= TSW_MIN_POINTS && scratch != nullptr && cap >= 4096) {
-        double *cl = scratch + r.raw_off + blockIdx.x; // this read's slice of the csum buffer
+        double *cl1 = scratch + r.raw_off + blockIdx.x, *cl2 = scratch2 + r.raw_off;
+        auto pair_at = [&](i64 k) { return k < cap1 ? cl1 + 2 * k : cl2 + 2 * (k - cap1); };
         const int nn = (int)n, dmax = (nn - 1) / 2;
-        const int ds = dmax < TSW_SAMPLE_DIST ? dmax : TSW_SAMPLE_DIST;
+        // Sample size.  The window spans +-4 sigma of a sample quantile, so the list holds about
+        // 4 ns / sqrt(sample) pairs.  Measured per workgroup: ~1.3 cycles per sample element,
+        // ~20 per listed pair (scattered append, exact division, select) -- a flat optimum
+        // around 64-128 k samples for 1000 points; more when the scratch is small (the list
+        // should stay under 60 % of it).
+        int ds;
+        {
+            const double want = 4.0 * (double)ns / (0.6 * (double)cap);
+            const double need = want * want / (double)nn;
+            ds = need < 96.0 ? 96 : (need > (double)TSW_SAMPLE_DIST ? TSW_SAMPLE_DIST : (int)need + 1);
+            ds = ds < dmax ? ds : dmax;
+        }
         const double glo = 0.5, gsc = (double)BS_NB / 1.0;
         for (int b = tid; b < BS_NB; b += SEL_NT) sm.hist[b] = 0;
         if (tid == 0) { s_ncand = 0; s_win_ok = 0; }
@@ -716,24 +733,40 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
             }
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) { // wave 0: the buckets holding the sample ranks (0.5 -/+ dq) m
             const double m = (double)nn * ds;
             const double dq = 4.0 * sqrt(0.25 / m) + 0.0005;
             const i64 r1 = (i64)((0.5 - dq) * m), r2 = (i64)((0.5 + dq) * m);
-            i64 acc = 0; int b1 = -1, b2 = -1;
-            for (int b = 0; b < BS_NB; b++) {
-                const i64 nx = acc + sm.hist[b];
-                if (b1 < 0 && nx > r1) b1 = b;
-                if (b2 < 0 && nx > r2) { b2 = b; break; }
+            const int per = BS_NB / 64;
+            i64 c = 0;
+            for (int q = 0; q < per; q++) c += sm.hist[tid * per + q];
+            i64 inc = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                const i64 t = shfl_i64(inc, tid - d < 0 ? 0 : tid - d);
+                if (tid >= d) inc += t;
+            }
+            // first bucket whose cumulative count exceeds the rank: exactly one lane owns it
+            i64 acc = inc - c;
+            int b1 = -1, b2 = -1;
+            for (int q = 0; q < per; q++) {
+                const i64 nx = acc + sm.hist[tid * per + q];
+                if (acc <= r1 && r1 < nx) b1 = tid * per + q;
+                if (acc <= r2 && r2 < nx) b2 = tid * per + q;
                 acc = nx;
             }
-            if (b1 > 0 && b2 >= b1 && b2 < BS_NB - 1) {
-                s_win[0] = glo + (double)b1 / gsc;
-                s_win[1] = glo + (double)(b2 + 1) / gsc;
-                s_win_ok = 1;
+            const u64 m1 = __ballot(b1 >= 0), m2 = __ballot(b2 >= 0);
+            if (m1 && m2) {
+                b1 = __shfl(b1, __ffsll((unsigned long long)m1) - 1, 64);
+                b2 = __shfl(b2, __ffsll((unsigned long long)m2) - 1, 64);
+                if (tid == 0 && b1 > 0 && b2 >= b1 && b2 < BS_NB - 1) {
+                    s_win[0] = glo + (double)b1 / gsc;
+                    s_win[1] = glo + (double)(b2 + 1) / gsc;
+                    s_win_ok = 1;
+                }
             }
         }
         __syncthreads();
+        TBA_PHASE(3, 1);
         if (s_win_ok) {
             const double t1 = s_win[0], t2 = s_win[1]; // 0.5 < t1 < t2 < 1.5
             const double A1 = t1 - t1 * TSW_REL, B2 = t2 + t2 * TSW_REL;
@@ -759,30 +792,32 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
                         if (d0 + u > dlim) continue;
                         const double b = ei - ej[u], a = mi - mj[u];
                         if (b == 0) continue; // max_slope = 1000: above the window
-                        double rr = __builtin_amdgcn_rcp(b);
-                        rr = __builtin_fma(__builtin_fma(-b, rr, 1.0), rr, rr);
-                        const double q = a * rr;
-                        if (q < A1) { c_lo++; continue; }       // safely below the window
-                        if (q >= B2) continue;                   // safely above
+                        // a / b against the guarded edges without dividing: the sign of b is
+                        // folded into a, then a' < A1 |b|  =>  a / b < A1 (1 + 2^-53) < t1
+                        const double ab = fabs(b), as = b < 0 ? -a : a;
+                        if (as < A1 * ab) { c_lo++; continue; }  // safely below the window
+                        if (as >= B2 * ab) continue;             // safely above
                         // inside, or too close to an edge to tell (NaNs land here too)
                         const u32 pos = atomicAdd(&s_ncand, 1u);
-                        if (pos < cap) { cl[2 * (i64)pos] = a; cl[2 * (i64)pos + 1] = b; }
+                        if (pos < cap) { double *pr = pair_at(pos); pr[0] = a; pr[1] = b; }
                     }
                 }
             }
             c_lo = block_sum_i64(c_lo, &sm.rad);
             __threadfence_block();
             __syncthreads();
+            TBA_PHASE(3, 2);
             const i64 n_c = s_ncand;
             if (n_c <= cap) {
                 // exact slopes of the listed pairs; in-window ones stay (in place of their a),
                 // the rest becomes +inf and the ones below t1 are counted
                 i64 lo_more = 0, inw = 0;
                 for (i64 k = tid; k < n_c; k += SEL_NT) {
-                    const double sl = cl[2 * k] / cl[2 * k + 1];
+                    double *pr = pair_at(k);
+                    const double sl = pr[0] / pr[1];
                     const bool below = sl < t1, in = sl >= t1 && sl < t2;
                     lo_more += below; inw += in;
-                    cl[2 * k] = in ? sl : INFINITY;
+                    pr[0] = in ? sl : INFINITY;
                 }
                 c_lo += block_sum_i64(lo_more, &sm.rad);
                 inw = block_sum_i64(inw, &sm.rad);
@@ -790,14 +825,14 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
                 __syncthreads();
                 const i64 k_lo = (ns - 1) / 2 - c_lo, k_hi = ns / 2 - c_lo;
                 if (k_lo >= 0 && k_hi < inw) {
-                    const double a = block_kth([&](i64 k) { return cl[2 * k]; }, n_c, k_lo, t1, t2, &sm);
+                    const double a = block_kth([&](i64 k) { return pair_at(k)[0]; }, n_c, k_lo, t1, t2, &sm);
                     const int found = sm.found;
                     const double nxt = sm.next;
                     __syncthreads();
                     double b = a;
                     if (k_hi != k_lo) {
                         if (found & 2) b = nxt; // the next order statistic came with the first one
-                        else { b = block_kth([&](i64 k) { return cl[2 * k]; }, n_c, k_hi, t1, t2, &sm); __syncthreads(); }
+                        else { b = block_kth([&](i64 k) { return pair_at(k)[0]; }, n_c, k_hi, t1, t2, &sm); __syncthreads(); }
                     }
                     slope = (ns & 1) ? a : (a + b) / 2.0;
                     fast_done = true;
@@ -805,10 +840,14 @@ __global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevPa
             }
         }
     }
+    TBA_PHASE(3, 3);
     if (!fast_done) slope = block_median_fe(slopes, ns, 0.5, 1.5, &sm);
+    TBA_PHASE(3, 4);
     // intercepts of a normalised read sit within a unit or so of 0 (first bucket range only)
     double inter = block_median_fast([&](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, -2.0,
                                      2.0, &sm);
+    TBA_PHASE(3, 5);
+    TBA_PHASE_END(3);
     if (tid == 0) {
         if (slope == 0) { r.status = TBA_RESCALE_FAIL; return; }
         double scale_corr = 1 / slope;
@@ -865,7 +904,7 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const D
         const bool staged = span <= CAP;
         if (staged) {
             __builtin_amdgcn_wave_barrier();
-            for (i64 k = lane; k < span; k += 64) lds[k] = x[lo + k];
+            wave_stage<CAP / 64>(x, lo, span, lds, [](i64, double xv) { return xv; });
             __builtin_amdgcn_wave_barrier();
         }
         const double len = (double)(b - a);
@@ -922,11 +961,11 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
         double s = 0;
         if (span <= CAP) {
             __builtin_amdgcn_wave_barrier();
-            for (i64 k = lane; k < span; k += 64) {
-                const double v = skip ? x[lo + k] : (x[lo + k] - ca) / cb; // resquiggle.py:1190
-                if (WRITE) y[lo + k] = v;
-                lds[k] = v;
-            }
+            wave_stage<CAP / 64>(x, lo, span, lds, [&](i64 j, double xv) {
+                const double v = skip ? xv : (xv - ca) / cb; // resquiggle.py:1190
+                if (WRITE) y[j] = v;
+                return v;
+            });
             __builtin_amdgcn_wave_barrier();
             s = seq_sum_lds(lds, a - lo, b - lo);
         } else {

@@ -20,13 +20,18 @@ typedef uint32_t u32;
 #define SCALE_CHANGE_THRESH 0.1   // _default_parameters.py:170
 #define MAX_TS_POINTS 1000        // _default_parameters.py:178
 
-// optional per-phase cycle stamps into ReadState.dbg (build with -DTBA_PHASE_DEBUG)
+// optional per-phase cycle stamps into ReadState.dbg: build with -DTBA_PHASE_DEBUG=<kernel>
+// (1 k_peaks, 2 k_normalize, 3 k_theil_sen); stamps are cumulative from the kernel's start
 #ifdef TBA_PHASE_DEBUG
-#define TBA_PHASE_T0() const i64 tba_t0_ = __builtin_readcyclecounter()
-#define TBA_PHASE(i_) do { if (threadIdx.x == 0) r.dbg[i_] = __builtin_readcyclecounter() - tba_t0_; } while (0)
+#define TBA_PHASE_T0(k_) const i64 tba_t0_ = (k_) == TBA_PHASE_DEBUG ? (i64)__builtin_readcyclecounter() : 0; \
+    const i64 tba_w0_ = (k_) == TBA_PHASE_DEBUG ? (i64)__builtin_amdgcn_s_memrealtime() : 0
+// dbg[7]: the same interval on the constant 100 MHz counter (gives the shader clock of the run)
+#define TBA_PHASE_END(k_) do { if ((k_) == TBA_PHASE_DEBUG && threadIdx.x == 0) r.dbg[7] = (i64)__builtin_amdgcn_s_memrealtime() - tba_w0_; } while (0)
+#define TBA_PHASE(k_, i_) do { if ((k_) == TBA_PHASE_DEBUG && threadIdx.x == 0) r.dbg[i_] = (i64)__builtin_readcyclecounter() - tba_t0_; } while (0)
 #else
-#define TBA_PHASE_T0() do { } while (0)
-#define TBA_PHASE(i_) do { } while (0)
+#define TBA_PHASE_T0(k_) do { } while (0)
+#define TBA_PHASE(k_, i_) do { } while (0)
+#define TBA_PHASE_END(k_) do { } while (0)
 #endif
 
 enum { PATH_NONE = 0, PATH_ADAPTIVE = 1, PATH_STATIC = 2 };

@@ -581,7 +581,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 12 theil-sen
     if (ON(TBA_STAGE_RESCALE)) {
-        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr, e->d_csum.as<double>());
+        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr, e->d_csum.as<double>(), e->d_score.as<double>());
     }
     MARK(); // 13 rescale + score
     if (ON(TBA_STAGE_RESCALE)) {

@@ -1,0 +1,42 @@
+// Development aid: resident workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor) and
+// register / LDS use (hipFuncGetAttributes) of the batch kernels, from the same headers the
+// engine is built from.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o alt_builds/occupancy tools/occupancy.hip
+//   gpurun -- alt_builds/occupancy
+#include "../tombo_amd/csrc/tba_common.h"
+#include "../tombo_amd/csrc/k_select.h"
+#include "../tombo_amd/csrc/k_segment.h"
+#include "../tombo_amd/csrc/k_dp.h"
+#include "../tombo_amd/csrc/k_tail.h"
+#include <cstdio>
+
+template <class K> static void report(const char *name, K kernel, int threads)
+{
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0);
+    hipFuncAttributes a{};
+    hipError_t e2 = hipFuncGetAttributes(&a, reinterpret_cast<const void *>(kernel));
+    printf("%-28s threads %4d  workgroups/CU %2d (waves/CU %2d)  vgpr %3d  lds %6zu  scratch %4zu  %s %s\n",
+           name, threads, nb, nb * threads / 64, a.numRegs, a.sharedSizeBytes, a.localSizeBytes,
+           e == hipSuccess ? "" : hipGetErrorString(e), e2 == hipSuccess ? "" : hipGetErrorString(e2));
+}
+
+int main()
+{
+    report("k_normalize<double>", k_normalize<double>, SEL_NT);
+    report("k_normalize<int16_t>", k_normalize<int16_t>, SEL_NT);
+    report("k_cumsum_scores<20>", k_cumsum_scores<20>, 256);
+    report("k_cumsum_scores<32>", k_cumsum_scores<32>, 256);
+    report("k_scores_ttest<double>", k_scores_ttest<double>, 256);
+    report("k_peaks", k_peaks, SEL_NT);
+    report("k_event_means<double>", k_event_means<double>, 256);
+    report("k_dp<8,false>", k_dp<8, false>, 64);
+    report("k_dp<5,false>", k_dp<5, false>, 64);
+    report("k_dp<12,false>", k_dp<12, false>, 64);
+    report("k_main_tb", k_main_tb, 64);
+    report("k_skip_dp", k_skip_dp, 64);
+    report("k_theil_sen", k_theil_sen, SEL_NT);
+    report("k_rescale_absz<true>", k_rescale_absz<true>, 256);
+    report("k_rescale_absz<false>", k_rescale_absz<false>, 256);
+    return 0;
+}

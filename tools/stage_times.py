@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--rna', action='store_true')
     ap.add_argument('--repeat', type=int, default=3)
     ap.add_argument('--skip-norm-out', action='store_true')
+    ap.add_argument('--libs', default='', help='comma-separated builds of libtombo_amd.so to compare on the same reads')
     a = ap.parse_args()
     from tombo_amd import _native, tombo_stats as ts, tombo_helper as th
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
@@ -41,29 +42,51 @@ def main():
     src = [r.astype(dt) for r in src]
     rng = np.random.RandomState(1)
     si = np.stack([rng.choice(a.bases, 1000, replace=False) for _ in range(a.reads)]) if a.bases > 1000 else None
-    eng = _native.Engine(0)
-    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
-    eng.upload(_native.make_params(params),
-               _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[sn],
-                                 skip_norm_out=a.skip_norm_out),
-               src, seqs, samp_ind=si, stall_ints=st if a.rna else None)
-    eng.run()
-    acc = np.zeros(32)
-    for _ in range(a.repeat):
+    import hashlib
+    digests = []
+    eng = None
+    for lib_path in (a.libs.split(',') if a.libs else [None]):
+        if lib_path is not None:   # another build of the library, same process, same reads
+            if eng is not None:
+                eng.close()
+            _native.LIB_PATH, _native._lib = os.path.abspath(lib_path), None
+            print('--- %s' % lib_path)
+        eng = _native.Engine(0)
+        eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+        eng.upload(_native.make_params(params),
+                   _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[sn],
+                                     skip_norm_out=a.skip_norm_out),
+                   src, seqs, samp_ind=si, stall_ints=st if a.rna else None)
         eng.run()
-        acc += eng.get(_native.GET_KERNEL_MS)
-    acc /= a.repeat
-    out = eng.download(want_norm=False)
-    print('reads %d bases %d W %d dac %s dtype %s: ok %d' % (a.reads, a.bases, a.bandwidth, a.dac, a.dtype,
-                                                           int((out['status'] == 0).sum())))
-    print('  '.join('%s %.2f' % (k, v) for k, v in zip(_native.STAGE_NAMES, acc[:16]) if v > 0.004))
+        acc = np.zeros(32)
+        for _ in range(a.repeat):
+            eng.run()
+            acc += eng.get(_native.GET_KERNEL_MS)
+        acc /= a.repeat
+        out = eng.download(want_norm=not a.skip_norm_out)
+        print('reads %d bases %d W %d dac %s dtype %s: ok %d' % (a.reads, a.bases, a.bandwidth, a.dac,
+                                                               a.dtype, int((out['status'] == 0).sum())))
+        print('  '.join('%s %.2f' % (k, v) for k, v in zip(_native.STAGE_NAMES, acc[:16]) if v > 0.004))
+        h = hashlib.sha256()   # (large arrays enter through a 64-bit xor / wrapping sum)
+        for k in sorted(out):
+            if isinstance(out[k], np.ndarray):
+                b = np.ascontiguousarray(out[k]).reshape(-1).view(np.uint8)
+                b = b[:b.size // 8 * 8].view(np.uint64)
+                w = np.arange(1, 1 + min(b.size, 1 << 16), dtype=np.uint64)
+                h.update(np.bitwise_xor.reduce(b).tobytes() + b.sum(dtype=np.uint64).tobytes() +
+                         (b[:w.size] * w).sum(dtype=np.uint64).tobytes())
+        digests.append(h.hexdigest())
+        print('result digest %s' % digests[-1][:16])
+        if os.environ.get('TBA_DBG_PHASES'):
+            d = eng.get(_native.GET_DEBUG_COUNTERS)
+            print('dbg mean', ' '.join('%.0f' % x for x in d.mean(axis=0)))
+            print('dbg sum ', ' '.join('%.0f' % x for x in d.sum(axis=0)))
+            print('dbg max ', ' '.join('%.0f' % x for x in d.max(axis=0)))
+
+    if len(digests) > 1:
+        print('all builds give identical results: %s' % (len(set(digests)) == 1))
     path = eng.get(_native.GET_PATH)
     print('start calls: %s' % np.bincount(path[:, 3], minlength=3).tolist())
-    if os.environ.get('TBA_DBG_PHASES'):
-        d = eng.get(_native.GET_DEBUG_COUNTERS)
-        print('dbg mean', ' '.join('%.0f' % x for x in d.mean(axis=0)))
-        print('dbg sum ', ' '.join('%.0f' % x for x in d.sum(axis=0)))
-        print('dbg max ', ' '.join('%.0f' % x for x in d.max(axis=0)))
 
 
 if __name__ == '__main__':
