@@ -48,20 +48,7 @@ struct DpJob {
 
 // wave-level helpers on the DPP crossbar (no LDS round trip): lane i <- lane i-1, and a full
 // wave max (quad_perm / row_ror / row_bcast ladder, result broadcast from lane 63)
-__device__ __forceinline__ double wave_shr1_f64(double x, double lane0_val)
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(lane0_val), lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0_val), hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_shl1_f64(double x, double lane63_val) // lane i <- lane i+1
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(lane63_val), lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane63_val), hi, 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
+// (wave_shr1_f64 / wave_shl1_f64: tba_common.h)
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_mov_f64(double x)
 {

@@ -20,7 +20,11 @@ template <> struct raw_is_int<int16_t> { static constexpr bool value = true; };
 #define NORM_WINDOW_MIN 16384 // below this the generic select is cheap anyway
 
 template <class RT>
-__global__ __launch_bounds__(SEL_NT) void k_normalize(ReadState *rs, const DevParams *dp,
+// (second launch bound = wavefronts per SIMD the register allocation must leave room for: these
+// workgroup-per-read kernels are latency bound, their time follows the resident workgroups per
+// CU -- see tools/occupancy.hip -- and without the bound the allocator drifts across an
+// occupancy step with every edit)
+__global__ __launch_bounds__(SEL_NT, 4) void k_normalize(ReadState *rs, const DevParams *dp,
     const RT *raw, double *norm, const double *sv_in, int mode, int write_norm)
 {
     __shared__ BucketSmem sm;
@@ -450,8 +454,8 @@ __device__ __forceinline__ bool prio_before(double sp, i64 p, double sq, i64 q)
 //            index, so that is score[p + d] >= score[p]); "this position outranks the one at
 //            -d" is the complement over valid pairs, shifted up by d
 //   T, S     taken / suppressed so far
-// The masks come from one compare + ballot per 64 positions and offset, selected into their
-// lane.  A round is then ~20 bit operations per offset for 4096 positions:
+// The masks come from one compare (= ballot: the compare writes a lane mask) per 64 positions and
+// offset, selected into their lane.  A round is then ~20 bit operations per offset for 4096 positions:
 // taken-by-a-higher-neighbour suppresses, no-undecided-higher-neighbour takes; the neighbour
 // words cross lanes through DPP.  Decisions are only ever taken from decided neighbours, so
 // whatever is decided here is final; the first and last lane of a tile are halo (their outside
@@ -495,8 +499,15 @@ __device__ __forceinline__ W64 w_ballot_to_lane(W64 old, u64 m, int g) // word o
 // the selection that follows): one LDS counter bump per 64 positions.
 template <int R>
 __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *dense, u32 *n_dense,
-                          double &mn, double &mx)
+                          double &mn, double &mx, i64 *tdbg = nullptr)
 {
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 4
+    // wave 0's cycles in the three parts of a tile, rounds and tiles (sums over its tiles)
+#define TILE_T(i_) do { if (tdbg && threadIdx.x == 0) { const i64 t_ = (i64)__builtin_readcyclecounter(); tdbg[i_] += t_ - tile_t_; tile_t_ = t_; } } while (0)
+    i64 tile_t_ = (i64)__builtin_readcyclecounter();
+#else
+#define TILE_T(i_) do { } while (0)
+#endif
     static_assert(R >= 1 && R < 32, "exclusion radius");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     i64 left = 0;
@@ -507,22 +518,46 @@ __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *de
         W64 V = zero, G[R + 1];
 #pragma unroll
         for (int d = 1; d <= R; d++) G[d] = zero;
-        // masks: group g = positions g0 + 64 g + lane
-#pragma unroll 4
-        for (int g = 0; g < 64; g++) {
-            const i64 p = g0 + 64 * g + lane;
-            const bool vp = p >= 0 && p < ns;
-            const i64 pc = p < 0 ? 0 : (p >= ns ? ns - 1 : p);
-            const double sp = s[pc];
-            V = w_ballot_to_lane(V, __ballot(vp), g);
+        // masks: group g = positions g0 + 64 g + lane.  Every score is loaded once; the
+        // neighbour at +d is the value d lanes up: one wave_shl:1 DPP step per offset, lane 63
+        // taking lane d-1 of the next group.  Groups come in chunks of GC whose loads are in
+        // flight together, the next chunk's issued before this one's masks are built.
+#ifndef PKB_GC
+#define PKB_GC 4 // (4 / 4: no register spills at 128 VGPRs; radius 2 fits 80 = three workgroups per CU)
+#endif
+        constexpr int GC = PKB_GC;
+        auto load_group = [&](int g) {
+            const i64 p = g0 + 64 * (i64)g + lane;
+            return s[p < 0 ? 0 : (p >= ns ? ns - 1 : p)];
+        };
+        double cu[GC], nx[GC];
 #pragma unroll
-            for (int d = 1; d <= R; d++) {
-                const i64 q = p + d;
-                const i64 qc = q < 0 ? 0 : (q >= ns ? ns - 1 : q);
-                const double sq = s[qc];
-                G[d] = w_ballot_to_lane(G[d], __ballot(vp && q >= 0 && q < ns && sq >= sp), g);
+        for (int u = 0; u < GC; u++) cu[u] = load_group(u);
+        for (int c0 = 0; c0 < 64; c0 += GC) {
+#pragma unroll
+            for (int u = 0; u < GC; u++) // (group 64: the first R positions past the tile)
+                nx[u] = (u == 0 || c0 + GC < 64) ? load_group(c0 + GC + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < GC; u++) {
+                const int g = c0 + u;
+                const i64 p = g0 + 64 * (i64)g + lane;
+                const bool vp = p >= 0 && p < ns;
+                const double sp = cu[u], up = u + 1 < GC ? cu[u + 1 < GC ? u + 1 : 0] : nx[0];
+                V = w_ballot_to_lane(V, __ballot(vp), g);
+                double sq = sp;
+#pragma unroll
+                for (int d = 1; d <= R; d++) {
+                    const double edge = __hiloint2double(
+                        __builtin_amdgcn_readlane(__double2hiint(up), d - 1),
+                        __builtin_amdgcn_readlane(__double2loint(up), d - 1));
+                    sq = wave_shl1_f64(sq, edge); // score at p + d
+                    G[d] = w_ballot_to_lane(G[d], __ballot(vp && p + d < ns && sq >= sp), g);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < GC; u++) cu[u] = nx[u];
         }
+        TILE_T(0);
         // validity of the words just outside the tile
         const i64 after = ns - (g0 + PKB_SPAN); // positions of the signal past the tile
         const W64 v_after = after >= 64 ? ones : (after <= 0 ? zero :
@@ -555,8 +590,12 @@ __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *de
             const W64 nT = w_andn(w_andn(U, at), au);
             T = w_or(T, nT); S = w_or(S, nS);
             U = w_andn(w_andn(U, nT), nS);
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 4
+            if (tdbg && threadIdx.x == 0) tdbg[3]++;
+#endif
             if (__ballot((nS.lo | nS.hi | nT.lo | nT.hi) != 0) == 0) break;
         }
+        TILE_T(1);
         // core lanes 1..62 -> one state byte per position, taken scores -> dense list.  The
         // slot of every taken position is known up front (prefix of the per-word counts: one
         // counter bump per tile), and the scores of four groups are fetched before they are used.
@@ -575,35 +614,55 @@ __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *de
             dbase = (u32)__builtin_amdgcn_readfirstlane((int)dbase);
         }
         auto out_group = [&](int g, double v) {
+            // the group's taken / suppressed words as lane predicates (inverse ballot: the word
+            // becomes the exec mask) and the rank of a taken lane inside its word (v_mbcnt)
             const u32 tl = __builtin_amdgcn_readlane((int)T.lo, g), th = __builtin_amdgcn_readlane((int)T.hi, g);
             const u32 sl = __builtin_amdgcn_readlane((int)S.lo, g), sh = __builtin_amdgcn_readlane((int)S.hi, g);
+            const bool tb = __builtin_amdgcn_inverse_ballot_w64(((u64)th << 32) | tl);
+            const bool sb = __builtin_amdgcn_inverse_ballot_w64(((u64)sh << 32) | sl);
             const i64 p = g0 + 64 * g + lane;
-            const u32 tb = lane < 32 ? (tl >> lane) & 1u : (th >> (lane - 32)) & 1u;
-            const u32 sb = lane < 32 ? (sl >> lane) & 1u : (sh >> (lane - 32)) & 1u;
-            if (p < ns) st[p] = (unsigned char)(tb | (sb << 1));
+            if (p < ns) st[p] = (unsigned char)(tb ? 1 : (sb ? 2 : 0)); // (never both)
             if (tb) {
-                const u32 below = lane < 32 ? __popc(tl & ((1u << lane) - 1u))
-                                            : __popc(tl) + __popc(th & ((1u << (lane - 32)) - 1u));
+                const u32 below = __builtin_amdgcn_mbcnt_hi(th, __builtin_amdgcn_mbcnt_lo(tl, 0u));
                 dense[dbase + (u32)__builtin_amdgcn_readlane(excl, g) + below] = v;
                 mn = v < mn ? v : mn; mx = v > mx ? v : mx;
             }
         };
         auto score_at = [&](int g) { const i64 p = g0 + 64 * g + lane; return s[p < ns ? p : ns - 1]; };
+#ifndef PKB_OU
+#define PKB_OU 4
+#endif
+        constexpr int OU = PKB_OU; // groups whose scores are in flight together
         int g = 1;
-        for (; g + 3 < 63; g += 4) {
-            double v[4];
+        for (; g + OU - 1 < 63; g += OU) {
+            double v[OU];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = score_at(g + u);
+            for (int u = 0; u < OU; u++) v[u] = score_at(g + u);
 #pragma unroll
-            for (int u = 0; u < 4; u++) out_group(g + u, v[u]);
+            for (int u = 0; u < OU; u++) out_group(g + u, v[u]);
         }
-        for (; g < 63; g++) out_group(g, score_at(g));
+        {
+            double v[OU];
+#pragma unroll
+            for (int u = 0; u < OU; u++) v[u] = g + u < 63 ? score_at(g + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < OU; u++) if (g + u < 63) out_group(g + u, v[u]);
+        }
         if (lane >= 1 && lane < 63) left += __popc(U.lo) + __popc(U.hi);
+        TILE_T(2);
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 4
+        if (tdbg && threadIdx.x == 0) tdbg[4]++;
+#endif
     }
+#undef TILE_T
     return left;
 }
 
-__global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams *dp,
+// RT: the exclusion radius min_obs_per_base - 1 the tile code is compiled for (2: DNA default,
+// 5: RNA default -- one kernel each, so that the narrow one does not carry the wide one's
+// registers); 0: any radius, everything through the global rounds.
+template <int RT>
+__global__ __launch_bounds__(SEL_NT, 4) void k_peaks(ReadState *rs, const DevParams *dp,
     const double *score, unsigned char *state, double *dense, i64 *valid_cpts, int ttest)
 {
     __shared__ BucketSmem sm;
@@ -634,9 +693,12 @@ __global__ __launch_bounds__(SEL_NT) void k_peaks(ReadState *rs, const DevParams
         i64 left_undecided = 0;
         if (tid == 0) s_ndense = 0;
         __syncthreads();
-        if (m - 1 == 2) { left_undecided = peaks_bits<2>(s, st, ns, dn, &s_ndense, mn, mx); fused = true; __syncthreads(); }
-        else if (m - 1 == 5) { left_undecided = peaks_bits<5>(s, st, ns, dn, &s_ndense, mn, mx); fused = true; __syncthreads(); }
-        else { // unusual min_obs_per_base: everything goes through the global rounds
+        if constexpr (RT > 0) {
+            if (m - 1 != RT) { if (tid == 0) r.status = TBA_INTERNAL; return; } // (host dispatch)
+            left_undecided = peaks_bits<RT>(s, st, ns, dn, &s_ndense, mn, mx, r.dbg);
+            fused = true;
+            __syncthreads();
+        } else { // unusual min_obs_per_base: everything goes through the global rounds
             for (i64 p = tid; p < ns; p += SEL_NT) st[p] = 0;
             left_undecided = 1;
             __syncthreads();

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
 // over the resolved boundaries) are computed here, for the <= 1000 sampled bases only: a thread
 // sums its base's samples in order and divides once -- a read of 10 000 bases touches a tenth of
 // its signal instead of all of it (the separate k_base_means pass of round 1: 2.7 ms, RNA 9 ms).
-__global__ __launch_bounds__(SEL_NT) void k_theil_sen(ReadState *rs, const DevParams *dp,
+__global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const DevParams *dp,
     const double *norm, const i64 *segs, const double *ref_means, const i64 *samp_ind, double *scratch,
     double *scratch2)
 {

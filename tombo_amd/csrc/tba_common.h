@@ -89,6 +89,23 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
     return __builtin_fma(e, y, q);
 }
 
+// whole-wave shift by one lane on the DPP crossbar (no LDS round trip): lane i <- lane i-1 /
+// lane i <- lane i+1; the lane without a source takes the given value
+__device__ __forceinline__ double wave_shr1_f64(double x, double lane0_val)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(lane0_val), lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0_val), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1_f64(double x, double lane63_val) // lane i <- lane i+1
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(lane63_val), lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane63_val), hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // order-preserving map double -> u64 (ascending); no NaNs on this path
 __device__ __forceinline__ u64 f64_key(double x)
 {

@@ -67,6 +67,17 @@ static const char *STAGE_NAMES[N_STAGE] = {
 
 #define WIDE_BLOCKS 64 // workgroups of k_dp_wide (each owns two scratch rows)
 #define TB_LANES 16    // reads per wavefront of the latency-bound lane-per-read kernels
+
+// k_peaks is compiled per exclusion radius (min_obs_per_base - 1): 2 and 5 are the defaults of
+// the DNA / RNA parameter sets, anything else takes the generic kernel
+static void launch_peaks(i64 min_obs_per_base, unsigned n_blocks, hipStream_t s, ReadState *rs,
+                         const DevParams *dp, const double *score, unsigned char *state,
+                         double *dense, i64 *valid_cpts, int ttest)
+{
+    if (min_obs_per_base - 1 == 2) k_peaks<2><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest);
+    else if (min_obs_per_base - 1 == 5) k_peaks<5><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest);
+    else k_peaks<0><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest);
+}
 struct tba_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -519,7 +530,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 3 peaks
     if (ON(TBA_STAGE_SEGMENT)) {
-        k_peaks<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
+        launch_peaks(P.min_obs_per_base, nb, s, rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
         if (e->any_stall) k_remove_stalls<<<nb, SEL_NT, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>(), e->d_csum.as<double>());
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
             RAW_DISPATCH(rdt, (k_event_means<RT><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 1)));
@@ -1148,7 +1159,7 @@ static int c_valid_cpts(tba_engine *e, const double *sig, int64_t n, int64_t min
     } else {
         k_scores_ttest<double><<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
     }
-    k_peaks<<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_score.as<double>(),
+    launch_peaks(min_base_obs, 1, s, d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_score.as<double>(),
                                  d_state.as<unsigned char>(), d_csum.as<double>(), d_cpts.as<i64>(), ttest);
     C_TRY(hipGetLastError());
     C_TRY(hipStreamSynchronize(s));

@@ -28,7 +28,8 @@ int main()
     report("k_cumsum_scores<20>", k_cumsum_scores<20>, 256);
     report("k_cumsum_scores<32>", k_cumsum_scores<32>, 256);
     report("k_scores_ttest<double>", k_scores_ttest<double>, 256);
-    report("k_peaks", k_peaks, SEL_NT);
+    report("k_peaks<2>", k_peaks<2>, SEL_NT);
+    report("k_peaks<5>", k_peaks<5>, SEL_NT);
     report("k_event_means<double>", k_event_means<double>, 256);
     report("k_dp<8,false>", k_dp<8, false>, 64);
     report("k_dp<5,false>", k_dp<5, false>, 64);
