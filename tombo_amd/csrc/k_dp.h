@@ -701,7 +701,7 @@ __device__ inline int dev_banded_traceback(const unsigned char *mv, i64 stride, 
 // start discovery epilogue: traceback, score_valid_bases (tombo_stats.py:2340-2362), events per
 // base (resquiggle.py:740-752) and the retry / fallback decision (resquiggle.py:992-1006).
 // One thread per read.
-__global__ void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int mode,
+__global__ __launch_bounds__(64) void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
     const unsigned char *moves, i64 start_moves_stride, i64 *read_tb, double *start_vals)
 {
@@ -746,7 +746,7 @@ __global__ void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int 
 }
 
 // the branch of find_adaptive_base_assignment before start discovery (resquiggle.py:984-989)
-__global__ void k_path0(ReadState *rs, i64 n_reads, const DevParams *dp)
+__global__ __launch_bounds__(64) void k_path0(ReadState *rs, i64 n_reads, const DevParams *dp)
 {
     i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (ri >= n_reads) return;
@@ -763,7 +763,7 @@ __global__ void k_path0(ReadState *rs, i64 n_reads, const DevParams *dp)
 // _get_masked_start_fwd_pass (resquiggle.py:607-683) or find_static_base_assignment
 // (resquiggle.py:561-571).  One thread per read; writes band_starts / lo / hi for the static
 // rows and the moves size (in moves_off, turned into an offset by k_scan_moves).
-__global__ void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *band_starts,
+__global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const DevParams *dp, i64 *band_starts,
     i32 *lo_arr, i32 *hi_arr)
 {
     i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;

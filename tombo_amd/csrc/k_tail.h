@@ -982,13 +982,63 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
     }
 }
 
-// ts.get_read_seg_score (tombo_stats.py:2327-2338): np.mean in numpy's summation order.
-// One thread per read.
-__global__ void k_final_score(ReadState *rs, i64 n_reads, const double *absz)
+// ts.get_read_seg_score (tombo_stats.py:2327-2338): np.mean in numpy's summation order
+// (np.add.reduce: 8192-element chunks accumulated left to right, each summed pairwise: a size m
+// splits at m/2 rounded down to a multiple of 8 until a piece has <= 128 elements, a leaf keeps 8
+// strided partial sums -- np_pairwise_leaf).  One wavefront per read: lane 0 lists the leaves of
+// a chunk (pre-order walk, left first: at most 127), the lanes sum a leaf each, lane 0 adds the
+// leaf sums up in the recursion's order.  (One thread per read walked 10 000 values through a
+// chain of dependent loads: 1.1 ms per 10 000 reads.)
+__global__ __launch_bounds__(64) void k_final_score(ReadState *rs, i64 n_reads, const double *absz)
 {
-    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int l_start[128], l_len[128], s_nleaf;
+    __shared__ double l_sum[128];
+    __shared__ int st_a[16], st_n[16], st_st[16];
+    __shared__ double st_v[16];
+    const i64 ri = blockIdx.x;
     if (ri >= n_reads) return;
     ReadState &r = rs[ri];
     if (r.status != TBA_OK) return;
-    r.score = np_sum(absz + r.ref_off, r.B) / (double)r.B;
+    const int lane = threadIdx.x;
+    const double *a = absz + r.ref_off;
+    const i64 n = r.B;
+    double acc = 0.0;
+    for (i64 c0 = 0; c0 < n; c0 += 8192) {
+        const int m = (int)(n - c0 < 8192 ? n - c0 : 8192);
+        if (lane == 0) {
+            int sp = 0, nl = 0;
+            st_a[0] = 0; st_n[0] = m;
+            while (sp >= 0) {
+                const int s0 = st_a[sp], len = st_n[sp];
+                sp--;
+                if (len <= 128) { l_start[nl] = s0; l_len[nl] = len; nl++; continue; }
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                st_a[sp + 1] = s0 + n2; st_n[sp + 1] = len - n2; // right, visited after ...
+                st_a[sp + 2] = s0; st_n[sp + 2] = n2;            // ... the left half
+                sp += 2;
+            }
+            s_nleaf = nl;
+        }
+        __syncthreads();
+        for (int k = lane; k < s_nleaf; k += 64) l_sum[k] = np_pairwise_leaf(a + c0 + l_start[k], l_len[k]);
+        __syncthreads();
+        if (lane == 0) { // the recursion again, leaf values from l_sum in visiting order
+            int sp = 0, next = 0;
+            double ret = 0;
+            st_n[0] = m; st_st[0] = 0;
+            while (sp >= 0) {
+                const int len = st_n[sp];
+                if (len <= 128) { ret = l_sum[next++]; sp--; continue; }
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                if (st_st[sp] == 0) { st_st[sp] = 1; st_n[sp + 1] = n2; st_st[sp + 1] = 0; sp++; }
+                else if (st_st[sp] == 1) { st_v[sp] = ret; st_st[sp] = 2; st_n[sp + 1] = len - n2; st_st[sp + 1] = 0; sp++; }
+                else { ret = st_v[sp] + ret; sp--; }
+            }
+            acc += ret;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) r.score = acc / (double)r.B;
 }

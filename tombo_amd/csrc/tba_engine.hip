@@ -548,12 +548,12 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     if (ON(TBA_STAGE_START)) {
         k_path0<<<tpr, 64, 0, s>>>(rs, n, dp);
         launch_dp(e, cpl_class(P.start_bw), DP_START_TRY);
-        k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_TRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+        k_start_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, DP_START_TRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
     }
     MARK(); // 7
     if (ON(TBA_STAGE_START)) {
         launch_dp(e, cpl_class(P.start_save_bw), DP_START_RETRY);
-        k_start_tb<<<tpr, 64, 0, s>>>(rs, n, dp, DP_START_RETRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
+        k_start_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, DP_START_RETRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
     }
     MARK(); // 8 prep
     if (ON(TBA_STAGE_ASSIGN)) {
@@ -600,7 +600,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
             k_rescale_absz<false><<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), nullptr, e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
         else
             k_rescale_absz<true><<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_norm_out.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_absz.as<double>());
-        k_final_score<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, e->d_absz.as<double>());
+        k_final_score<<<nb, 64, 0, s>>>(rs, n, e->d_absz.as<double>());
     }
     MARK(); // 14 end
 #undef MARK
