@@ -1,5 +1,6 @@
 """A dict-backed stand-in for the part of the h5py group interface that
-write_new_fast5_group uses (`__getitem__`, `create_group`, `create_dataset`, `.attrs`): the build
+write_new_fast5_group and the FAST5 readers of the mapping step use (`__getitem__`, `values`,
+`create_group`, `create_dataset`, dataset `[()]` / `[:]`, `.attrs`): the build
 image has no HDF5 library, so the FAST5 writer is exercised against this and its tree is compared
 with the tree the REFERENCE's writer produces on the same stand-in (gen_golden_fast5.py)."""
 import numpy as np
@@ -10,6 +11,10 @@ class MemDataset(object):
         self.data = np.array(data)
         self.kw = kw
         self.attrs = {}
+
+    def __getitem__(self, key):          # ds[()] -> scalar / whole array, ds[:] -> array
+        v = self.data[key]
+        return v.item() if isinstance(v, np.ndarray) and v.shape == () and v.dtype.kind in 'SUO' else v
 
 
 class MemGroup(object):
@@ -35,6 +40,12 @@ class MemGroup(object):
         for part in [p for p in path.split('/') if p]:
             g = g.items[part]
         return g
+
+    def values(self):
+        return self.items.values()
+
+    def __contains__(self, name):
+        return name in self.items
 
 
 def tree(node, prefix=''):

@@ -1,0 +1,98 @@
+"""FAST5 in -> FAST5 record + index record out, the whole worker loop in batch form
+(`mapping.process_fast5_batch`: N3 glue, N1 iteration loop on the GPU, N2 writer).  The files are
+dict-backed FAST5 trees (tests/memh5.py), the aligner is scripted (tests/scripted_aligner.py);
+signal is synthesised from the reference sequence the hit points at, so the resquiggle has to
+succeed and its result has to equal a direct `resquiggle_batch_iters` on hand-built inputs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(samp_name):
+    import gen_golden_map as gm
+    from scripted_aligner import ScriptedAligner, Hit
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    rna = samp_name == 'RNA'
+    samp = th.seqSampleType(samp_name, rna)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    save = ts.load_resquiggle_parameters(samp, use_save_bandwidth=True)
+    K, cp = model.kmer_width, model.central_pos
+    rng = np.random.RandomState(3)
+    records, hits, fast5s, truth = {}, {}, [], []
+    for i, (nb, strand) in enumerate(((400, 1), (650, -1), (300, 1), (520, -1))):
+        seq, raw, _ = synth.synth_read(model, nb, 700 + i, **(synth.RNA_SYNTH if rna else synth.DNA_SYNTH))
+        flank_l = ''.join(rng.choice(list('ACGT'), 30 + i))
+        flank_r = ''.join(rng.choice(list('ACGT'), 25))
+        ctg = 'ctg%d' % i
+        records[ctg] = flank_l + (seq if strand == 1 else th.rev_comp(seq)) + flank_r
+        # the k-mer context the mapping adds around [r_st, r_en): see mapping.map_read
+        upstream = strand == 1   # DNA and RNA alike while USE_START_CLIP_BASES is off
+        before = cp if upstream else K - cp - 1
+        r_st = len(flank_l) + before
+        r_en = r_st + nb
+        read = ''.join(rng.choice(list('ACGT'), 2 * i)) + \
+            (records[ctg][r_st:r_en] if strand == 1 else th.rev_comp(records[ctg][r_st:r_en]))
+        dac = np.round(raw / 0.1709 + 10.0).astype(np.int16)
+        f = gm.make_fast5(read.replace('T', 'U') if rna else read, '5' * len(read), 10, 900 + i)
+        slot = next(iter(f['/Raw/Reads'].values()))
+        slot.create_dataset('Signal', data=dac[::-1].copy() if rna else dac)   # RNA is stored 3'->5'
+        hits[read] = [Hit(ctg, r_st, r_en, strand, nb - 3, [(nb, 0)], 2 * i, len(read))]
+        fast5s.append((f, 'reads/r%d.fast5' % i))
+        truth.append((seq, dac, ctg, r_st, strand))
+    return samp, model, params, save, ScriptedAligner(records, hits), fast5s, truth
+
+
+@pytest.mark.parametrize('samp_name', ['DNA', 'RNA'])
+def test_fast5_to_record(samp_name):
+    import memh5
+    from tombo_amd import mapping, resquiggle as rq, tombo_helper as th
+    samp, model, params, save, aligner, fast5s, truth = _setup(samp_name)
+    # one unmappable read and one without basecalls ride along
+    import gen_golden_map as gm
+    fast5s.append((gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 990), 'reads/nohit.fast5'))
+    fast5s.append((gm.make_fast5('ACGT', '5555', 500, 991, fastq=False), 'reads/nofastq.fast5'))
+    np.random.seed(5)
+    index, failures = mapping.process_fast5_batch(fast5s, aligner, model, params, samp,
+                                                  save_params=save, compute_sd=True)
+    assert sorted(m for m, _, _ in failures) == ['Alignment not produced',
+                                                 'Fastq slot not present in --basecall-group']
+    assert all(t for _, _, t in failures)
+    assert len(index) == len(truth)
+    # the same reads, hand-mapped, through the iteration loop directly
+    mrs = []
+    for (seq, dac, ctg, r_st, strand), (f, fn) in zip(truth, fast5s):
+        mrs.append(rq.adjust_map_res(th.resquiggleResults(
+            align_info=th.alignInfo('x', 'BaseCalled_template', 0, 0, 0, 0, 1, 0),
+            genome_loc=th.genomeLocation(r_st, '+' if strand == 1 else '-', ctg), genome_seq=seq,
+            mean_q_score=20.0, raw_signal=dac[::-1].copy() if samp.rev_sig else dac), samp))
+    np.random.seed(5)
+    direct = rq.resquiggle_batch_iters(mrs, model, params, save_params=save, outlier_thresh=5.0,
+                                       seq_samp_type=samp)
+    for (chrm, strand, rd), want, (seq, dac, ctg, r_st, st), (f, fn) in zip(index, direct, truth, fast5s):
+        assert not isinstance(want, Exception)
+        assert (chrm, strand) == (ctg, '+' if st == 1 else '-')
+        assert rd.start == r_st and rd.end == r_st + len(want.segs) - 1
+        assert rd.read_start_rel_to_raw == want.read_start_rel_to_raw
+        assert rd.sig_match_score == want.sig_match_score and rd.filtered == (want.sig_match_score > {'DNA': 1.1, 'RNA': 2}[samp.name])
+        assert rd.fn == fn and rd.corr_group == 'RawGenomeCorrected_000/BaseCalled_template'
+        assert rd.rna == samp.rev_sig and rd.mean_q_score == 20.0
+        # the record in the file
+        t = memh5.tree(f)
+        g = '/Analyses/RawGenomeCorrected_000/BaseCalled_template'
+        assert t[g + '@status'] == 'success' and t[g + '@rna'] == samp.rev_sig
+        assert t[g + '@shift'] == want.scale_values.shift and t[g + '@scale'] == want.scale_values.scale
+        ev = t[g + '/Events']
+        np.testing.assert_array_equal(ev['start'], want.segs[:-1])
+        np.testing.assert_array_equal(ev['length'], np.diff(want.segs))
+        assert b''.join(ev['base']).decode() == seq[model.central_pos:model.central_pos + len(want.segs) - 1]
+        assert t[g + '/Events@read_start_rel_to_raw'] == want.read_start_rel_to_raw
+        assert t[g + '/Alignment@mapped_chrom'] == ctg and t[g + '/Alignment@mapped_start'] == r_st

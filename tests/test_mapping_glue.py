@@ -1,0 +1,106 @@
+"""the host glue around the aligner call (tombo_amd/mapping.py) against what
+the live reference made of the same FAST5 trees and scripted hits
+(tests/golden/gen_golden_map.py -> map_cases.json).  CPU only: nothing here touches the engine."""
+import os
+import sys
+import json
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+import gen_golden_map as gm  # noqa: E402  (input builders only; the reference is not imported)
+from tombo_amd import mapping, tombo_helper as th, tombo_stats as ts  # noqa: E402
+
+GOLD = json.load(open(os.path.join(HERE, 'golden', 'map_cases.json')))
+RECORDS, CASES = gm.cases()
+
+
+def _std_ref(samp_name):
+    return ts.TomboModel(seq_samp_type=th.seqSampleType(samp_name, samp_name == 'RNA'))
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_map_read_equals_reference(name):
+    case, want = CASES[name], GOLD[name]['map_read']
+    samp = th.seqSampleType(case['samp'], case['samp'] == 'RNA')
+    f, al = gm.build(case, RECORDS)
+    kw = dict(q_score_thresh=case['kw'].get('q_score_thresh', 0), seq_len_rng=case['kw'].get('seq_len_rng'))
+    if 'error' in want:
+        with pytest.raises(th.TomboError) as ei:
+            mapping.map_read(f, al, _std_ref(case['samp']), samp, **kw)
+        assert str(ei.value) == want['error']
+        return
+    if 'unexpected' in want:
+        # aligner.seq() yields nothing: the reference means to raise 'Invalid mapping location'
+        # but constructs a TomboReads instead of a TomboError (resquiggle.py:1361) and dies with
+        # an unrelated exception; here the intended TomboError is raised
+        with pytest.raises(th.TomboError) as ei:
+            mapping.map_read(f, al, _std_ref(case['samp']), samp, **kw)
+        assert str(ei.value) == 'Invalid mapping location'
+        return
+    mr = mapping.map_read(f, al, _std_ref(case['samp']), samp, **kw)
+    assert list(mr.align_info) == want['align_info']
+    assert list(mr.genome_loc) == want['genome_loc']
+    assert mr.genome_seq == want['genome_seq']
+    assert float(mr.mean_q_score) == want['mean_q_score']
+    assert mr.start_clip_bases == want['start_clip_bases']
+    assert al.n_drained == want['drained']                      # the hit iterator was exhausted
+    assert mr.raw_signal is None and mr.segs is None             # signal fields stay empty
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_fast5_read_filters_and_index_record(name):
+    """read_fast5_for_mapping + filter_and_index_record = the reference's _io_and_map_read around
+    the resquiggle call (which the generator answered with a scripted result)"""
+    case = CASES[name]
+    samp = th.seqSampleType(case['samp'], case['samp'] == 'RNA')
+    for want in GOLD[name]['io']:
+        f, al = gm.build(case, RECORDS)
+        kw = dict(q_score_thresh=case['kw'].get('q_score_thresh', 0), seq_len_rng=case['kw'].get('seq_len_rng'),
+                  sig_len_rng=case['kw'].get('sig_len_rng'))
+        expect_err = want['raised'] or (want['failed'][0][0] if want['failed'] and not want['index'] else None)
+        if expect_err is not None:
+            with pytest.raises(th.TomboError) as ei:
+                mapping.read_fast5_for_mapping(f, al, _std_ref(case['samp']), samp, **kw)
+            if expect_err != 'unexpected':
+                assert str(ei.value) == expect_err
+            continue
+        mr = mapping.read_fast5_for_mapping(f, al, _std_ref(case['samp']), samp, **kw)
+        assert mr.raw_signal.dtype == np.int16 and mr.raw_signal.shape[0] == case['n_raw']
+        assert mr.channel_info == th.channelInfo(10.0, 1400.5, 8192.0, b'17', 4000)
+        # the scripted resquiggle result of the generator
+        nb = len(mr.genome_seq) - 5
+        segs = np.arange(nb + 1, dtype=np.int64) * want['step']
+        res = mr._replace(read_start_rel_to_raw=123, segs=segs, sig_match_score=want['score'])
+        of = None if want['obs_filter'] is None else [tuple(x) for x in want['obs_filter']]
+        chrm, strand, rd = mapping.filter_and_index_record(
+            res, 'dir/read_%d.fast5' % case['seed'], 'RawGenomeCorrected_000', 'BaseCalled_template',
+            samp, 1.1, of)
+        got = [chrm, strand] + [x.item() if hasattr(x, 'item') else x for x in rd]
+        assert got == want['index'][0]
+
+
+def test_read_id_fallbacks_and_missing_channel():
+    case = CASES['dna_plus']
+    samp = th.seqSampleType('DNA', False)
+    f, al = gm.build(case, RECORDS)
+    del f['/Raw/Reads'].items['Read_%d' % case['seed']].attrs['read_id']
+    del f.items['UniqueGlobalKey']
+    mr = mapping.read_fast5_for_mapping(f, al, _std_ref('DNA'), samp)
+    assert mr.align_info.ID == str(case['seed'])    # read_num stands in for a missing read_id
+    assert mr.channel_info is None                   # channel information is optional
+    f2 = gm.memh5.MemGroup()
+    with pytest.raises(th.TomboError) as ei:
+        mapping.read_fast5_for_mapping(f2, al, _std_ref('DNA'), samp)
+    assert 'Raw data is not found' in str(ei.value)
+
+
+def test_sequence_helpers():
+    assert th.rev_comp('AACGT') == 'ACGTT' and th.comp_seq('ACGTN') == 'TGCAN'
+    assert th.invalid_seq('ACGU') and not th.invalid_seq('ACGT')
+    assert th.rev_transcribe('ACGUU') == 'ACGTT'
+    assert th.get_mean_q_score('5I#') == np.mean([20, 40, 2])

@@ -16,8 +16,10 @@ from . import _native
 from ._default_parameters import (
     MAX_RAW_CPTS, MIN_EVENT_TO_SEQ_RATIO, SIG_MATCH_THRESH, DNA_SAMP_TYPE, RNA_SAMP_TYPE,
     MAX_POINTS_FOR_THEIL_SEN)
+from .mapping import get_read_seq, map_read   # (tombo.resquiggle's names; the glue lives there)
 
 __all__ = ['resquiggle_read', 'resquiggle_batch', 'resquiggle_batch_iters', 'adjust_map_res',
+           'get_read_seq', 'map_read',
            'resquiggle_batch_events', 'batch_de_novo_stats', 'get_engine', 'default_device', 'segment_signal',
            'find_adaptive_base_assignment', 'find_seq_start_in_events',
            'find_static_base_assignment', 'resolve_skipped_bases_with_raw']

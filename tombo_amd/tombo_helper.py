@@ -11,8 +11,14 @@ can switch packages without touching its code:
   dpResults         tombo_helper.py:255      genomeLocation    tombo_helper.py:268
   channelInfo       tombo_helper.py:286      seqSampleType     tombo_helper.py:330
   get_seq_kmers     tombo_helper.py:526
+  sequenceData      tombo_helper.py:277      comp_seq / rev_comp / invalid_seq /
+  rev_transcribe / get_mean_q_score          tombo_helper.py:370-394
+  get_raw_read_slot tombo_helper.py:1071     get_channel_info  tombo_helper.py:2071
 """
+import re
 from collections import namedtuple
+
+import numpy as np
 
 
 class TomboError(Exception):
@@ -54,6 +60,60 @@ channelInfo = namedtuple('channelInfo', (
     'offset', 'range', 'digitisation', 'number', 'sampling_rate'))
 
 seqSampleType = namedtuple('seqSampleType', ('name', 'rev_sig'))
+
+sequenceData = namedtuple('sequenceData', ('seq', 'id', 'mean_q_score'))
+
+PHRED_BASE = 33                      # _default_parameters.py:184
+_COMPLEMENT = str.maketrans('ACGT', 'TGCA')
+_NOT_ACGT = re.compile('[^ACGT]')
+
+
+def comp_seq(seq):
+    """complement of a DNA string (other characters pass through)"""
+    return seq.translate(_COMPLEMENT)
+
+
+def rev_comp(seq):
+    return seq.translate(_COMPLEMENT)[::-1]
+
+
+def invalid_seq(seq):
+    """True when the sequence holds anything but A, C, G, T"""
+    return _NOT_ACGT.search(seq) is not None
+
+
+def rev_transcribe(seq):
+    """RNA basecalls to the DNA alphabet (U -> T)"""
+    return seq.replace('U', 'T')
+
+
+def get_mean_q_score(read_q):
+    """mean Phred score of a FASTQ quality string (np.mean of the per-base integers)"""
+    return np.mean([q - PHRED_BASE for q in read_q.encode('ASCII')])
+
+
+def get_raw_read_slot(fast5_data):
+    """the (single) read group under /Raw/Reads of an open single-read FAST5"""
+    try:
+        return next(iter(fast5_data['/Raw/Reads'].values()))
+    except KeyError:
+        raise TomboError(
+            'Raw data is not found in /Raw/Reads/Read_[read#]. Note that ' +
+            'Tombo does not support multi-fast5 format.')
+
+
+def get_channel_info(fast5_data):
+    try:
+        attrs = fast5_data['UniqueGlobalKey/channel_id'].attrs
+    except KeyError:
+        raise TomboError("No channel_id group in HDF5 file. " +
+                         "Probably mux scan HDF5 file.")
+    try:
+        return channelInfo(attrs.get('offset'), attrs.get('range'), attrs.get('digitisation'),
+                           attrs.get('channel_number'),
+                           attrs.get('sampling_rate').astype(np.int64))
+    except KeyError:
+        raise TomboError("Channel info parameters not available.")
 
 
 def get_seq_kmers(seq, kmer_width, rev_strand=False):
