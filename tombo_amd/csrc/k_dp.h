@@ -930,37 +930,48 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, cons
             stv[k] = st[rc_ - 1];
             win[k] = *(const uint4 *)(mv + rc_ * rowb + 4 * wb);
         }
+        // Per row, off the dependent chain (it only needs the fetched window): one bit per cell
+        // for "not a stay" and "is a diagonal move" in the two 32-cell halves, and the answer for
+        // "everything at or below the position in the upper half was a stay" (the highest
+        // non-stay cell of the lower half).
+        u64 nzl[TBR], nzh[TBR], d2l[TBR], d2h[TBR];
+        int fl_full[TBR], m2_full[TBR];
+#pragma unroll
+        for (int k = 0; k < TBR; k++) {
+            const u64 lo = ((u64)win[k].y << 32) | win[k].x, hi = ((u64)win[k].w << 32) | win[k].z;
+            const u64 E = 0x5555555555555555ull;
+            nzl[k] = (lo | (lo >> 1)) & E; nzh[k] = (hi | (hi >> 1)) & E;
+            d2l[k] = (lo >> 1) & ~lo & E;  d2h[k] = (hi >> 1) & ~hi & E;
+            const int cf = __clzll((long long)(nzl[k] | 1ull)); // (| 1: defined for an empty half)
+            fl_full[k] = nzl[k] ? 31 - (cf >> 1) : -1;
+            m2_full[k] = (int)((d2l[k] >> (2 * (fl_full[k] & 31))) & 1ull);
+        }
 #pragma unroll
         for (int k = 0; k < TBR; k++) {
             const i64 rr = r0 - k;
-            if (rr < 1 || rc != TBA_OK) continue;
+            const bool act = rr >= 1 && rc == TBA_OK;
+            // Fast form, branch-free on the dependent chain (a wavefront of 16 lanes on its own
+            // SIMD pays ~10 cycles per dependent instruction and much more per exec-mask
+            // branch): the position lies in the 64-cell window; the highest non-stay move at or
+            // below it is one shift + count-leading-zeros in its 32-cell half, else the
+            // precomputed answer of the lower half.
             const i64 bp64 = cur_ev - stv[k];
-            int bp = (int)bp64, m = 0;
-            // Fast form, branch-free (a wave of 16 lanes on its own SIMD pays ~10 cycles per
-            // dependent instruction and much more per exec-mask branch): the position lies in
-            // the 64-cell window (4 dwords of 16 two-bit moves); per dword, independently, the
-            // highest non-stay move at or below the position (dwords above it are masked out,
-            // dwords below it count in full), then the highest dword that has one.
+            int bp = (int)bp64;
             const int lc = bp - 16 * wb;                // position inside the window
-            const bool in_win = bp64 < Wi && bp64 >= 0 && lc >= 0 && lc < 64;
-            const int d = lc >> 4, q = lc & 15;
-            const u32 wv[4] = {win[k].x, win[k].y, win[k].z, win[k].w};
-            int fi[4], mi[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 mk = i < d ? 0xffffffffu : (i == d ? (0xffffffffu >> (30 - 2 * q)) : 0u);
-                const u32 x = wv[i] & mk;
-                const u32 nz = (x | (x >> 1)) & 0x55555555u;
-                fi[i] = nz ? (31 - __clz((int)nz)) >> 1 : -1;
-                mi[i] = (int)((wv[i] >> (2 * (fi[i] & 15))) & 3u);
-            }
-            int f = fi[0], mf = mi[0];
-            f = fi[1] >= 0 ? 16 + fi[1] : f;  mf = fi[1] >= 0 ? mi[1] : mf;
-            f = fi[2] >= 0 ? 32 + fi[2] : f;  mf = fi[2] >= 0 ? mi[2] : mf;
-            f = fi[3] >= 0 ? 48 + fi[3] : f;  mf = fi[3] >= 0 ? mi[3] : mf;
-            const bool fast = in_win && f >= 0;
-            if (fast) { bp = 16 * wb + f; m = mf; }
-            if (__builtin_expect(!fast, 0)) {
+            const bool in_win = bp64 < Wi && bp64 >= 0 && (unsigned)lc < 64u;
+            const bool up = (lc & 32) != 0;
+            const int amt = 62 - 2 * (lc & 31);
+            const u64 sn = (up ? nzh[k] : nzl[k]) << amt, s2 = (up ? d2h[k] : d2l[k]) << amt;
+            const bool hit = sn != 0;
+            const int c = __clzll((long long)(sn | 1ull)); // 1 + 2 (lc - f); 63 without a hit
+            const bool low = !hit && up && fl_full[k] >= 0;
+            const int m2_hit = (int)((s2 >> (63 - c)) & 1ull);
+            const int f = hit ? lc - (c >> 1) : fl_full[k];
+            const int m2 = hit ? m2_hit : m2_full[k];
+            const bool fast = in_win && (hit || low);
+            int m = m2 ? 2 : 1;
+            if (fast) bp = 16 * wb + f;
+            if (__builtin_expect(act && !fast, 0)) {
                 // outside the window, or nothing but stays down to its start: the reference's
                 // cell-by-cell walk with direct loads (python wrap-around of a negative index kept)
                 if (bp64 >= Wi || bp64 < -Wi) { rc = TBA_INTERNAL; continue; }
@@ -977,13 +988,16 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, cons
                 if (rc != TBA_OK) continue;
             }
             if (m == 2) bp--;
-            if (thresh >= 0) {
-                const int a = bp, b2 = Wi - bp - 1;
-                if ((a < b2 ? a : b2) < thresh) { rc = TBA_BEYOND_BANDWIDTH; continue; }
+            const int edge = bp < Wi - bp - 1 ? bp : Wi - bp - 1;
+            const bool beyond = thresh >= 0 && edge < thresh;
+            if (act) {
+                if (beyond) rc = TBA_BEYOND_BANDWIDTH;
+                else {
+                    cur_ev = stv[k] + bp;
+                    tb[rr - 1] = cur_ev + 1;
+                    bp_guess = bp;
+                }
             }
-            cur_ev = stv[k] + bp;
-            tb[rr - 1] = cur_ev + 1;
-            bp_guess = bp;
         }
     }
     if (rc != TBA_OK) { r.status = rc; return; }
