@@ -295,7 +295,8 @@ def main():
                     help='end-to-end (host in -> host out) measurement: int16 in / records + '
                          'int32 boundaries out, float64 in / float64 signal + int64 boundaries '
                          'out, or skipped')
-    ap.add_argument('--stream-batch', type=int, default=5000, help='reads per streamed batch')
+    ap.add_argument('--stream-batch', type=int, default=None,
+                    help='reads per streamed batch (default: 10000 compact, 5000 full: its float64 outputs are page-locked per slot)')
     ap.add_argument('--slots', type=int, default=3, help='engine slots per GPU of the streaming pipeline')
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
@@ -465,6 +466,8 @@ def main():
     e2e = None
     if a.e2e != 'none':
         compact = a.e2e == 'compact'
+        if a.stream_batch is None:
+            a.stream_batch = 10000 if compact else 5000
         src = dacs if compact else raws
         src_stalls = stalls_dac if compact else stalls
         if longtail:
@@ -498,7 +501,9 @@ def main():
                            pool[big].seq_off, samp_ind=pool[big].samp_ind, stall_ints=pool[big].stall_ints,
                            stall_off=pool[big].stall_off, wait=True)
         th2d = time.perf_counter() - th2d
-        n_stream = len(pool) * a.steps * world       # batches of the whole job
+        # batches of the whole job: K passes over the pool, but never so few that filling and
+        # draining the slots is most of the measurement
+        n_stream = max(len(pool) * a.steps, 2 * a.slots + 2) * world
         queue = sharding.BatchQueue(n_stream)
         barrier()
         t0 = time.perf_counter()
