@@ -38,15 +38,14 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_normalize(ReadState *rs, const De
     const tba_opts &o = dp->o;
     double shift, scale, lo = 0, hi = 0;
     double xlo = 0, xhi = 0, mn = 0, mx = 0; // middle order statistics / range of the raw signal
-    bool have_lims = false, use_sv = false, have_dev = false;
+    bool have_lims = false, have_dev = false;
     double dlo = 0, dhi = 0; // middle order statistics of |x - shift|
     if (r.sv_flags & 1) {
-        use_sv = true;
         shift = sv_in[4 * blockIdx.x + 0];
         scale = sv_in[4 * blockIdx.x + 1];
         if (r.sv_flags & 2) { have_lims = true; lo = sv_in[4 * blockIdx.x + 2]; hi = sv_in[4 * blockIdx.x + 3]; }
     } else if (mode == 1 && !o.has_const_scale && o.use_rna_event_scale) {
-        use_sv = true; // get_scale_values_from_events result, tombo_stats.py:217-233
+        // get_scale_values_from_events result, tombo_stats.py:217-233
         shift = r.shift; scale = r.scale; have_lims = true; lo = r.lower; hi = r.upper;
     } else {
         // strided sample, kept in registers: range guess for the selects and window steering
