@@ -283,6 +283,23 @@ def test_full_size_reads_vs_oracle_on_gpu():
     assert all(o['status'] == 0 for o in oracles)
 
 
+def test_long_reads_vs_oracle_on_gpu():
+    """Reads well past one 8 192-element summation chunk of np.mean, 16-row traceback blocks by the
+    thousand and several event-detection tiles: 18 kb, 25 kb and 37 kb next to a short one"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=500)
+    reads = []
+    for seed, nb in enumerate((18000, 700, 25000, 37000)):
+        seq, raw, _ = synth.synth_read(model, nb, 88000 + seed, **synth.DNA_SYNTH)
+        reads.append((raw, seq, None, _si(nb, seed)))
+    eng, out, oracles = run_batch(model, params, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'long')
+    assert not bad, '\n'.join(bad[:40])
+    assert all(o['status'] == 0 for o in oracles)
+
+
 def test_default_bandwidth_ragged_batch_on_gpu():
     """BASELINE configs[2] shape: the adaptive path at Tombo's default bandwidth 300, ragged
     lengths"""
