@@ -342,6 +342,26 @@ def test_rna_batch_on_gpu():
     assert sum(o['status'] == 0 for o in oracles) >= 6
 
 
+def test_long_rna_reads_vs_oracle_on_gpu():
+    """RNA reads of 6 and 9 kb (260 k / 390 k samples: dozens of event-detection tiles at radius
+    5, every LDS class of the skipped-base windows, a stall in the longer one)"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('RNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    reads = []
+    for seed, nb in enumerate((6000, 9000, 350)):
+        seq, raw, _ = synth.synth_read(model, nb, 99000 + seed, **synth.RNA_SYNTH)
+        if seed == 1:
+            raw = np.concatenate([raw[:150000], np.full(2000, raw[150000]) +
+                                  np.random.default_rng(2).normal(0, 3.0, 2000), raw[150000:]])
+        reads.append((raw, seq, ts.identify_stalls(raw), _si(nb, seed)))
+    eng, out, oracles = run_batch(model, params, 'RNA', reads)
+    bad = compare_batch(eng, oracles, out, 'rna_long')
+    assert not bad, '\n'.join(bad[:40])
+    assert sum(o['status'] == 0 for o in oracles) >= 2
+
+
 def test_batch_properties_at_scale_on_gpu():
     """size-independent properties on a larger batch (no oracle): monotone boundaries, trimmed
     signal covered exactly, determinism across runs, independence from batch composition"""
