@@ -466,8 +466,8 @@ def main():
     e2e = None
     if a.e2e != 'none':
         compact = a.e2e == 'compact'
-        if a.stream_batch is None:
-            a.stream_batch = 10000 if compact else 5000
+        if a.stream_batch is None:   # (ranks sharing one device -- a rehearsal -- share its memory too)
+            a.stream_batch = 10000 if compact and ndev >= world else 5000
         src = dacs if compact else raws
         src_stalls = stalls_dac if compact else stalls
         if longtail:
