@@ -772,12 +772,55 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
             const double A1 = t1 - t1 * TSW_REL, B2 = t2 + t2 * TSW_REL;
             i64 c_lo = 0;
             const int dtop = dmax + ((nn & 1) ? 0 : 1);
+            auto classify = [&](double a, double b) {
+                if (b == 0) return; // max_slope = 1000: above the window
+                // a / b against the guarded edges without dividing: the sign of b is folded
+                // into a, then a' < A1 |b|  =>  a / b < A1 (1 + 2^-53) < t1
+                const double ab = fabs(b), as = b < 0 ? -a : a;
+                if (as < A1 * ab) { c_lo++; return; }  // safely below the window
+                if (as >= B2 * ab) return;             // safely above
+                // inside, or too close to an edge to tell (NaNs land here too)
+                const u32 pos = atomicAdd(&s_ncand, 1u);
+                if (pos < cap) { double *pr = pair_at(pos); pr[0] = a; pr[1] = b; }
+            };
+            if (!(nn & 1)) {
+                // Even n (the 1000-point sample): the pass is bound by LDS bandwidth (two 8-byte
+                // reads per pair), so a thread keeps TWO points and walks the distances four at
+                // a time: the 8 pairs need 5 partner points instead of 8.  The circle is walked
+                // in the order slot 0, nh, 1, nh + 1, ... (any order of the point set gives every
+                // unordered pair once): thread t holds positions 2t and 2t + 1 = slots t and
+                // nh + t, the partner at position 2t + c sits in slot (c & 1) nh + (t + c / 2)
+                // mod nh -- consecutive threads, consecutive slots.
+                const int nh = nn / 2;
+                const bool okr = tid < nh;
+                const int tc = okr ? tid : 0;
+                const double eA = s_ev[tc], mA = s_md[tc], eB = s_ev[nh + tc], mB = s_md[nh + tc];
+                // the antipodal distance nh only from the first half of the circle
+                const int dlimA = okr ? (2 * tc < nh ? nh : nh - 1) : 0;
+                const int dlimB = okr ? (2 * tc + 1 < nh ? nh : nh - 1) : 0;
+                for (int d0 = 1; d0 <= nh; d0 += 4) {
+                    double ep[5], mp[5];
+#pragma unroll
+                    for (int u = 0; u < 5; u++) {
+                        const int c = d0 + u;
+                        int h = tc + (c >> 1);
+                        h = h >= nh ? h - nh : h;
+                        const int slot = (c & 1) ? nh + h : h;
+                        ep[u] = s_ev[slot]; mp[u] = s_md[slot];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (d0 + u <= dlimA) classify(mA - mp[u], eA - ep[u]);
+                        if (d0 + u <= dlimB) classify(mB - mp[u + 1], eB - ep[u + 1]);
+                    }
+                }
+            } else
             for (int i0 = 0; i0 < nn; i0 += SEL_NT) {
                 const int i = i0 + tid;
                 const bool okr = i < nn;
                 const int ic = okr ? i : 0;
                 const double ei = s_ev[ic], mi = s_md[ic];
-                const int dlim = okr ? ((nn & 1) || i >= nn / 2 ? dmax : dtop) : 0;
+                const int dlim = okr ? dmax : 0;
                 for (int d0 = 1; d0 <= dtop; d0 += 4) {
                     double ej[4], mj[4];
 #pragma unroll
@@ -788,19 +831,8 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
                         ej[u] = s_ev[j]; mj[u] = s_md[j];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (d0 + u > dlim) continue;
-                        const double b = ei - ej[u], a = mi - mj[u];
-                        if (b == 0) continue; // max_slope = 1000: above the window
-                        // a / b against the guarded edges without dividing: the sign of b is
-                        // folded into a, then a' < A1 |b|  =>  a / b < A1 (1 + 2^-53) < t1
-                        const double ab = fabs(b), as = b < 0 ? -a : a;
-                        if (as < A1 * ab) { c_lo++; continue; }  // safely below the window
-                        if (as >= B2 * ab) continue;             // safely above
-                        // inside, or too close to an edge to tell (NaNs land here too)
-                        const u32 pos = atomicAdd(&s_ncand, 1u);
-                        if (pos < cap) { double *pr = pair_at(pos); pr[0] = a; pr[1] = b; }
-                    }
+                    for (int u = 0; u < 4; u++)
+                        if (d0 + u <= dlim) classify(mi - mj[u], ei - ej[u]);
                 }
             }
             c_lo = block_sum_i64(c_lo, &sm.rad);
