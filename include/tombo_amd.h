@@ -89,6 +89,23 @@ typedef struct {
                               caller recomputes it from raw + scale_values, as Tombo does when it
                               reads a resquiggled FAST5 back: tombo_helper.py get_raw_read_slot /
                               tombo_stats.normalize_raw_signal); norm_signal downloads are refused */
+    /* ---- the worker's per-read preparation (_resquiggle_worker.adjust_map_res,
+     * resquiggle.py:1506-1530), on the device, part of the upload / of tba_batch_enqueue ---- */
+    int64_t reverse_raw;   /* the samples arrive in acquisition order (direct RNA: 3'->5') and are
+                              flipped in place once after the upload: raw_signal[::-1], :1516 */
+    int64_t detect_stalls; /* ts.identify_stalls(raw_signal, MEAN_STALL_PARAMS) (tombo_stats.py:
+                              269-368, the running-window-mean method; :1524-1528) over the
+                              (flipped) raw samples; its intervals take the place of stall_ints,
+                              which must then be NULL */
+    int64_t stall_window_size, stall_n_windows, stall_mini_window_size,
+        stall_min_consecutive_obs, stall_edge_buffer; /* th.stallParams, tombo_helper.py:200-214 */
+    double  stall_threshold;
+    int64_t device_subsample; /* draw the Theil-Sen subsample of reads with more than 1000 bases
+                              (np.random.choice(B, 1000, replace=False), tombo_stats.py:411-416)
+                              on the device instead of taking samp_ind: the first 1000 images of
+                              a keyed pseudo-random permutation of [0, B) (counter based: a
+                              function of subsample_seed and the read's index in the batch) */
+    uint64_t subsample_seed;
 } tba_opts;
 
 typedef struct tba_engine tba_engine;
@@ -207,6 +224,12 @@ enum {
     TBA_GET_SEGS = 17,        /* int64, CSR by seg_off: boundaries after skipped-base resolution */
     TBA_GET_STATUS = 18,      /* int32[n] */
     TBA_GET_START_FAIL = 19,  /* int32[n]: status that failed the first start-discovery try (0: none) */
+    TBA_GET_STALL_INTS = 20,  /* int64[][2]: the stall intervals in force (given, or detected under
+                                 tba_opts.detect_stalls), read i at STALL_OFF[i], N_STALL[i] of them */
+    TBA_GET_N_STALL = 21,     /* int64[n] */
+    TBA_GET_STALL_OFF = 22,   /* int64[n] */
+    TBA_GET_SAMP_IND = 23,    /* int64[n][1000]: the Theil-Sen subsamples used (as uploaded, or as
+                                 drawn under tba_opts.device_subsample; reads of <= 1000 bases: unused) */
     TBA_GET_DEBUG_COUNTERS = 99 /* int64[n][8]: ReadState.dbg, only filled by -DTBA_PHASE_DEBUG /
                                    -DTBA_SWEEP_STATS profiling builds (zeros otherwise) */
 };
@@ -354,6 +377,34 @@ int tba_read_pvals(tba_engine *e, const double *means, const double *ref_means,
 int tba_batch_de_novo_stats(tba_engine *e, int64_t fm_offset, double smallest_pval,
                             double *pvals, int64_t n_values);
 
+/* ---- the worker's per-read preparation (row P10) ---------------------------------------------
+ * ts.identify_stalls(all_raw_signal, stall_params) (tombo_stats.py:269-368), running-window-mean
+ * method, for one read in host memory (raw_dtype: TBA_RAW_*): ints[2 i], ints[2 i + 1] = the
+ * i-th (widened, merged) stall interval, *n_ints of them (cap = capacity of ints in intervals;
+ * TBA_E_ARG with *n_ints set when it is too small).  Inside a batch the same kernels run under
+ * tba_opts.detect_stalls. */
+int tba_identify_stalls(tba_engine *e, const void *raw, int raw_dtype, int64_t n,
+    int64_t window_size, int64_t n_windows, int64_t mini_window_size, double threshold,
+    int64_t min_consecutive_obs, int64_t edge_buffer, int64_t *ints, int64_t cap, int64_t *n_ints);
+
+/* Host-side, no GPU involved: pack n_reads per-read sample arrays (raw_ptrs[i], raw_off[i+1] -
+ * raw_off[i] samples of type raw_dtype; reverse != 0: copied back to front) and sequences
+ * (seq_ptrs[i]: ASCII A/C/G/T, seq_off[i+1] - seq_off[i] letters, stored as codes 0..3, anything
+ * else as 255 -> TBA_INVALID_SEQ) into the CSR buffers tba_batch_upload_async takes, with
+ * n_threads threads.  This is the reader of the reference's worker pool (resquiggle.py:1385-1486)
+ * for callers that hold one array per read. */
+int tba_pack_reads(int64_t n_reads, const void *const *raw_ptrs, int raw_dtype, int reverse,
+    const int64_t *raw_off, void *raw_out, const char *const *seq_ptrs, const int64_t *seq_off,
+    uint8_t *seq_out, int n_threads);
+
+/* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build: lets a
+ * binding without a C compiler (ctypes) check its struct mirrors */
+int tba_abi_sizes(int64_t *out, int64_t n);
+
+/* self-test: out[t] = index t of the subsample tba_opts.device_subsample draws for read
+ * `read_index` of a batch under `seed`, for a read of n bases (t < count <= n) */
+int tba_selftest_subsample(tba_engine *e, int64_t n, uint64_t seed, int64_t read_index,
+                           int64_t count, int64_t *out);
 /* self-test: out[i] = the row-constant division used inside the DP kernel (reciprocal + two
  * residual corrections) for a[i] / b[i]; must equal the IEEE quotient bit for bit */
 int tba_selftest_division(tba_engine *e, const double *a, const double *b, int64_t n,

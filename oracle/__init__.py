@@ -309,3 +309,57 @@ def calc_scaled_llh_ratio_const_var(means, ref_means, alt_means, const_var, scal
     return float(lib().orc_calc_scaled_llh_ratio_const_var(
         *[_p(x) for x in a], i64(a[0].shape[0]), f64(const_var), f64(scale_factor),
         f64(density_height_factor), f64(density_height_power)))
+
+
+def identify_stalls(all_raw_signal, stall_params=None):
+    """numpy restatement of ts.identify_stalls, running-window-mean method (tombo/tombo_stats.py:
+    269-368) -- the checker of csrc/k_prep_raw.h.  Pinned: the `stall_ints` of
+    the RNA fixtures in tests/golden were recorded from the live reference.
+
+    7 offsets of a 50-sample moving average; metric = (sum of the 21 pairwise absolute
+    differences + the first one once more) / 21, centred at window_size//2; runs of
+    metric <= threshold longer than min_consecutive_obs, widened and merged.
+    """
+    from tombo_amd import tombo_helper as th
+    from tombo_amd._default_parameters import STALL_PARAMS
+    sp = th.stallParams(**STALL_PARAMS) if stall_params is None else stall_params
+    x = np.asarray(all_raw_signal)
+    n = x.shape[0]
+    if n < sp.window_size:
+        return []
+    mw, nw = sp.mini_window_size, sp.n_windows
+    assert sp.window_size == mw * nw
+    csum = np.cumsum(x)
+    csum[mw:] = csum[mw:] - csum[:-mw]
+    mov = csum[mw - 1:] / mw
+    n_pos = n - sp.window_size + 1
+    offs = [mov[mw * k: mw * k + n_pos] for k in range(nw)]
+    diffs = [np.abs(offs[i] - offs[j]) for i in range(nw) for j in range(i + 1, nw)]
+    acc = diffs[0].copy()
+    for d in diffs:
+        acc += d
+    metric = np.full(n, np.nan)
+    start_offset = int(sp.window_size * 0.5)
+    metric[start_offset:start_offset + n_pos] = acc / len(diffs)
+    with np.errstate(invalid='ignore'):
+        below = metric <= sp.threshold
+    edges = np.where(np.diff(np.concatenate([[False], below])))[0]
+    if below[-1]:
+        edges = np.concatenate([edges, [n]])
+    ivals = edges.reshape(-1, 2)
+    ivals = ivals[(ivals[:, 1] - ivals[:, 0]) > sp.min_consecutive_obs]
+    if ivals.shape[0] == 0:
+        return []
+    expand = (sp.window_size // 2) - sp.edge_buffer
+    if expand <= 0:
+        return ivals
+    ivals = ivals.copy()
+    ivals[:, 0] -= expand
+    ivals[:, 1] += expand
+    merged = [ivals[0].copy()]
+    for cur in ivals:
+        if cur[0] > merged[-1][1]:
+            merged.append(cur.copy())
+        else:
+            merged[-1][1] = cur[1]
+    return merged

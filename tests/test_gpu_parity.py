@@ -9,6 +9,8 @@ separately.
 import numpy as np
 import pytest
 
+import oracle
+
 from conftest import golden_names
 
 pytestmark = pytest.mark.gpu
@@ -334,7 +336,7 @@ def test_rna_batch_on_gpu():
         if seed == 4:  # a stalled stretch in the middle of the read
             raw = np.concatenate([raw[:40000], np.full(1500, raw[40000]) +
                                   np.random.default_rng(1).normal(0, 3.0, 1500), raw[40000:]])
-        reads.append((raw, seq, ts.identify_stalls(raw), _si(nb, seed)))
+        reads.append((raw, seq, oracle.identify_stalls(raw), _si(nb, seed)))
     assert any(len(r[2]) for r in reads), 'no stall interval exercised'
     eng, out, oracles = run_batch(model, params, 'RNA', reads)
     bad = compare_batch(eng, oracles, out, 'rna')
@@ -355,7 +357,7 @@ def test_long_rna_reads_vs_oracle_on_gpu():
         if seed == 1:
             raw = np.concatenate([raw[:150000], np.full(2000, raw[150000]) +
                                   np.random.default_rng(2).normal(0, 3.0, 2000), raw[150000:]])
-        reads.append((raw, seq, ts.identify_stalls(raw), _si(nb, seed)))
+        reads.append((raw, seq, oracle.identify_stalls(raw), _si(nb, seed)))
     eng, out, oracles = run_batch(model, params, 'RNA', reads)
     bad = compare_batch(eng, oracles, out, 'rna_long')
     assert not bad, '\n'.join(bad[:40])

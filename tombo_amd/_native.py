@@ -50,7 +50,12 @@ class Opts(C.Structure):
                 ('check_start_score', i64), ('sig_match_thresh', f64),
                 ('max_raw_cpts', i64), ('min_event_to_seq_ratio', f64),
                 ('use_rna_event_scale', i64), ('rna_scale_num_events', i64),
-                ('rna_scale_max_frac_events', f64), ('skip_norm_out', i64)]
+                ('rna_scale_max_frac_events', f64), ('skip_norm_out', i64),
+                ('reverse_raw', i64), ('detect_stalls', i64),
+                ('stall_window_size', i64), ('stall_n_windows', i64),
+                ('stall_mini_window_size', i64), ('stall_min_consecutive_obs', i64),
+                ('stall_edge_buffer', i64), ('stall_threshold', f64),
+                ('device_subsample', i64), ('subsample_seed', C.c_uint64)]
 
 
 class ReadResult(C.Structure):
@@ -76,7 +81,8 @@ RAW_DTYPES = {np.dtype(np.float64): RAW_F64, np.dtype(np.float32): RAW_F32,
 # TBA_GET_* selectors
 GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START, \
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
-    GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL = range(1, 20)
+    GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL, \
+    GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND = range(1, 24)
 GET_DEBUG_COUNTERS = 99  # ReadState.dbg of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS profiling build
 STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, STAGE_SKIP, \
     STAGE_RESCALE = range(7)
@@ -85,7 +91,7 @@ PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SE
 MAX_BAND = 3072
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
-               "rescale_score", "rna_scale", "total"]
+               "rescale_score", "stalls", "total"]
 
 _lib = None
 
@@ -122,8 +128,25 @@ def make_params(rp):
 
 def make_opts(outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
               sig_match_thresh=None, max_raw_cpts=200, min_event_to_seq_ratio=1.1,
-              skip_norm_out=False):
+              skip_norm_out=False, reverse_raw=False, stall_params=None, subsample_seed=None):
+    """tba_opts.  `reverse_raw` / `stall_params` (a th.stallParams of the running-window-mean
+    method): the worker's RNA preparation on the device (resquiggle.py:1506-1530);
+    `subsample_seed` (int): the Theil-Sen subsample is drawn on the device."""
     o = Opts()
+    o.reverse_raw = int(bool(reverse_raw))
+    if stall_params is not None:
+        sp = stall_params
+        if sp.n_windows is None or sp.mini_window_size is None or \
+                getattr(sp, 'lower_pctl', None) is not None:
+            raise NotImplementedError('only the running-window-mean stall detector '
+                                      '(MEAN_STALL_PARAMS, the reference default) is on the device')
+        o.detect_stalls = 1
+        o.stall_window_size, o.stall_n_windows = int(sp.window_size), int(sp.n_windows)
+        o.stall_mini_window_size = int(sp.mini_window_size)
+        o.stall_min_consecutive_obs, o.stall_edge_buffer = int(sp.min_consecutive_obs), int(sp.edge_buffer)
+        o.stall_threshold = float(sp.threshold)
+    if subsample_seed is not None:
+        o.device_subsample, o.subsample_seed = 1, int(subsample_seed) & 0xffffffffffffffff
     o.has_outlier_thresh = int(outlier_thresh is not None)
     o.outlier_thresh = 0.0 if outlier_thresh is None else float(outlier_thresh)
     o.has_const_scale = int(const_scale is not None)
@@ -374,6 +397,8 @@ class Engine(object):
             GET_REF_MEANS: (np.float64, int(self.ref_off[-1])),
             GET_REF_SDS: (np.float64, int(self.ref_off[-1])),
             GET_STATUS: (np.int32, n), GET_START_FAIL: (np.int32, n),
+            GET_N_STALL: (np.int64, n), GET_STALL_OFF: (np.int64, n),
+            GET_SAMP_IND: (np.int64, (n, 1000)),
         }
         if what in (GET_VALID_CPTS, GET_EVENT_MEANS):
             out = np.zeros(max(int(self.ev_off[-1]), 1),
@@ -386,6 +411,17 @@ class Engine(object):
         self._check(self._L.tba_batch_get(self._h, C.c_int(what), out.ctypes.data_as(C.c_void_p),
                                           i64(out.nbytes)), 'tba_batch_get')
         return out
+
+    def stall_ints(self):
+        """per read the stall intervals in force ([k, 2] int64; given, or detected on the device)"""
+        cnt, off = self.get(GET_N_STALL), self.get(GET_STALL_OFF)
+        if not cnt.any():
+            return [np.zeros((0, 2), np.int64) for _ in range(self.n)]
+        flat = np.zeros((int((off + cnt).max()), 2), np.int64)
+        self._check(self._L.tba_batch_get(self._h, C.c_int(GET_STALL_INTS),
+                                          flat.ctypes.data_as(C.c_void_p), i64(flat.nbytes)),
+                    'tba_batch_get')
+        return [flat[int(o):int(o) + int(c)].copy() for o, c in zip(off, cnt)]
 
     def run_stages(self, first, last):
         self._check(self._L.tba_batch_run_stages(self._h, C.c_int(first), C.c_int(last)),
@@ -426,3 +462,59 @@ class Engine(object):
         a, c = f64(0), f64(0)
         self._check(self._L.tba_batch_stats(self._h, C.byref(a), C.byref(c)), 'tba_batch_stats')
         return a.value, c.value
+
+
+def identify_stalls(eng, raw, sp):
+    """tba_identify_stalls: ts.identify_stalls (running-window-mean method) of one read on the
+    device; returns an int64 [k, 2] array"""
+    raw = np.asarray(raw)
+    if raw.dtype not in RAW_DTYPES or not raw.flags.c_contiguous:
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+    n = raw.shape[0]
+    cap = n // (int(sp.min_consecutive_obs) + 1) + 2
+    out = np.zeros((cap, 2), np.int64)
+    cnt = i64(0)
+    if n == 0:
+        return out[:0]
+    eng._check(eng._L.tba_identify_stalls(
+        eng._h, raw.ctypes.data_as(C.c_void_p), C.c_int(RAW_DTYPES[raw.dtype]), i64(n),
+        i64(int(sp.window_size)), i64(int(sp.n_windows)), i64(int(sp.mini_window_size)),
+        f64(float(sp.threshold)), i64(int(sp.min_consecutive_obs)), i64(int(sp.edge_buffer)),
+        _p(out, i64), i64(cap), C.byref(cnt)), 'tba_identify_stalls')
+    return out[:cnt.value]
+
+
+def pack_reads(raws, seqs, reverse=False, pinned=False, n_threads=None):
+    """tba_pack_reads: per-read sample arrays (one dtype of RAW_DTYPES, else float64) and
+    sequences (str / bytes of ACGT) -> (raw, raw_off, seq, seq_off, keep) CSR arrays, copied by
+    native threads; `pinned`: the big arrays live in page-locked memory (keep them referenced
+    through `keep`)."""
+    L = lib()
+    n = len(raws)
+    raws = [np.asarray(r) for r in raws]
+    dts = set(r.dtype for r in raws)
+    dt = next(iter(dts)) if len(dts) == 1 and next(iter(dts)) in RAW_DTYPES else np.dtype(np.float64)
+    raws = [r if r.dtype == dt and r.flags.c_contiguous else np.ascontiguousarray(r, dtype=dt)
+            for r in raws]
+    seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    raw_off = np.zeros(n + 1, np.int64)
+    np.cumsum([r.shape[0] for r in raws], out=raw_off[1:])
+    seq_off = np.zeros(n + 1, np.int64)
+    np.cumsum([len(s) for s in seqs], out=seq_off[1:])
+    keep = []
+    if pinned:
+        pr, ps = PinnedArray(int(raw_off[-1]), dt), PinnedArray(int(seq_off[-1]), np.uint8)
+        keep = [pr, ps]
+        raw, seq = pr.a, ps.a
+    else:
+        raw, seq = np.empty(int(raw_off[-1]), dt), np.empty(int(seq_off[-1]), np.uint8)
+    rp = (C.c_void_p * n)(*[r.ctypes.data for r in raws])
+    sp = (C.c_char_p * n)(*seqs)
+    if n_threads is None:
+        n_threads = min(16, os.cpu_count() or 1)
+    rc = L.tba_pack_reads(i64(n), rp, C.c_int(RAW_DTYPES[dt]), C.c_int(int(bool(reverse))),
+                          _p(raw_off, i64), raw.ctypes.data_as(C.c_void_p), sp, _p(seq_off, i64),
+                          seq.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(int(n_threads)))
+    if rc != 0:
+        raise EngineError('tba_pack_reads failed (%d): %s' % (rc, L.tba_last_error().decode()))
+    return raw, raw_off, seq, seq_off, keep

@@ -1,0 +1,205 @@
+// k_prep_raw.h -- the worker's per-read preparation on the device:
+//   _resquiggle_worker.adjust_map_res   tombo/resquiggle.py:1506-1530  (RNA flip, stall detection)
+//   ts.identify_stalls, mean-window     tombo/tombo_stats.py:269-368
+// The cumulative sum under the stall metric is k_cumsum_scores<.., RT, 1> (k_segment.h): its
+// left-to-right float64 order is part of the metric's bits for float input (int16 DAC sums are
+// exact in any order and take the same kernel).
+#pragma once
+#include "tba_common.h"
+
+// raw_signal[::-1] in place (resquiggle.py:1516).  grid: (blocks, reads)
+template <class RT>
+__global__ __launch_bounds__(256) void k_reverse_raw(const ReadState *rs, RT *raw)
+{
+    const ReadState &r = rs[blockIdx.y];
+    RT *x = raw + r.raw_off;
+    const i64 n = r.n_raw, half = n / 2;
+    for (i64 i0 = (i64)blockIdx.x * 1024 + threadIdx.x; i0 < half; i0 += (i64)gridDim.x * 1024) {
+        RT a[4], b[4]; // all eight loads first
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const i64 i = i0 + u * 256;
+            if (i < half) { a[u] = x[i]; b[u] = x[n - 1 - i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const i64 i = i0 + u * 256;
+            if (i < half) { x[i] = b[u]; x[n - 1 - i] = a[u]; }
+        }
+    }
+}
+
+// bit array of one read inside a shared word buffer: read i owns [raw_off / 64 + i, ... + n_raw / 64]
+__device__ __forceinline__ i64 stall_word_base(const ReadState &r, i64 read_index) { return (r.raw_off >> 6) + read_index; }
+
+// compute_running_mean_diffs (tombo_stats.py:273-301) + the threshold test (:332-334), one lane
+// per position of the metric array, 64 positions = one ballot word of "metric <= threshold".
+//   c[k] = sum of the first k samples (csum + raw_off + read index, n_raw + 1 entries)
+//   moving_average[j] = (c[j + mw] - c[j]) / mw                      (:277-283; j = 0: c[mw] - 0)
+//   offsets[k][p] = moving_average[mw k + p], p < n - ws + 1          (:286-292)
+//   diff_sums = diffs[0].copy(); for d in diffs: diff_sums += d       (:298-300: diffs[0] twice)
+//   metric[ws // 2 ... + p] = diff_sums / len(diffs), NaN elsewhere   (:312-327)
+// The two divisions have loop-invariant divisors: div_by_recip (tba_common.h) is IEEE division.
+// NW > 0: n_windows as a compile-time constant (7 = MEAN_STALL_PARAMS), else <= 16 at run time.
+template <int NW>
+__global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const DevParams *dp,
+    const double *csum, u64 *bits)
+{
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const tba_opts &o = dp->o;
+    const i64 n = r.n_raw, ws = o.stall_window_size, mw = o.stall_mini_window_size;
+    const int nw = NW > 0 ? NW : (int)o.stall_n_windows;
+    const i64 n_words = (n + 63) >> 6;
+    u64 *bw = bits + stall_word_base(r, blockIdx.y);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 n_pos = n - ws + 1;              // <= 0: read shorter than the window, no metric
+    const i64 start_offset = (i64)((double)ws * 0.5);
+    const double *c = csum + r.raw_off + blockIdx.y;
+    const double dmw = (double)mw, rmw = 1.0 / dmw;
+    const double dnd = (double)(nw * (nw - 1) / 2), rnd = 1.0 / dnd;
+    const double thr = o.stall_threshold;
+    for (i64 w = (i64)blockIdx.x * 4 + wave; w < n_words; w += (i64)gridDim.x * 4) {
+        const i64 q = (w << 6) + lane, p = q - start_offset;
+        const bool valid = p >= 0 && p < n_pos;
+        bool below = false;
+        if (valid) {
+            double m[NW > 0 ? NW : 16];
+            double prev = c[p];
+#pragma unroll
+            for (int k = 0; k < (NW > 0 ? NW : 16); k++) {
+                if (NW > 0 || k < nw) {
+                    const double nxt = c[p + mw * (k + 1)];
+                    m[k] = div_by_recip(nxt - prev, dmw, rmw);
+                    prev = nxt;
+                }
+            }
+            double acc = fabs(m[0] - m[1]); // diffs[0].copy()
+#pragma unroll
+            for (int i = 0; i < (NW > 0 ? NW : 16); i++)
+#pragma unroll
+                for (int j = i + 1; j < (NW > 0 ? NW : 16); j++)
+                    if (NW > 0 || j < nw) acc = acc + fabs(m[i] - m[j]);
+            below = div_by_recip(acc, dnd, rnd) <= thr;
+        }
+        const u64 word = __ballot(below);
+        if (lane == 0) bw[w] = word;
+    }
+}
+
+// Runs of "below" longer than min_consecutive_obs (tombo_stats.py:332-340): one thread per word
+// finds the runs that START in it and follows each to its end (almost all runs die within a few
+// words; a real stall is followed to its end by one thread).  Qualifying runs are appended to the
+// read's slice of `ints` in arrival order (k_stall_merge sorts them).
+__global__ __launch_bounds__(256) void k_stall_runs(ReadState *rs, const DevParams *dp, const u64 *bits,
+    i64 *ints)
+{
+    ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const i64 n = r.n_raw, n_words = (n + 63) >> 6, min_obs = dp->o.stall_min_consecutive_obs;
+    const i64 cap = n / (min_obs + 1) + 2;
+    const u64 *bw = bits + stall_word_base(r, blockIdx.y);
+    i64 *out = ints + 2 * r.stall_off;
+    for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < n_words; t += (i64)gridDim.x * 256) {
+        const u64 w = bw[t];
+        if (w == 0) continue;
+        const u64 prevbit = t > 0 ? bw[t - 1] >> 63 : 0;
+        u64 starts = w & ~((w << 1) | prevbit);
+        while (starts) {
+            const int b = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            const i64 s = (t << 6) + b;
+            const u64 z = b == 63 ? 0 : (~w & (~0ull << (b + 1)));
+            i64 e;
+            if (z) e = (t << 6) + __builtin_ctzll(z);
+            else {
+                i64 tw = t + 1;
+                while (tw < n_words && bw[tw] == ~0ull) tw++;
+                e = tw < n_words ? (tw << 6) + __builtin_ctzll(~bw[tw]) : n;
+            }
+            if (e - s > min_obs) {
+                const i64 slot = (i64)atomicAdd((unsigned long long *)&r.n_stall, 1ull);
+                if (slot < cap) { out[2 * slot] = s; out[2 * slot + 1] = e; }
+            }
+        }
+    }
+}
+
+// The tail of identify_stalls (tombo_stats.py:346-364): intervals in position order, widened by
+// window_size // 2 - edge_buffer on both sides and merged where they then overlap.  One thread per
+// read (a read has a handful of stalls).
+__global__ __launch_bounds__(64) void k_stall_merge(ReadState *rs, i64 n_reads, const DevParams *dp,
+    i64 *ints)
+{
+    const i64 ri = (i64)blockIdx.x * 64 + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK || r.n_stall == 0) return;
+    const tba_opts &o = dp->o;
+    const i64 cap = r.n_raw / (o.stall_min_consecutive_obs + 1) + 2;
+    i64 n = r.n_stall;
+    if (n > cap) { r.status = TBA_INTERNAL; r.n_stall = 0; return; } // (cannot happen: see cap)
+    i64 *v = ints + 2 * r.stall_off;
+    for (i64 i = 1; i < n; i++) { // insertion sort by start
+        const i64 s = v[2 * i], e = v[2 * i + 1];
+        i64 j = i;
+        while (j > 0 && v[2 * (j - 1)] > s) { v[2 * j] = v[2 * (j - 1)]; v[2 * j + 1] = v[2 * (j - 1) + 1]; j--; }
+        v[2 * j] = s; v[2 * j + 1] = e;
+    }
+    const i64 ex = o.stall_window_size / 2 - o.stall_edge_buffer;
+    if (ex > 0) {
+        i64 m = 0; // merged intervals so far - 1
+        v[0] -= ex; v[1] += ex;
+        for (i64 i = 1; i < n; i++) {
+            const i64 s = v[2 * i] - ex, e = v[2 * i + 1] + ex;
+            if (s > v[2 * m + 1]) { m++; v[2 * m] = s; v[2 * m + 1] = e; }
+            else v[2 * m + 1] = e;
+        }
+        n = m + 1;
+    }
+    r.n_stall = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-side Theil-Sen subsample (tba_opts.device_subsample): index t of the subsample is the
+// image of t under a keyed pseudo-random permutation of [0, n) -- a 6-round Feistel network over
+// the 2 * hb >= log2(n) bits, cycle-walked into the range.  The first 1000 images of a random
+// permutation are a uniform draw without replacement, which is what np.random.choice(n, 1000,
+// replace=False) (tombo_stats.py:411-416) is; every index is computed independently (counter
+// based: no state, any thread order).
+__device__ __forceinline__ u32 mix32(u32 h)
+{
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ u64 splitmix64(u64 x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ u64 subsample_key(u64 seed, i64 read_index)
+{
+    return splitmix64(seed ^ splitmix64((u64)read_index + 1));
+}
+__device__ inline i64 keyed_perm(i64 t, i64 n, u64 key)
+{
+    if (n <= 1) return 0;
+    const int bits = 64 - __builtin_clzll((u64)(n - 1));
+    const int hb = (bits + 1) >> 1;
+    const u32 mask = hb >= 32 ? 0xffffffffu : ((1u << hb) - 1u);
+    const u32 k0 = (u32)key, k1 = (u32)(key >> 32);
+    u64 x = (u64)t;
+    do {
+        u32 L = (u32)(x >> hb) & mask, R = (u32)x & mask;
+#pragma unroll
+        for (int rd = 0; rd < 6; rd++) {
+            const u32 f = mix32((R ^ ((rd & 1) ? k1 : k0)) + (u32)rd * 0x9e3779b9u);
+            const u32 nr = L ^ (f & mask);
+            L = R; R = nr;
+        }
+        x = ((u64)L << hb) | R;
+    } while (x >= (u64)n);
+    return (i64)x;
+}

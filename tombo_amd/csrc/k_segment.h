@@ -249,14 +249,17 @@ __host__ inline int cs_reads_for(i64 n_reads)
     const i64 r32 = (n_reads + 8191) / 8192, r20 = (n_reads + 10239) / 10240;
     return r20 < r32 ? 20 : 32;
 }
-template <int CS_READS>
+// MODE 1 (identify_stalls, tombo_stats.py:277: np.cumsum(all_raw_signal)): the same pipeline over
+// the RAW samples (any boundary type, widened exactly), and what the store step writes is the
+// cumulative sum itself: score[raw_off + read + k] = sum of the first k samples, k = 0..n_raw.
+template <int CS_READS, class RT = double, int MODE = 0>
 __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 n_reads,
-    const DevParams *dp, const double *__restrict__ norm, double *__restrict__ score)
+    const DevParams *dp, const RT *__restrict__ norm, double *__restrict__ score)
 {
     // half rows per loader wave: 3 x CS_UNITS >= 2 x CS_READS, even so halves pair up
     constexpr int CS_UNITS = (((2 * CS_READS + 2) / 3) + 1) & ~1;
     __shared__ double tile[3][CS_READS * CS_STRIDE];
-    __shared__ double halo[CS_READS * 64]; // row q: the 2w sums before the tile being stored
+    __shared__ double halo[MODE == 0 ? CS_READS * 64 : 1]; // row q: the 2w sums before the tile being stored
     __shared__ i64 s_off[CS_READS], s_n[CS_READS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 r0 = (i64)blockIdx.x * CS_READS;
@@ -266,8 +269,10 @@ __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 
         const bool live = ri < n_reads && rs[ri].status == TBA_OK;
         s_off[tid] = live ? rs[ri].raw_off : 0;
         s_n[tid] = live ? rs[ri].n_raw : 0;
+        if (MODE == 1 && live) score[rs[ri].raw_off + ri] = 0.0; // c[0]
     }
-    for (int k = tid; k < CS_READS * 64; k += 256) halo[k] = 0.0; // c[0] = 0, nothing before it
+    if (MODE == 0)
+        for (int k = tid; k < CS_READS * 64; k += 256) halo[k] = 0.0; // c[0] = 0, nothing before it
     __syncthreads();
     i64 n_max = 0;
     for (int q = 0; q < CS_READS; q++) n_max = s_n[q] > n_max ? s_n[q] : n_max;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 
 #pragma unroll
         for (int u = 0; u < CS_UNITS; u++) {
             const i64 k = chunk * CS_CHUNK + ucol[u];
-            pre[u] = k < un[u] ? norm[uoff[u] + k] : 0.0;
+            pre[u] = k < un[u] ? (double)norm[uoff[u] + k] : 0.0;
         }
     };
     auto drop = [&](double *t) {
@@ -321,7 +326,22 @@ __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 
         } else {
             if (i + 1 < n_steps) drop(tile[(i + 1) % 3]);
             if (i + 2 < n_steps) fetch(i + 2);
-            if (i >= 1) {
+            if (MODE == 1 && i >= 1) { // the sums of tile i - 1 go out as they are
+                const double *t = tile[(i - 1) % 3];
+                double cc[CS_UNITS];
+#pragma unroll
+                for (int u = 0; u < CS_UNITS; u++) {
+                    const int x = (wave - 1) * CS_UNITS + u, q = x < 2 * CS_READS ? x >> 1 : 0;
+                    cc[u] = t[q * CS_STRIDE + ucol[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < CS_UNITS; u++) {
+                    const int x = (wave - 1) * CS_UNITS + u, q = x < 2 * CS_READS ? x >> 1 : 0;
+                    const i64 k = (i - 1) * CS_CHUNK + ucol[u]; // sample index; c index k + 1
+                    if (k < un[u]) score[uoff[u] + (r0 + q) + 1 + k] = cc[u];
+                }
+            }
+            if (MODE == 0 && i >= 1) {
                 // tile j = i - 1 holds c[jC + 1 .. jC + C] (column t <-> c index jC + 1 + t);
                 // halo row q holds c[jC + 1 - 2w .. jC].  Column t closes the window of position
                 // k = jC + 1 + t - 2w: score[k] = |2 c[k + w] - c[k] - c[k + 2w]| (pyx:94-98)

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
 // sums its base's samples in order and divides once -- a read of 10 000 bases touches a tenth of
 // its signal instead of all of it (the separate k_base_means pass of round 1: 2.7 ms, RNA 9 ms).
 __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const DevParams *dp,
-    const double *norm, const i64 *segs, const double *ref_means, const i64 *samp_ind, double *scratch,
+    const double *norm, const i64 *segs, const double *ref_means, i64 *samp_ind, double *scratch,
     double *scratch2)
 {
     __shared__ BucketSmem sm;
@@ -631,11 +631,16 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
     i64 n = r.B;
     if (n > MAX_TS_POINTS) {
         if (samp_ind == nullptr) { if (tid == 0) r.status = TBA_INTERNAL; return; }
-        const i64 *si = samp_ind + (i64)blockIdx.x * MAX_TS_POINTS;
+        i64 *si = samp_ind + (i64)blockIdx.x * MAX_TS_POINTS;
         n = MAX_TS_POINTS;
         bool bad = false;
+        // tba_opts.device_subsample: the indices are drawn here (k_prep_raw.h) and left in samp_ind
+        const bool draw = dp->o.device_subsample != 0;
+        const u64 key = subsample_key(dp->o.subsample_seed, blockIdx.x);
         for (i64 i = tid; i < n; i += SEL_NT) {
-            i64 k = si[i];
+            i64 k;
+            if (draw) { k = keyed_perm(i, r.B, key); si[i] = k; }
+            else k = si[i];
             if (k < 0 || k >= r.B) { bad = true; k = 0; }
             s_ev[i] = base_mean(k); s_md[i] = mu[k];
         }

@@ -4,6 +4,7 @@
 #include "tba_common.h"
 #include "k_select.h"
 #include "k_segment.h"
+#include "k_prep_raw.h"
 #include "k_dp.h"
 #include "k_tail.h"
 #include "k_cabi.h"
@@ -63,7 +64,7 @@ enum { N_STAGE = 16 };
 static const char *STAGE_NAMES[N_STAGE] = {
     "normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels", "start_dp",
     "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen", "rescale_score",
-    "rna_scale", "total"};
+    "stalls", "total"};
 
 #define WIDE_BLOCKS 64 // workgroups of k_dp_wide (each owns two scratch rows)
 #define TB_LANES 16    // reads per wavefront of the latency-bound lane-per-read kernels
@@ -87,7 +88,7 @@ struct tba_engine {
     bool finished = false; // the last stage (rescale + score) has run on the uploaded batch
     DevParams hp;
     i64 n_reads = 0, S_tot = 0, seq_tot = 0, B_tot = 0, E_tot = 0, max_raw = 0, max_B = 0;
-    i64 start_moves_stride = 0, moves_arena = 0, skip_arena = 0, wide_w = 0;
+    i64 start_moves_stride = 0, moves_arena = 0, skip_arena = 0, wide_w = 0, n_stall_cap = 0;
     bool any_stall = false, have_samp = false, have_sv = false;
     std::vector<i64> ne_override; // per-read num_events for the next upload (stepwise API)
     double algo_bytes = 0, dp_cells = 0;
@@ -198,6 +199,14 @@ extern "C" int tba_pinned_free(void *p)
     return 0;
 }
 
+// launch a kernel template instantiated for the batch's raw sample type
+#define RAW_DISPATCH(dt_, call_)                                                               \
+    do {                                                                                       \
+        if ((dt_) == TBA_RAW_I16) { typedef int16_t RT; call_; }                               \
+        else if ((dt_) == TBA_RAW_F32) { typedef float RT; call_; }                            \
+        else { typedef double RT; call_; }                                                     \
+    } while (0)
+
 // ---- batch sizing -----------------------------------------------------------------------------
 // Everything the device buffers of a batch depend on, from the per-read lengths alone (shared by
 // tba_batch_upload_async and tba_batch_footprint).
@@ -219,7 +228,7 @@ static int plan_batch(const tba_params *p, const tba_opts *o, i64 K, i64 n, cons
     const int cpl_main = cpl_class(p->bandwidth);
     if (cpl_class(p->start_bw) == 0 || cpl_class(p->start_save_bw) == 0 || cpl_main == 0)
         return set_err(TBA_E_ARG, "bandwidth / start bandwidth above TBA_MAX_BAND");
-    i64 ref_acc = 0, ev_acc = 0, raw_acc = 0, seq_acc = 0;
+    i64 ref_acc = 0, ev_acc = 0, raw_acc = 0, seq_acc = 0, stall_acc = 0;
     for (i64 i = 0; i < n; i++) {
         const i64 n_raw = raw_off ? raw_off[i + 1] - raw_off[i] : n_raw_arr[i];
         const i64 seq_len = seq_off ? seq_off[i + 1] - seq_off[i] : seq_len_arr[i];
@@ -238,6 +247,10 @@ static int plan_batch(const tba_params *p, const tba_opts *o, i64 K, i64 n, cons
         r.status = TBA_OK;
         r.sv_flags = sv_flags ? sv_flags[i] : 0;
         if (stall_off) { r.stall_off = stall_off[i]; r.n_stall = stall_off[i + 1] - stall_off[i]; }
+        else if (o->detect_stalls) { // capacity of k_stall_runs: a run is longer than min_consecutive_obs
+            r.stall_off = stall_acc;
+            stall_acc += (n_raw > 0 ? n_raw : 0) / (o->stall_min_consecutive_obs + 1) + 2;
+        }
         if (B <= 0 || n_raw <= 0) {
             r.status = n_raw <= 0 ? TBA_NO_RAW : TBA_INTERNAL;
             continue;
@@ -275,7 +288,7 @@ static int plan_batch(const tba_params *p, const tba_opts *o, i64 K, i64 n, cons
     // raw-DP scratch arena (8-byte units): windows are a few bases x tens of samples; reads that
     // do not fit the arena get TBA_UNSUPPORTED
     z.skip_arena = n * 32768 + (32ll << 20);
-    z.n_stall = stall_off ? stall_off[n] : 0;
+    z.n_stall = stall_off ? stall_off[n] : stall_acc;
     return 0;
 }
 
@@ -295,7 +308,7 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     if (!o->skip_norm_out) BUF(d_norm_out, S * 8);
     BUF(d_csum, (S + N) * 8);
     BUF(d_score, S * 8);
-    BUF(d_state, S);
+    BUF(d_state, std::max(S, S / 8 + 8 * N + 64)); // (also the stall detector's bit words)
     BUF(d_cpts, Et * 8);
     BUF(d_evm, Et * 8);
     BUF(d_seq, (size_t)std::max<i64>(z.seq_tot, 1));
@@ -369,6 +382,14 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
         if (raw_off[i + 1] < raw_off[i] || seq_off[i + 1] < seq_off[i])
             return set_err(TBA_E_ARG, "offset arrays must be non-decreasing");
     const bool stalls = stall_ints && stall_off;
+    if (o->detect_stalls) {
+        if (stalls) return set_err(TBA_E_ARG, "stall_ints given together with tba_opts.detect_stalls");
+        // th.stallParams of the running-window-mean method (tombo_stats.py:317-323)
+        if (o->stall_n_windows < 2 || o->stall_n_windows > 16 || o->stall_mini_window_size < 1 ||
+            o->stall_window_size != o->stall_n_windows * o->stall_mini_window_size ||
+            o->stall_min_consecutive_obs < 0 || !(o->stall_threshold == o->stall_threshold))
+            return set_err(TBA_E_ARG, "bad stall detection parameters");
+    }
     if (stalls) {
         if (stall_off[0] != 0) return set_err(TBA_E_ARG, "offset arrays must start at 0");
         for (i64 i = 0; i < n_reads; i++) {
@@ -399,7 +420,8 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
     e->S_tot = z.S_tot; e->seq_tot = z.seq_tot; e->B_tot = z.B_tot; e->E_tot = z.E_tot;
     e->max_raw = z.max_raw; e->max_B = z.max_B; e->wide_w = z.wide_w;
     e->algo_bytes = z.algo_bytes; e->dp_cells = z.cells;
-    e->any_stall = stalls && stall_off[n] > 0;
+    e->any_stall = (stalls && stall_off[n] > 0) || o->detect_stalls;
+    e->n_stall_cap = z.n_stall;
     e->have_samp = samp_ind != nullptr;
     e->have_sv = sv_in != nullptr && sv_flags != nullptr;
     e->start_moves_stride = z.start_moves_stride;
@@ -420,8 +442,13 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
     if (e->have_sv) HIP_TRY(hipMemcpyAsync(e->d_sv_in.p, sv_in, N * 32, hipMemcpyHostToDevice, s));
     if (e->have_samp)
         HIP_TRY(hipMemcpyAsync(e->d_samp.p, samp_ind, N * MAX_TS_POINTS * 8, hipMemcpyHostToDevice, s));
-    if (e->any_stall)
+    if (stalls && stall_off[n] > 0)
         HIP_TRY(hipMemcpyAsync(e->d_stall.p, stall_ints, (size_t)stall_off[n] * 16, hipMemcpyHostToDevice, s));
+    if (o->reverse_raw) { // once per upload, in stream order behind the copy
+        const unsigned gr = (unsigned)std::min<i64>(std::max<i64>((z.max_raw / 2 + 1023) / 1024, 1), 64);
+        RAW_DISPATCH(raw_dtype, (k_reverse_raw<RT><<<dim3(gr, (unsigned)n), 256, 0, s>>>(e->d_rs.as<ReadState>(), e->d_raw.as<RT>())));
+        HIP_TRY(hipGetLastError());
+    }
     e->have_batch = true;
     return 0;
 }
@@ -472,14 +499,6 @@ static void launch_dp(tba_engine *e, int cpl, int mode)
     }
 }
 
-// launch a kernel template instantiated for the batch's raw sample type
-#define RAW_DISPATCH(dt_, call_)                                                               \
-    do {                                                                                       \
-        if ((dt_) == TBA_RAW_I16) { typedef int16_t RT; call_; }                               \
-        else if ((dt_) == TBA_RAW_F32) { typedef float RT; call_; }                            \
-        else { typedef double RT; call_; }                                                     \
-    } while (0)
-
 static int enqueue_stages(tba_engine *e, int first, int last)
 {
     if (!e || !e->have_batch) return set_err(TBA_E_STATE, "no batch uploaded");
@@ -510,8 +529,21 @@ static int enqueue_stages(tba_engine *e, int first, int last)
 #define MARK() HIP_TRY(hipEventRecord(e->ev[st++], s))
 #define ON(stage_) ((stage_) >= first && (stage_) <= last)
     const bool rna = P.use_t_test_seg != 0;
-    MARK(); // 0 normalize
     const int rdt = e->raw_dtype;
+    // caller-side preparation: ts.identify_stalls over the raw samples (events 15 -> 16)
+    HIP_TRY(hipEventRecord(e->ev[15], s));
+    if (ON(TBA_STAGE_SEGMENT) && e->hp.o.detect_stalls) {
+        double *csum = e->d_csum.as<double>();
+        u64 *bits = e->d_state.as<u64>();
+        if (cs_reads_for(n) == 20) RAW_DISPATCH(rdt, (k_cumsum_scores<20, RT, 1><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
+        else RAW_DISPATCH(rdt, (k_cumsum_scores<32, RT, 1><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
+        if (e->hp.o.stall_n_windows == 7) k_stall_metric<7><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, csum, bits);
+        else k_stall_metric<0><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, csum, bits);
+        k_stall_runs<<<dim3(gx(e->max_raw / 64 + 1), nb), 256, 0, s>>>(rs, dp, bits, e->d_stall.as<i64>());
+        k_stall_merge<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_stall.as<i64>());
+    }
+    HIP_TRY(hipEventRecord(e->ev[16], s));
+    MARK(); // 0 normalize
     const bool fused_scores = 2 * P.running_stat_width <= 64; // cumsum + scores in one kernel
     if (ON(TBA_STAGE_SEGMENT) && !rna)
         RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0, 1)));
@@ -592,7 +624,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 12 theil-sen
     if (ON(TBA_STAGE_RESCALE)) {
-        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->have_samp ? e->d_samp.as<i64>() : nullptr, e->d_csum.as<double>(), e->d_score.as<double>());
+        k_theil_sen<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_segs.as<i64>(), e->d_refm.as<double>(), e->have_samp || e->hp.o.device_subsample ? e->d_samp.as<i64>() : nullptr, e->d_csum.as<double>(), e->d_score.as<double>());
     }
     MARK(); // 13 rescale + score
     if (ON(TBA_STAGE_RESCALE)) {
@@ -694,7 +726,8 @@ extern "C" int tba_batch_sync(tba_engine *e)
     if (e->ran) {
         memset(e->stage_ms, 0, sizeof(e->stage_ms));
         for (int i = 0; i < 14; i++) (void)hipEventElapsedTime(&e->stage_ms[i], e->ev[i], e->ev[i + 1]);
-        (void)hipEventElapsedTime(&e->stage_ms[15], e->ev[0], e->ev[14]);
+        (void)hipEventElapsedTime(&e->stage_ms[14], e->ev[15], e->ev[16]); // stall detection
+        (void)hipEventElapsedTime(&e->stage_ms[15], e->ev[15], e->ev[14]);
     }
     return 0;
 }
@@ -823,6 +856,11 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
     case TBA_GET_REF_MEANS: return copy(e->d_refm, (size_t)e->B_tot * 8);
     case TBA_GET_REF_SDS: return copy(e->d_refs, (size_t)e->B_tot * 8);
     case TBA_GET_SEGS: return copy(e->d_segs, (size_t)(e->B_tot + e->n_reads) * 8);
+    case TBA_GET_SAMP_IND: return copy(e->d_samp, N * MAX_TS_POINTS * 8);
+    case TBA_GET_STALL_INTS:
+        if (!e->any_stall) return set_err(TBA_E_STATE, "the batch has no stall intervals");
+        // (the caller sizes `out` by the intervals in use: max(STALL_OFF + N_STALL))
+        return copy(e->d_stall, std::min((size_t)e->n_stall_cap * 16, (size_t)out_bytes));
     case TBA_GET_KERNEL_MS:
         if ((size_t)out_bytes < sizeof(e->stage_ms)) return set_err(TBA_E_ARG, "output buffer too small");
         memcpy(out, e->stage_ms, sizeof(e->stage_ms));
@@ -840,10 +878,12 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
         for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].status;
         return 0;
     }
-    if (what == TBA_GET_N_CPTS || what == TBA_GET_DP_READ_START) {
+    if (what == TBA_GET_N_CPTS || what == TBA_GET_DP_READ_START || what == TBA_GET_N_STALL ||
+        what == TBA_GET_STALL_OFF) {
         if ((size_t)out_bytes < N * 8) return set_err(TBA_E_ARG, "output buffer too small");
         for (size_t i = 0; i < N; i++)
-            ((i64 *)out)[i] = what == TBA_GET_N_CPTS ? rs[i].n_cpts : rs[i].dp_read_start;
+            ((i64 *)out)[i] = what == TBA_GET_N_CPTS ? rs[i].n_cpts : what == TBA_GET_N_STALL ? rs[i].n_stall
+                              : what == TBA_GET_STALL_OFF ? rs[i].stall_off : rs[i].dp_read_start;
         return 0;
     }
     if (what == TBA_GET_SEG_SV || what == TBA_GET_START || what == TBA_GET_THEIL_SEN) {
@@ -1509,4 +1549,138 @@ extern "C" int tba_selftest_approx_quotient(tba_engine *e, const double *a, cons
     C_TRY(hipStreamSynchronize(e->stream));
     C_TRY(hipMemcpy(out, d_o.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return TBA_OK;
+}
+
+// ---- ts.identify_stalls (tombo_stats.py:269-368), one read, host buffers --------------------
+extern "C" int tba_identify_stalls(tba_engine *e, const void *raw, int raw_dtype, int64_t n,
+    int64_t window_size, int64_t n_windows, int64_t mini_window_size, double threshold,
+    int64_t min_consecutive_obs, int64_t edge_buffer, int64_t *ints, int64_t cap, int64_t *n_ints)
+{
+    if (!e || !raw || n < 1 || !n_ints || (cap > 0 && !ints)) return set_err(TBA_E_ARG, "bad arguments");
+    if (raw_dtype < TBA_RAW_F64 || raw_dtype > TBA_RAW_I16) return set_err(TBA_E_ARG, "unknown raw dtype");
+    if (n_windows < 2 || n_windows > 16 || mini_window_size < 1 ||
+        window_size != n_windows * mini_window_size || min_consecutive_obs < 0)
+        return set_err(TBA_E_ARG, "bad stall detection parameters");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *n_ints = 0;
+    if (n < window_size) return TBA_OK; // tombo_stats.py:305-308
+    ReadState r;
+    memset(&r, 0, sizeof(r));
+    r.n_raw = n;
+    r.status = TBA_OK;
+    DevParams hp;
+    memset(&hp, 0, sizeof(hp));
+    hp.o.detect_stalls = 1;
+    hp.o.stall_window_size = window_size; hp.o.stall_n_windows = n_windows;
+    hp.o.stall_mini_window_size = mini_window_size; hp.o.stall_threshold = threshold;
+    hp.o.stall_min_consecutive_obs = min_consecutive_obs; hp.o.stall_edge_buffer = edge_buffer;
+    const i64 dev_cap = n / (min_consecutive_obs + 1) + 2;
+    Tmp d_r, d_p, d_raw, d_csum, d_bits, d_ints;
+    if (d_r.alloc(sizeof(r)) || d_p.alloc(sizeof(hp)) || d_raw.alloc((size_t)n * raw_elem_bytes(raw_dtype)) ||
+        d_csum.alloc((size_t)(n + 2) * 8) || d_bits.alloc((size_t)(n / 64 + 2) * 8) ||
+        d_ints.alloc((size_t)dev_cap * 16))
+        return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    hipStream_t s = e->stream;
+    C_TRY(hipMemcpyAsync(d_r.p, &r, sizeof(r), hipMemcpyHostToDevice, s));
+    C_TRY(hipMemcpyAsync(d_p.p, &hp, sizeof(hp), hipMemcpyHostToDevice, s));
+    C_TRY(hipMemcpyAsync(d_raw.p, raw, (size_t)n * raw_elem_bytes(raw_dtype), hipMemcpyHostToDevice, s));
+    ReadState *rs = d_r.as<ReadState>();
+    const DevParams *dp = d_p.as<DevParams>();
+    RAW_DISPATCH(raw_dtype, (k_cumsum_scores<32, RT, 1><<<1, 256, 0, s>>>(rs, 1, dp, d_raw.as<RT>(), d_csum.as<double>())));
+    const unsigned g = grid_for(n / 4 + 1);
+    if (n_windows == 7) k_stall_metric<7><<<dim3(g, 1), 256, 0, s>>>(rs, dp, d_csum.as<double>(), d_bits.as<u64>());
+    else k_stall_metric<0><<<dim3(g, 1), 256, 0, s>>>(rs, dp, d_csum.as<double>(), d_bits.as<u64>());
+    k_stall_runs<<<dim3(grid_for(n / 64 + 1), 1), 256, 0, s>>>(rs, dp, d_bits.as<u64>(), d_ints.as<i64>());
+    k_stall_merge<<<1, 64, 0, s>>>(rs, 1, dp, d_ints.as<i64>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipMemcpyAsync(&r, d_r.p, sizeof(r), hipMemcpyDeviceToHost, s));
+    C_TRY(hipStreamSynchronize(s));
+    if (r.status != TBA_OK) return r.status;
+    *n_ints = r.n_stall;
+    if (r.n_stall > cap) return set_err(TBA_E_ARG, "interval buffer too small (n_ints holds the count)");
+    if (r.n_stall > 0) C_TRY(hipMemcpy(ints, d_ints.p, (size_t)r.n_stall * 16, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+// self-test of the device-side subsample: out[t] = image of t under the keyed permutation of
+// [0, n) that read `read_index` of a batch would use under `seed` (t < count <= n)
+__global__ void k_c_perm_check(i64 n, u64 seed, i64 read_index, i64 count, i64 *out)
+{
+    const u64 key = subsample_key(seed, read_index);
+    for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < count; t += (i64)gridDim.x * 256)
+        out[t] = keyed_perm(t, n, key);
+}
+extern "C" int tba_selftest_subsample(tba_engine *e, int64_t n, uint64_t seed, int64_t read_index,
+                                      int64_t count, int64_t *out)
+{
+    if (!e || !out || n < 1 || count < 1 || count > n) return set_err(TBA_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    Tmp d_o;
+    if (d_o.alloc((size_t)count * 8)) return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    k_c_perm_check<<<grid_for(count), 256, 0, e->stream>>>(n, seed, read_index, count, d_o.as<i64>());
+    C_TRY(hipGetLastError());
+    C_TRY(hipStreamSynchronize(e->stream));
+    C_TRY(hipMemcpy(out, d_o.p, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return TBA_OK;
+}
+
+// ---- host-side packer: per-read arrays -> the CSR buffers of tba_batch_upload_async ----------
+// (the reader side of the reference's worker pool, resquiggle.py:1385-1486: one Python thread
+// cannot copy 100 k reads/s into a batch; this does it with n_threads native threads, GIL released)
+#include <thread>
+extern "C" int tba_pack_reads(int64_t n_reads, const void *const *raw_ptrs, int raw_dtype,
+    int reverse, const int64_t *raw_off, void *raw_out, const char *const *seq_ptrs,
+    const int64_t *seq_off, uint8_t *seq_out, int n_threads)
+{
+    if (n_reads < 0 || !raw_off || !seq_off || (n_reads > 0 && (!raw_ptrs || !seq_ptrs || !raw_out || !seq_out)))
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (raw_dtype < TBA_RAW_F64 || raw_dtype > TBA_RAW_I16) return set_err(TBA_E_ARG, "unknown raw dtype");
+    const size_t eb = raw_elem_bytes(raw_dtype);
+    static unsigned char code[256];
+    static bool have_code = false;
+    if (!have_code) { // ACGT -> 0..3, anything else 255 (the engine reports TBA_INVALID_SEQ)
+        for (int i = 0; i < 256; i++) code[i] = 255;
+        code[(int)'A'] = 0; code[(int)'C'] = 1; code[(int)'G'] = 2; code[(int)'T'] = 3;
+        have_code = true;
+    }
+    auto work = [&](i64 a, i64 b) {
+        for (i64 i = a; i < b; i++) {
+            const i64 n = raw_off[i + 1] - raw_off[i], m = seq_off[i + 1] - seq_off[i];
+            char *dst = (char *)raw_out + (size_t)raw_off[i] * eb;
+            const char *src = (const char *)raw_ptrs[i];
+            if (!reverse) memcpy(dst, src, (size_t)n * eb);
+            else if (eb == 2) { const int16_t *q = (const int16_t *)src; int16_t *d = (int16_t *)dst; for (i64 k = 0; k < n; k++) d[k] = q[n - 1 - k]; }
+            else if (eb == 4) { const float *q = (const float *)src; float *d = (float *)dst; for (i64 k = 0; k < n; k++) d[k] = q[n - 1 - k]; }
+            else { const double *q = (const double *)src; double *d = (double *)dst; for (i64 k = 0; k < n; k++) d[k] = q[n - 1 - k]; }
+            const unsigned char *sq = (const unsigned char *)seq_ptrs[i];
+            uint8_t *so = seq_out + seq_off[i];
+            for (i64 k = 0; k < m; k++) so[k] = code[sq[k]];
+        }
+    };
+    int nt = std::max(1, std::min<int>(n_threads, (int)std::min<i64>(n_reads, 256)));
+    if (nt == 1) { work(0, n_reads); return 0; }
+    // cut by bytes, not by reads: the reads of a sorted batch differ in length
+    std::vector<std::thread> th;
+    const i64 tot = raw_off[n_reads] * (i64)eb + seq_off[n_reads];
+    i64 a = 0;
+    for (int t = 0; t < nt; t++) {
+        i64 b = a;
+        const i64 goal = tot / nt * (t + 1);
+        while (b < n_reads && (t == nt - 1 || raw_off[b + 1] * (i64)eb + seq_off[b + 1] <= goal)) b++;
+        if (t == nt - 1) b = n_reads;
+        if (b > a) th.emplace_back(work, a, b);
+        a = b;
+    }
+    for (auto &x : th) x.join();
+    return 0;
+}
+
+// sizeof of the ABI structs, so that a binding can check its mirrors without a C compiler
+extern "C" int tba_abi_sizes(int64_t *out, int64_t n)
+{
+    if (!out || n < 3) return set_err(TBA_E_ARG, "bad arguments");
+    out[0] = (int64_t)sizeof(tba_params); out[1] = (int64_t)sizeof(tba_opts);
+    out[2] = (int64_t)sizeof(tba_read_result);
+    return 0;
 }

@@ -144,54 +144,20 @@ def compute_num_events(signal_len, seq_len, mean_obs_per_event,
     return max(signal_len // mean_obs_per_event, int(seq_len * min_event_to_seq_ratio))
 
 
-def identify_stalls(all_raw_signal, stall_params=None):
-    """Mean-window stall detector (caller-side RNA preparation).
-
-    7 offsets of a 50-sample moving average; metric = (sum of the 21 pairwise absolute
-    differences + the first one once more) / 21, centred at window_size//2; runs of
-    metric <= threshold longer than min_consecutive_obs, widened and merged.
-    """
+def identify_stalls(all_raw_signal, stall_params=None, return_metric=False):
+    """Stall intervals of one read (caller-side RNA preparation, tombo_stats.py:269-368, the
+    running-window-mean method): computed on the device (`tba_identify_stalls`; kernels in
+    csrc/k_prep_raw.h, the same ones a batch runs under `tba_opts.detect_stalls`).  Returns a list
+    of [start, end] int64 pairs like the reference.  int16 DAC, float32 and float64 samples are
+    taken as they are (DAC sums are exact, float sums keep np.cumsum's order)."""
+    if return_metric:
+        raise NotImplementedError('the per-sample stall metric stays on the device')
+    from . import _native, resquiggle as rq
     sp = th.stallParams(**STALL_PARAMS) if stall_params is None else stall_params
-    x = np.asarray(all_raw_signal)
-    n = x.shape[0]
-    if n < sp.window_size:
-        return []
-    mw, nw = sp.mini_window_size, sp.n_windows
-    assert sp.window_size == mw * nw
-    csum = np.cumsum(x)
-    csum[mw:] = csum[mw:] - csum[:-mw]
-    mov = csum[mw - 1:] / mw
-    n_pos = n - sp.window_size + 1
-    offs = [mov[mw * k: mw * k + n_pos] for k in range(nw)]
-    diffs = [np.abs(offs[i] - offs[j]) for i in range(nw) for j in range(i + 1, nw)]
-    acc = diffs[0].copy()
-    for d in diffs:
-        acc += d
-    metric = np.full(n, np.nan)
-    start_offset = int(sp.window_size * 0.5)
-    metric[start_offset:start_offset + n_pos] = acc / len(diffs)
-    with np.errstate(invalid='ignore'):
-        below = metric <= sp.threshold
-    edges = np.where(np.diff(np.concatenate([[False], below])))[0]
-    if below[-1]:
-        edges = np.concatenate([edges, [n]])
-    ivals = edges.reshape(-1, 2)
-    ivals = ivals[(ivals[:, 1] - ivals[:, 0]) > sp.min_consecutive_obs]
-    if ivals.shape[0] == 0:
-        return []
-    expand = (sp.window_size // 2) - sp.edge_buffer
-    if expand <= 0:
-        return ivals
-    ivals = ivals.copy()
-    ivals[:, 0] -= expand
-    ivals[:, 1] += expand
-    merged = [ivals[0].copy()]
-    for cur in ivals:
-        if cur[0] > merged[-1][1]:
-            merged.append(cur.copy())
-        else:
-            merged[-1][1] = cur[1]
-    return merged
+    if sp.lower_pctl is not None and sp.upper_pctl is not None:
+        raise NotImplementedError('the percentile stall detector (PCTL_STALL_PARAMS) is not the '
+                                  'reference default and not part of this engine')
+    return list(_native.identify_stalls(rq.get_engine(), all_raw_signal, sp))
 
 
 def remove_stall_cpts(stall_ints, valid_cpts):
