@@ -1,32 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- resquiggle reads/s of the HIP batch engine (BASELINE.json metric).
 
-A "step" is one pass of the whole hot path (normalise -> event detection -> start discovery ->
-adaptive banded DP -> traceback -> skipped-base raw DP -> Theil-Sen rescale -> score) over one
-batch of synthetic reads.  Workload at N=1 is BASELINE.json configs[1]: 10k synthetic 10 kb DNA
-reads, bandwidth 500.
+A "step" is one pass of the whole hot path (stall detection for RNA -> normalise -> event
+detection -> start discovery -> adaptive banded DP -> traceback -> skipped-base raw DP ->
+Theil-Sen rescale -> score) over one batch of synthetic reads.  Workload at N=1 is BASELINE.json
+configs[1]: 10k synthetic 10 kb DNA reads, bandwidth 500.
 
-Two measurements per run, both over the host work queue (tombo_amd/sharding.py: a shared counter
-every rank draws batch indices from; reads are independent, no data-path collective):
+Measurements of one run, all drawn through the host work queue (tombo_amd/sharding.py: a shared
+counter every rank draws batch indices from; reads are independent, no data-path collective, and
+the control plane -- barrier, two scalar reductions, the per-rank report -- is gloo on every
+path: no RCCL anywhere, as BASELINE.json's north_star states):
 
   value        RESIDENT: every rank's batch already sits in HBM when the timed region starts
                (float64 pA, the reference's in-memory type); K * N passes are drawn from the queue.
-  end_to_end   HOST BUFFERS IN -> HOST BUFFERS OUT through the streaming pipeline
-               (tombo_amd/streaming.py: n_slots engines per GPU, upload N+1 || compute N ||
-               download N-1): int16 DAC samples in page-locked host memory in, 64-byte record +
-               int32 boundaries per read out ("compact"), or float64 in / float64 normalised
-               signal + int64 boundaries out (--e2e full).
+  end_to_end   READS IN -> RESULTS OUT: per-read int16 DAC arrays (as the FAST5 `Signal` dataset
+               holds them; RNA in acquisition order) and sequence strings are packed into
+               page-locked CSR staging by native threads (tba_pack_reads), uploaded, run (RNA: flip
+               + stall detection on the device; Theil-Sen subsample drawn on the device) and come
+               back as a 64-byte record + int32 boundaries per read, through the streaming
+               pipeline (tombo_amd/streaming.py: n_slots engines per GPU, upload N+1 || compute
+               N || download N-1).  --e2e full: float64 in / float64 signal + int64 boundaries out.
+  api          (N = 1) the drop-in Python API itself: resquiggle_batch(list of map_res) reads/s
+               and the latency of a batch-of-one resquiggle_read.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--preset cfg1..cfg4|longtail] ...
 
 With --gpus N > 1 and no torchrun environment the script launches its own N ranks (one process
-per GPU, RCCL only for the barrier and the max-over-ranks time).  Prints ONE JSON line on rank 0.
+per GPU).  Prints ONE JSON line on rank 0.
 """
 import os
 import sys
 import json
 import time
-import socket
 import argparse
 import subprocess
 
@@ -39,14 +44,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6300 achievable
 DAC_PER_PA, DAC_OFFSET = 1.0 / 0.1709, 10.0  # MinION-like digitisation of the synthetic pA
 
-# stage (engine event bracket) -> the kernel that dominates it
-STAGE_KERNEL = {
-    'normalize': 'k_normalize', 'cumsum': 'k_cumsum_scores', 'scores': 'k_scores_ttest',
-    'peaks': 'k_peaks (+ RNA: stall removal, event scaling, normalisation)',
-    'event_means': 'k_event_means', 'ref_levels': 'k_ref_levels', 'start_dp': 'k_dp (start discovery)',
-    'start_tb': 'k_dp (start retry) + k_start_tb', 'prep': 'k_prep',
-    'main_dp': 'k_dp (main adaptive banded forward pass)', 'main_tb': 'k_main_tb',
-    'skip_resolve': 'k_skip_dp', 'theil_sen': 'k_theil_sen', 'rescale_score': 'k_rescale_absz'}
+# roofline: the dominant stage GROUP of the configuration (engine event brackets) and the kernels
+# inside it
+STAGE_GROUPS = [
+    ('main_dp', ['main_dp'], 'k_dp (main adaptive banded forward pass)'),
+    ('event_detection', ['cumsum', 'scores', 'peaks'],
+     'event detection bracket: k_cumsum_scores / k_scores_ttest + k_peaks (+ RNA: stall removal, '
+     'event scaling, normalisation)'),
+    ('normalize', ['normalize'], 'k_normalize'), ('stalls', ['stalls'], 'k_cumsum_scores<raw> + k_stall_metric'),
+    ('event_means', ['event_means'], 'k_event_means'), ('start', ['start_dp', 'start_tb'], 'k_dp (start discovery) + k_start_tb'),
+    ('main_tb', ['main_tb'], 'k_main_tb'), ('skip_resolve', ['skip_resolve'], 'k_skip_dp'),
+    ('theil_sen', ['theil_sen'], 'k_theil_sen'), ('rescale_score', ['rescale_score'], 'k_rescale_absz')]
 
 
 def _gen(args):
@@ -58,16 +66,15 @@ def _gen(args):
         _gen.models = models
     model = models[samp_name]
     kw = synth.RNA_SYNTH if samp_name == 'RNA' else synth.DNA_SYNTH
-    # RNA: generated in 5'->3' order = what the worker passes after [::-1]; stalls as the worker
-    # finds them
+    # RNA: generated in 5'->3' order = what the worker holds after [::-1]; the
+    # acquisition-order array (the file's) is its flip
     seq, raw, _ = synth.synth_read(model, n_bases, seed, **kw)
-    dac = np.round(raw * DAC_PER_PA + DAC_OFFSET).astype(np.int16) if want_dac else None
-    stalls = stalls_dac = None
-    if samp_name == 'RNA':
-        stalls = ts.identify_stalls(raw)
-        if want_dac:
-            stalls_dac = ts.identify_stalls(dac.astype(np.float64))
-    return ts.encode_seq(seq).copy(), raw, stalls, dac, stalls_dac
+    dac = None
+    if want_dac:
+        dac = np.round(raw * DAC_PER_PA + DAC_OFFSET).astype(np.int16)
+        if samp_name == 'RNA':
+            dac = np.ascontiguousarray(dac[::-1])
+    return seq, raw, dac
 
 
 def _under_profiler():
@@ -76,9 +83,10 @@ def _under_profiler():
 
 
 def make_reads(bases, base_seed, workers, samp_name='DNA', want_dac=False):
-    """Synthetic reads (read i: bases[i] bases, seed base_seed + i).  Worker processes are forked
-    before any HIP state exists; under rocprofv3 forked workers deadlock in the tool's signal
-    handler, so threads are used there."""
+    """Synthetic reads (read i: bases[i] bases, seed base_seed + i) -> (seq strings, float64 pA in
+    5'->3' order, int16 DAC in acquisition order or None).  Worker processes are forked before any
+    HIP state exists; under rocprofv3 forked workers deadlock in the tool's signal handler, so
+    threads are used there."""
     n_reads = len(bases)
     jobs = [(int(bases[i]), base_seed + i, samp_name, want_dac) for i in range(n_reads)]
     _gen(jobs[0])
@@ -92,13 +100,13 @@ def make_reads(bases, base_seed, workers, samp_name='DNA', want_dac=False):
             res = list(ex.map(_gen, jobs, chunksize=max(1, n_reads // (workers * 8))))
     else:
         res = [_gen(j) for j in jobs]
-    return [[r[k] for r in res] for k in range(5)]
+    return [[r[k] for r in res] for k in range(3)]
 
 
-def longtail_bases(n_reads, seed):
-    """long-tailed read lengths: log-normal (median 8 kb, sigma 0.9) clipped to 1-100 kb"""
+def longtail_bases(n_reads, seed, max_bases=200000):
+    """long-tailed read lengths: log-normal (median 8 kb, sigma 0.9) clipped to 1-200 kb"""
     rng = np.random.default_rng(seed)
-    return np.clip(np.exp(rng.normal(np.log(8000.0), 0.9, n_reads)), 1000, 100000).astype(np.int64)
+    return np.clip(np.exp(rng.normal(np.log(8000.0), 0.9, n_reads)), 1000, max_bases).astype(np.int64)
 
 
 def cpu_model():
@@ -124,31 +132,34 @@ def _cpu_one(i):
     return r['status'] == 0
 
 
-def cpu_baseline(seqs, raws, params, model, n_bases, samp_name, stalls, n_single, n_per_core):
+def cpu_baseline(seqs, raws, params, model, n_bases, samp_name, n_single, n_per_core):
     """The CPU restatement (oracle/, kind "port") on bounded samples of the same workload: one
     process, then one process per host core (forked before any HIP state exists; threads under a
     profiler, where forking deadlocks).  Reported baseline only; the oracle is never on the
-    measured path."""
+    measured path.  (RNA: the stall intervals the worker would pass in are computed by the
+    restatement outside the clock -- the reference's resquiggle_read does not include them.)"""
     import oracle
+    from tombo_amd import tombo_stats as ts
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
     n1 = min(n_single, len(raws))
     cores = os.cpu_count() or 1
-    nall = min(max(n_per_core * cores, cores), len(raws)) if cores > 1 else 0
+    nall = min(max(n_per_core * cores, cores), len(raws)) if cores > 1 and n_per_core > 0 else 0
+    nmax = max(n1, nall)
     rng = np.random.RandomState(7)
     sis = {i: rng.choice(int(n_bases[i]), 1000, replace=False)
-           for i in range(max(n1, nall)) if n_bases[i] > 1000}
-    _CPU_CTX.update(raws=raws, seqs=seqs, means=model.level_means, sds=model.level_sds,
-                    p=oracle.make_params(params),
+           for i in range(nmax) if n_bases[i] > 1000}
+    st = [oracle.identify_stalls(raws[i]) if samp_name == 'RNA' else None for i in range(nmax)]
+    _CPU_CTX.update(raws=raws, seqs=[ts.encode_seq(s) for s in seqs[:nmax]], means=model.level_means,
+                    sds=model.level_sds, p=oracle.make_params(params),
                     o=oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
-                                       sig_match_thresh=SIG_MATCH_THRESH[samp_name]),
-                    st=stalls if stalls is not None else [None] * len(raws), sis=sis)
+                                       sig_match_thresh=SIG_MATCH_THRESH[samp_name]), st=st, sis=sis)
     _cpu_one(0)  # page in
     t0 = time.perf_counter()
     ok1 = sum(_cpu_one(i) for i in range(n1))
     dt1 = time.perf_counter() - t0
     legs = [dict(value=round(n1 / dt1, 3), unit='reads/s', cores=1, kind='port',
                  sample='%d of the same reads through oracle/ (C restatement, 1 thread), %d ok' % (n1, ok1))]
-    if cores > 1:
+    if nall > 0:
         if _under_profiler():
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(cores) as ex:
@@ -173,7 +184,7 @@ def cpu_baseline(seqs, raws, params, model, n_bases, samp_name, stalls, n_single
 def pmc_child(path):
     """child of measure_pmc_traffic: load the reads the parent saved, one upload + one pass"""
     from tombo_amd import _native, tombo_stats as ts, tombo_helper as th
-    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH, STALL_PARAMS
     d = np.load(path, allow_pickle=False)
     meta = json.loads(str(d['meta']))
     samp = th.seqSampleType(meta['samp'], meta['samp'] == 'RNA')
@@ -184,21 +195,20 @@ def pmc_child(path):
     eng = _native.Engine(0)
     eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
     eng.upload_packed(_native.make_params(params),
-                      _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[meta['samp']]),
+                      _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[meta['samp']],
+                                        stall_params=th.stallParams(**STALL_PARAMS) if meta['samp'] == 'RNA' else None),
                       d['raw'], d['raw_off'], d['seq'], d['seq_off'],
-                      samp_ind=d['samp_ind'] if 'samp_ind' in d.files else None,
-                      stall_ints=d['stall_ints'] if 'stall_ints' in d.files else None,
-                      stall_off=d['stall_off'] if 'stall_off' in d.files else None, wait=True)
+                      samp_ind=d['samp_ind'] if 'samp_ind' in d.files else None, wait=True)
     eng.run()
     print('pmc child ok', int((eng.download(want_norm=False)['status'] == 0).sum()))
 
 
-def measure_pmc_traffic(packed, meta, timeout=150):
+def measure_pmc_traffic(packed, meta, device=0, timeout=150):
     """FETCH_SIZE + WRITE_SIZE of every kernel of one pass over `packed` (a sub-batch of the reads
     being benchmarked), from two separate `rocprofv3 --pmc` passes of a child process -- the two
     counters do not fit one pass on gfx950 (MI355X_MICROARCH.md, HBM section; KiB units; FETCH
-    raw and doubled).  Returns (bytes per read raw, bytes per read with FETCH doubled, per-kernel
-    dict) or raises."""
+    raw and doubled).  The child sees only `device`.  Returns (bytes per read raw, bytes per read
+    with FETCH doubled, per-kernel dict) or raises."""
     import glob
     import shutil
     import sqlite3
@@ -211,7 +221,11 @@ def measure_pmc_traffic(packed, meta, timeout=150):
     np.savez(path, meta=np.array(json.dumps(meta)), **{k: v for k, v in packed.items() if v is not None})
     n_reads = packed['raw_off'].shape[0] - 1
     tot = {}
-    env = dict(os.environ, TMPDIR='/tmp')
+    vis = os.environ.get('HIP_VISIBLE_DEVICES')
+    phys = vis.split(',')[device] if vis else str(device)
+    env = dict(os.environ, TMPDIR='/tmp', HIP_VISIBLE_DEVICES=phys)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'TBA_STORE_PORT'):
+        env.pop(k, None)
     try:
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = os.path.join(tmp, ctr)
@@ -241,39 +255,54 @@ def measure_pmc_traffic(packed, meta, timeout=150):
     return raw / n_reads, up / n_reads, kern
 
 
-def pack_lists(raws, seqs, samp_ind, stalls):
+def pack_lists(raws, seqs, samp_ind):
+    from tombo_amd import tombo_stats as ts
     raw_off = np.zeros(len(raws) + 1, np.int64)
     np.cumsum([len(r) for r in raws], out=raw_off[1:])
+    codes = [ts.encode_seq(s) for s in seqs]
     seq_off = np.zeros(len(seqs) + 1, np.int64)
-    np.cumsum([len(s) for s in seqs], out=seq_off[1:])
-    d = dict(raw=np.concatenate(raws), raw_off=raw_off, seq=np.concatenate(seqs), seq_off=seq_off,
-             samp_ind=samp_ind, stall_ints=None, stall_off=None)
-    if stalls is not None and any(s is not None and len(s) for s in stalls):
-        so = np.zeros(len(raws) + 1, np.int64)
-        np.cumsum([0 if s is None else len(s) for s in stalls], out=so[1:])
-        d['stall_off'] = so
-        d['stall_ints'] = np.array([[int(a), int(b)] for s in stalls if s is not None for a, b in s],
-                                   dtype=np.int64).reshape(-1, 2)
-    return d
+    np.cumsum([len(s) for s in codes], out=seq_off[1:])
+    return dict(raw=np.concatenate(raws), raw_off=raw_off, seq=np.concatenate(codes), seq_off=seq_off,
+                samp_ind=samp_ind)
 
 
 # ---- self-launch of N ranks ------------------------------------------------------------------
 def self_launch(n):
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
+    """N ranks of this script, one per GPU.  The rendezvous store is created HERE on a port the
+    kernel picks (no bind / close / rebind race) and stays up until the ranks are done; they join
+    it as clients (TBA_STORE_PORT)."""
+    from datetime import timedelta
+    import torch.distributed as dist
+    store = dist.TCPStore('127.0.0.1', 0, n, is_master=True, timeout=timedelta(seconds=1800),
+                          wait_for_workers=False)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                   MASTER_ADDR='127.0.0.1', TBA_STORE_PORT=str(store.port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     for p in procs:
         rc = p.wait() or rc
+    del store
     sys.exit(rc)
+
+
+def init_control_plane(rank, world):
+    """gloo process group for the barrier / reductions / per-rank report (never RCCL: ranks of a
+    resquiggle job exchange no data).  Under torchrun the env:// rendezvous of the launcher is
+    used; ranks launched by self_launch join its store."""
+    import torch.distributed as dist
+    from datetime import timedelta
+    if 'TBA_STORE_PORT' in os.environ:
+        store = dist.TCPStore('127.0.0.1', int(os.environ['TBA_STORE_PORT']), world, is_master=False,
+                              timeout=timedelta(seconds=1800))
+        dist.init_process_group('gloo', store=store, rank=rank, world_size=world,
+                                timeout=timedelta(seconds=1800))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timedelta(seconds=1800))
+    return dist
 
 
 def main():
@@ -285,25 +314,30 @@ def main():
     ap.add_argument('--bases', type=int, default=10000)
     ap.add_argument('--bandwidth', type=int, default=500)
     ap.add_argument('--cpu-sample', type=int, default=150, help='reads of the 1-thread CPU leg')
-    ap.add_argument('--cpu-per-core', type=int, default=6, help='reads per core of the all-core CPU leg')
+    ap.add_argument('--cpu-per-core', type=int, default=4, help='reads per core of the all-core CPU leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--preset', choices=['cfg2', 'cfg3', 'cfg1', 'cfg4', 'longtail'], default=None,
                     help='BASELINE.json configs: cfg2 10kb/W=500 (default), cfg3 10kb/W=300, '
-                         'cfg1 2kb/W=100, cfg4 RNA 3kb/W=500; longtail: log-normal 1-100 kb DNA '
+                         'cfg1 2kb/W=100, cfg4 RNA 3kb/W=500; longtail: log-normal 1-200 kb DNA '
                          'reads (median 8 kb), W=500, batches cut by the planner')
     ap.add_argument('--e2e', choices=['compact', 'full', 'none'], default='compact',
-                    help='end-to-end (host in -> host out) measurement: int16 in / records + '
+                    help='end-to-end (reads in -> results out) measurement: int16 in / records + '
                          'int32 boundaries out, float64 in / float64 signal + int64 boundaries '
                          'out, or skipped')
+    ap.add_argument('--subsample', choices=['device', 'numpy'], default='device',
+                    help='end-to-end leg: Theil-Sen subsample drawn on the device (keyed permutation) '
+                         'or by np.random.choice on the feeder thread (the seeded-parity mode)')
     ap.add_argument('--stream-batch', type=int, default=None,
                     help='reads per streamed batch (default: 10000 compact, 5000 full: its float64 outputs are page-locked per slot)')
     ap.add_argument('--slots', type=int, default=3, help='engine slots per GPU of the streaming pipeline')
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
                          'engine / stream (kernels of different sub-batches overlap)')
+    ap.add_argument('--api-reads', type=int, default=2000, help='reads of the resquiggle_batch API leg (0: skip)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes behind roofline.traffic')
     ap.add_argument('--pmc-reads', type=int, default=1024, help='reads of the counter passes')
     ap.add_argument('--pmc-child', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--engine-stub', default=None, help=argparse.SUPPRESS)  # tests/: host logic without a GPU
     a = ap.parse_args()
     if a.pmc_child:
         return pmc_child(a.pmc_child)
@@ -318,33 +352,41 @@ def main():
         samp_name, a.bases, a.bandwidth = 'RNA', 3000, 500
     longtail = a.preset == 'longtail'
     if longtail and a.reads == 10000:
-        a.reads = 16000   # enough work per pass to hide the serial time of a 100 kb read
+        a.reads = 16000   # enough work per pass to hide the serial time of a 200 kb read
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    # stdout carries exactly one line, the JSON of rank 0: library chatter written to fd 1 (gloo /
-    # RCCL banners, HIP warnings) is sent to stderr for the rest of the process
+    t_start = time.perf_counter()
+    # stdout carries exactly one line, the JSON of rank 0: library chatter written to fd 1 (gloo
+    # banners, HIP warnings) is sent to stderr for the rest of the process
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
     # synthetic input first: worker processes must be forked before HIP is initialised
     from tombo_amd import _native, planner, sharding, streaming, tombo_stats as ts, tombo_helper as th
-    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH, STALL_PARAMS
+    stub = None
+    if a.engine_stub:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('tba_engine_stub', a.engine_stub)
+        stub = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(stub)
+        stub.install(_native)
     samp = th.seqSampleType(samp_name, samp_name == 'RNA')
+    rna = samp_name == 'RNA'
     model = ts.TomboModel(seq_samp_type=samp)
     params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=a.bandwidth)
     if a.bandwidth <= 100:
         params = params._replace(band_bound_thresh=10)  # the default 40 fails every read at W=100
+    stall_params = th.stallParams(**STALL_PARAMS) if rna else None
     workers = max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))
-    seed0 = 1000003 * (rank + 1)
+    seed0 = 1000003 * (rank + 1)    # every rank has its own, distinct reads
     bases = longtail_bases(a.reads, seed0) if longtail else np.full(a.reads, a.bases, np.int64)
-    want_dac = a.e2e == 'compact'
+    want_dac = a.e2e == 'compact' or a.api_reads > 0
     t_gen = time.perf_counter()
-    seqs, raws, stalls, dacs, stalls_dac = make_reads(bases, seed0, workers, samp_name, want_dac)
+    seqs, raws, dacs = make_reads(bases, seed0, workers, samp_name, want_dac)
     t_gen = time.perf_counter() - t_gen
-    if samp_name != 'RNA':
-        stalls = stalls_dac = None
     rng = np.random.RandomState(12345 + rank)
     si = np.zeros((a.reads, 1000), np.int64)
     for i in range(a.reads):
@@ -355,36 +397,37 @@ def main():
     n_raw = np.array([len(r) for r in raws], np.int64)
     seq_len = np.array([len(s) for s in seqs], np.int64)
 
+    # the CPU legs run on rank 0 at every N, before any HIP state exists and before the control
+    # plane is up (the other ranks wait for rank 0 in its rendezvous)
     cpu_legs = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu_legs = cpu_baseline(seqs, raws, params, model, bases, samp_name, stalls, a.cpu_sample,
-                                a.cpu_per_core)
+    t_cpu = time.perf_counter()
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu_legs = cpu_baseline(seqs, raws, params, model, bases, samp_name, a.cpu_sample, a.cpu_per_core)
+    t_cpu = time.perf_counter() - t_cpu
 
+    dist = init_control_plane(rank, world) if world > 1 else None
     import torch
-    dist = None
-    ndev = max(torch.cuda.device_count(), 1)
+    have_cuda = stub is None and torch.cuda.is_available()
+    ndev = max(torch.cuda.device_count(), 1) if have_cuda else max(_native.lib().tba_device_count(), 1)
     dev = local_rank % ndev
-    torch.cuda.set_device(dev)
-    red_dev = 'cuda'
-    if world > 1:
-        import torch.distributed as dist
-        if ndev >= world:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
-        else:
-            # fewer GPUs than ranks (a development box): the ranks share devices, which RCCL
-            # refuses; the barrier / max-over-ranks then go over gloo
-            dist.init_process_group('gloo')
-            red_dev = 'cpu'
+    dev_name = 'stub'
+    if have_cuda:
+        torch.cuda.set_device(dev)
+        dev_name = torch.cuda.get_device_name(dev)
+
+    def dev_sync():
+        if have_cuda:
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def reduce(x, op):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -395,7 +438,8 @@ def main():
         return reduce(x, dist.ReduceOp.SUM) if dist is not None else x
 
     p = _native.make_params(params)
-    o = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name])
+    o = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name],
+                          stall_params=stall_params)
 
     # ---- phase 1: resident ---------------------------------------------------------------
     # one engine per planned batch (the uniform presets are a single batch); a pass = every
@@ -405,7 +449,7 @@ def main():
     free_b, total_b = probe.device_mem()
     if longtail:
         # several batches resident at once, each on its own stream: the one-wave-per-read kernels
-        # of the batch holding the 100 kb reads run for ~0.2 s, the other batches fill the machine
+        # of the batch holding the longest reads run for a long time, the other batches fill the machine
         tot = planner.exact_bytes(n_raw, seq_len, p, o, model.kmer_width)
         plan = planner.plan_batches(n_raw, seq_len, p, o, model.kmer_width,
                                     min(0.2 * free_b, max(tot / 6.0, 2e9)))
@@ -414,11 +458,11 @@ def main():
     engines = [probe] + [_native.Engine(dev) for _ in plan[1:]]
     t_up = time.perf_counter()
     up_bytes = 0
+    codes = [ts.encode_seq(s) for s in seqs]
     for eng, idx in zip(engines, plan):
         eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
-        eng.upload(p, o, [raws[i] for i in idx], [seqs[i] for i in idx],
-                   samp_ind=None if si is None else si[idx],
-                   stall_ints=None if stalls is None else [stalls[i] for i in idx])
+        eng.upload(p, o, [raws[i] for i in idx], [codes[i] for i in idx],
+                   samp_ind=None if si is None else si[idx])
         up_bytes += int(n_raw[idx].sum()) * 8
     t_up = time.perf_counter() - t_up
     algo_bytes = dp_cells = 0.0
@@ -435,7 +479,7 @@ def main():
 
     for _ in range(a.warmup):
         one_pass()
-    queue = sharding.BatchQueue(a.steps * world)   # constructed by every rank, in the same order
+    queue = sharding.BatchQueue(a.steps * world, key='resident')
     barrier()
     t0 = time.perf_counter()
     stage = np.zeros(32)
@@ -445,6 +489,8 @@ def main():
         for eng in engines:
             stage += eng.get(_native.GET_KERNEL_MS)
         my_steps += 1
+    dev_sync()
+    my_dt = time.perf_counter() - t0     # this rank's own busy time (imbalance shows in per_rank)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     steps_done = int(round(sum_over_ranks(float(my_steps))))
@@ -461,6 +507,9 @@ def main():
     for eng in engines:
         eng.close()
     del engines, probe
+    rank_rec = dict(rank=rank, device=dev, device_name=dev_name, steps=my_steps,
+                    resident_reads_per_s=round(a.reads * my_steps / my_dt, 2) if my_steps else 0.0,
+                    resident_busy_s=round(my_dt, 4))
 
     # ---- phase 2: end to end through the streaming pipeline ---------------------------------
     e2e = None
@@ -468,8 +517,10 @@ def main():
         compact = a.e2e == 'compact'
         if a.stream_batch is None:   # (ranks sharing one device -- a rehearsal -- share its memory too)
             a.stream_batch = 10000 if compact and ndev >= world else 5000
+        # what a reader hands over: one array per read (the FAST5 `Signal` dataset for compact:
+        # int16, RNA in acquisition order -> flipped on the device) and the sequence string
         src = dacs if compact else raws
-        src_stalls = stalls_dac if compact else stalls
+        dev_flip = rna and compact
         if longtail:
             o_s = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name],
                                     skip_norm_out=compact)
@@ -477,38 +528,24 @@ def main():
                                          np.int16 if compact else np.float64, max_reads=a.stream_batch)
         else:
             splan = [np.arange(s, min(s + a.stream_batch, a.reads)) for s in range(0, a.reads, a.stream_batch)]
-        t_pin = time.perf_counter()
-        pool = [streaming.ReadBatch.from_lists(
-            [src[i] for i in idx], [seqs[i] for i in idx],
-            samp_inds=None if si is None else [si[i] for i in idx],
-            stalls=None if src_stalls is None else [src_stalls[i] for i in idx], tag=k, pinned=True)
-            for k, idx in enumerate(splan)]
-        t_pin = time.perf_counter() - t_pin
+        host_draw = a.subsample == 'numpy' and si is not None
         pipe = streaming.StreamPipeline(model, params, n_slots=a.slots, device=dev, outlier_thresh=5.0,
                                         seq_samp_type=samp, want_norm=not compact,
-                                        segs_dtype=np.int32 if compact else np.int64)
-        in_bytes = [b.raw.nbytes + b.seq.nbytes + (0 if b.samp_ind is None else b.samp_ind.nbytes) for b in pool]
-        # warm-up: every slot sees the largest batch once (buffers sized, code paged in); the
-        # transfer rate of one isolated upload is taken on the way
-        big = max(range(len(pool)), key=lambda k: in_bytes[k])
-        for _ in range(2 * a.slots):   # both output sets of every slot get their pinned arrays
-            pipe.submit(pool[big])
-        pipe.flush()
-        eng0 = pipe.slots[0].eng
-        torch.cuda.synchronize()
-        th2d = time.perf_counter()
-        eng0.upload_packed(pipe.params, pipe.opts, pool[big].raw, pool[big].raw_off, pool[big].seq,
-                           pool[big].seq_off, samp_ind=pool[big].samp_ind, stall_ints=pool[big].stall_ints,
-                           stall_off=pool[big].stall_off, wait=True)
-        th2d = time.perf_counter() - th2d
-        # batches of the whole job: K passes over the pool, but never so few that filling and
-        # draining the slots is most of the measurement
-        n_stream = max(len(pool) * a.steps, 2 * a.slots + 2) * world
-        queue = sharding.BatchQueue(n_stream)
-        barrier()
-        t0 = time.perf_counter()
-        cnt = dict(reads=0, ok=0, out=0, moved=0, submit_s=0.0, nb=0)
+                                        segs_dtype=np.int32 if compact else np.int64,
+                                        reverse_raw=dev_flip, stall_params=stall_params,
+                                        subsample_seed=None if host_draw else 20260927 + rank)
+        feeder = streaming.ReadFeeder(n_slots=a.slots, n_threads=workers)
+        pools = [([src[i] for i in idx], [seqs[i] for i in idx], idx) for idx in splan]
+        cnt = dict(reads=0, ok=0, out=0, moved=0, submit_s=0.0, pack_wait_s=0.0, nb=0)
         est = np.zeros(32)
+
+        def start_pack(k):
+            sub_r, sub_s, idx = pools[k]
+            smp = None
+            if host_draw:   # the reference's own draw, per read, on the feeder thread
+                smp = [np.random.choice(int(bases[i]), 1000, replace=False) if bases[i] > 1000 else None
+                       for i in idx]
+            feeder.prefetch(sub_r, sub_s, samp_inds=smp, tag=k)
 
         def consume(res):
             cnt['reads'] += res.n
@@ -516,61 +553,150 @@ def main():
             est[:] += res.stage_ms
             cnt['ok'] += int((res.results['status'] == 0).sum())
             cnt['out'] += res.results.nbytes + res.segs.nbytes + (0 if res.norm is None else res.norm.nbytes)
-        for b in queue:
-            k = b % len(pool)
-            cnt['moved'] += in_bytes[k]
-            ts0 = time.perf_counter()
-            done = pipe.submit(pool[k])
-            cnt['submit_s'] += time.perf_counter() - ts0
-            if done is not None:
+
+        def stream(batch_ids):
+            """pack batch b+1 on the feeder thread while batch b is submitted"""
+            it = iter(batch_ids)
+            nxt = next(it, None)
+            if nxt is not None:
+                start_pack(nxt % len(pools))
+            while nxt is not None:
+                tw = time.perf_counter()
+                batch = feeder.take()
+                cnt['pack_wait_s'] += time.perf_counter() - tw
+                nxt = next(it, None)
+                if nxt is not None:
+                    start_pack(nxt % len(pools))
+                cnt['moved'] += batch.raw.nbytes + batch.seq.nbytes + (0 if batch.samp_ind is None else batch.samp_ind.nbytes)
+                ts0 = time.perf_counter()
+                done = pipe.submit(batch)
+                cnt['submit_s'] += time.perf_counter() - ts0
+                if done is not None:
+                    consume(done)
+            for done in pipe.flush():
                 consume(done)
-        for done in pipe.flush():
-            consume(done)
+        # warm-up: every slot and every staging set sees the largest batch (buffers sized, code
+        # paged in); the transfer rate of one isolated upload is taken on the way
+        big = max(range(len(pools)), key=lambda k: int(n_raw[pools[k][2]].sum()))
+        t_pin = time.perf_counter()
+        stream([big] * (2 * a.slots + 2))
+        t_pin = time.perf_counter() - t_pin
+        wb = feeder.pack(pools[big][0], pools[big][1])
+        dev_sync()
+        th2d = time.perf_counter()
+        pipe.slots[0].eng.upload_packed(pipe.params, pipe.opts, wb.raw, wb.raw_off, wb.seq, wb.seq_off, wait=True)
+        th2d = time.perf_counter() - th2d
+        t_pk = time.perf_counter()
+        feeder.pack(pools[big][0], pools[big][1])
+        t_pk = time.perf_counter() - t_pk
+        big_bytes = wb.raw.nbytes + wb.seq.nbytes
+        for k in cnt:
+            cnt[k] = 0 if isinstance(cnt[k], int) else 0.0
+        est[:] = 0
+        # batches of the whole job: K passes over the pool, but never so few that filling and
+        # draining the slots is most of the measurement
+        n_stream = max(len(pools) * a.steps, 2 * a.slots + 2) * world
+        queue = sharding.BatchQueue(n_stream, key='stream')
+        barrier()
+        t0 = time.perf_counter()
+        stream(queue)
+        dev_sync()
+        my_dt_e = time.perf_counter() - t0
         barrier()
         dt_e = max_over_ranks(time.perf_counter() - t0)
         tot_reads = sum_over_ranks(float(cnt['reads']))
+        rank_rec.update(stream_batches=cnt['nb'], stream_reads_per_s=round(cnt['reads'] / my_dt_e, 2),
+                        stream_busy_s=round(my_dt_e, 4))
         e2e = {
             'value': round(tot_reads / dt_e, 2), 'unit': 'reads/s', 'mode': a.e2e,
-            'what': ('int16 DAC samples + sequence codes + Theil-Sen subsamples in page-locked host '
-                     'memory -> 64-byte record + int32 base boundaries per read in page-locked host '
-                     'memory' if compact else
-                     'float64 samples + sequence codes + subsamples in page-locked host memory -> '
+            'what': ('per-read int16 DAC arrays (RNA: acquisition order) + sequence strings -> packed '
+                     'into page-locked CSR staging by native threads -> upload -> %sfull pipeline '
+                     '(Theil-Sen subsample: %s) -> 64-byte record + int32 base boundaries per read in '
+                     'page-locked host memory' % ('flip + stall detection + ' if rna else '',
+                                                  'np.random.choice on the feeder thread' if host_draw else
+                                                  'drawn on the device') if compact else
+                     'per-read float64 arrays + sequence strings -> packed -> upload -> full pipeline -> '
                      'record + int64 boundaries + float64 normalised signal in page-locked host memory'),
-            'slots_per_gpu': a.slots, 'reads_per_batch': int(np.mean([b.n for b in pool])),
+            'slots_per_gpu': a.slots, 'reads_per_batch': int(np.mean([len(x[2]) for x in pools])),
             'batches': n_stream, 'reads': int(tot_reads), 'seconds': round(dt_e, 4),
             'success_rate': round(sum_over_ranks(float(cnt['ok'])) / max(tot_reads, 1), 4),
             'in_GB_per_10k_reads': round(cnt['moved'] / max(cnt['reads'], 1) * 1e4 / 1e9, 3),
             'out_GB_per_10k_reads': round(cnt['out'] / max(cnt['reads'], 1) * 1e4 / 1e9, 3),
-            'h2d_GBps': round(in_bytes[big] / th2d / 1e9, 2),
+            'h2d_GBps': round(big_bytes / th2d / 1e9, 2),
+            'pack_GBps': round(big_bytes / t_pk / 1e9, 2), 'pack_threads': workers,
             'host_s_in_submit': round(cnt['submit_s'], 4),
+            'host_s_waiting_for_packer': round(cnt['pack_wait_s'], 4),
             'stage_ms_per_batch': {k: round(float(v) / max(cnt['nb'], 1), 3) for k, v in
                                    zip(_native.STAGE_NAMES, est[:16]) if v > 0},
-            'pinned_pool_build_s': round(t_pin, 2)}
+            'warmup_incl_pinning_s': round(t_pin, 2)}
         pipe.close()
+        feeder.close()
+
+    # ---- phase 3 (N = 1): the drop-in API itself -------------------------------------------
+    api = None
+    if world == 1 and a.api_reads > 0 and not longtail:
+        from tombo_amd import resquiggle as rq
+        n_api = min(a.api_reads, a.reads)
+        mk = lambda i, sig: th.resquiggleResults(
+            align_info=th.alignInfo('read_%d' % i, 'BaseCalled_template', 0, 0, 0, 0, int(bases[i]), 0),
+            genome_loc=th.genomeLocation(0, '+', 'synth'), genome_seq=seqs[i], mean_q_score=10.0,
+            raw_signal=sig)
+        # what _io_and_map_read hands the worker: the file's int16 samples (RNA: acquisition order)
+        mrs = [mk(i, dacs[i]) for i in range(n_api)]
+        eng = rq.get_engine(dev)
+        kw = dict(outlier_thresh=5.0, seq_samp_type=samp, engine=eng, reverse_raw=rna, stall_params=stall_params)
+        api = {'reads': n_api, 'raw_dtype': 'int16', 'returns': 'list of resquiggleResults (float64 '
+               'normalised signal + int64 boundaries per read), same as the reference'}
+        for mode, extra in (('numpy_subsample', {}), ('device_subsample', dict(subsample_seed=1))):
+            rq.resquiggle_batch(mrs[:64], model, params, **kw, **extra)    # staging sized, code paged in
+            rq.resquiggle_batch(mrs, model, params, **kw, **extra)
+            t0 = time.perf_counter()
+            res = rq.resquiggle_batch(mrs, model, params, **kw, **extra)
+            dta = time.perf_counter() - t0
+            api['resquiggle_batch_' + mode] = {
+                'reads_per_s': round(n_api / dta, 1), 'seconds': round(dta, 4),
+                'ok': sum(not isinstance(r, Exception) for r in res)}
+        # where the time of one call goes (second mode: no host RNG)
+        t0 = time.perf_counter()
+        for i in range(n_api):
+            np.random.choice(int(bases[i]), 1000, replace=False) if bases[i] > 1000 else None
+        api['host_s_numpy_subsample_draws'] = round(time.perf_counter() - t0, 4)
+        lat = []
+        for i in range(24):   # the worker's per-read sequence: adjust_map_res, then resquiggle_read
+            t0 = time.perf_counter()
+            rq.resquiggle_read(rq.adjust_map_res(mrs[i % n_api], samp), model, params, 5.0, seq_samp_type=samp)
+            lat.append(time.perf_counter() - t0)
+        api['resquiggle_read_latency_ms'] = {'median': round(float(np.median(lat[4:])) * 1e3, 3),
+                                             'p90': round(float(np.percentile(lat[4:], 90)) * 1e3, 3),
+                                             'calls': len(lat) - 4}
+
+    per_rank = [rank_rec]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, rank_rec)
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = a.reads * steps_done / dt
         tot_bases = float(bases.sum())
-        # dominant kernel of THIS configuration: the longest stage of the engine's event brackets
-        # (HIP events on the engine's own stream)
         names = _native.STAGE_NAMES
-        i_dom = int(np.argmax(stage[:14]))
-        dom_ms = float(stage[i_dom])
+        sms = dict(zip(names, [float(x) for x in stage[:16]]))
+        # dominant stage group of THIS configuration (HIP events on the engine's own stream)
+        grp = max(STAGE_GROUPS, key=lambda g: sum(sms.get(k, 0.0) for k in g[1]))
+        dom_ms = sum(sms.get(k, 0.0) for k in grp[1])
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        i_dp = names.index('main_dp')
-        dp_ms = float(stage[i_dp])
+        dp_ms = sms['main_dp']
         traffic = traffic_up = None
-        traffic_note = 'not measured (--no-pmc, N > 1, or already under a profiler)'
+        traffic_note = 'not measured (--no-pmc, or already under a profiler)'
         traffic_kernels = None
-        if world == 1 and not a.no_pmc and not _under_profiler():
-            try:
+        t_pmc = time.perf_counter()
+        if not a.no_pmc and not _under_profiler() and stub is None:
+            try:   # rank 0's child passes, after the timed regions, on rank 0's device
                 sub = np.arange(min(a.pmc_reads, a.reads))
                 packed = pack_lists([raws[i] for i in sub], [seqs[i] for i in sub],
-                                    None if si is None else si[sub],
-                                    None if stalls is None else [stalls[i] for i in sub])
+                                    None if si is None else si[sub])
                 per_raw, per_up, traffic_kernels = measure_pmc_traffic(
-                    packed, dict(samp=samp_name, bandwidth=a.bandwidth))
+                    packed, dict(samp=samp_name, bandwidth=a.bandwidth), device=dev)
                 # the counter passes run a sub-batch of the same reads; traffic scales with the
                 # samples / bases processed
                 scale = float(n_raw.sum()) / float(n_raw[sub].sum())
@@ -582,32 +708,44 @@ def main():
                                 'to every read (upper bound)' % len(sub))
             except Exception as e:  # counters are evidence, not the metric: never fail the bench
                 traffic_note = 'counter passes failed: %s' % (str(e)[:200],)
+        t_pmc = time.perf_counter() - t_pmc
+        rates = [r['resident_reads_per_s'] for r in per_rank if r['steps']]
         res = {
             'metric': 'resquiggle reads/s (%s, bw=%d)' % (
                 '10 kb DNA' if (samp_name, a.bases, longtail) == ('DNA', 10000, False) else
-                'long-tailed 1-100 kb DNA' if longtail else
+                'long-tailed 1-200 kb DNA' if longtail else
                 '%g kb %s' % (a.bases / 1000.0, samp_name), a.bandwidth), 'value': round(value, 2),
             'unit': 'reads/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%d synthetic %s %s reads per GPU per step, bandwidth=%d, full '
-                                   'resquiggle_read path, float64 inputs resident in HBM; %d passes '
+                                   'resquiggle_read path%s, float64 inputs resident in HBM; %d passes '
                                    'drawn from the host work queue by %d rank(s)' % (
-                                       a.reads, 'long-tailed (1-100 kb)' if longtail else '%d-base' % a.bases,
-                                       samp_name, a.bandwidth, a.steps * world, world),
+                                       a.reads, 'long-tailed (1-200 kb)' if longtail else '%d-base' % a.bases,
+                                       samp_name, a.bandwidth,
+                                       ' incl. the worker\'s stall detection (ts.identify_stalls) on the device' if rna else '',
+                                       a.steps * world, world),
                        'reads_per_gpu': a.reads, 'bases': int(a.bases) if not longtail else None,
-                       'mean_bases': round(tot_bases / a.reads, 1), 'bandwidth': a.bandwidth,
+                       'mean_bases': round(tot_bases / a.reads, 1), 'max_bases': int(bases.max()),
+                       'bandwidth': a.bandwidth,
                        'resident_batches_per_gpu': len(plan),
                        'bases_per_s': round(tot_bases * steps_done / dt, 1),
                        'success_rate': round(n_ok / float(a.reads), 4),
                        'parallelism': 'reads sharded over %d process(es) through a shared batch '
-                                      'counter, no collective' % world,
+                                      'counter; no collective on the data path, gloo control plane' % world,
+                       'devices': [r['device'] for r in per_rank], 'visible_devices': ndev,
+                       'ranks_share_devices': ndev < world,
                        'h2d_upload_s': round(t_up, 3),
                        'h2d_upload_GBps_pageable': round(up_bytes / t_up / 1e9, 2),
-                       'synth_generation_s': round(t_gen, 1),
-                       'stage_ms': {k: round(float(v), 3) for k, v in zip(names, stage[:16]) if v > 0}},
+                       'setup_s': {'synthesis': round(t_gen, 1), 'cpu_legs': round(t_cpu, 1),
+                                   'pmc_child_passes': round(t_pmc, 1),
+                                   'total_wall': round(time.perf_counter() - t_start, 1)},
+                       'stage_ms': {k: round(v, 3) for k, v in sms.items() if v > 0}},
+            'per_rank': per_rank,
+            'per_rank_reads_per_s': {'min': min(rates) if rates else None, 'max': max(rates) if rates else None},
             'end_to_end': e2e,
-            'roofline': {'bound': 'hbm', 'kernel': STAGE_KERNEL.get(names[i_dom], names[i_dom]),
+            'api': api,
+            'roofline': {'bound': 'hbm', 'kernel': grp[2], 'stage_group': grp[0],
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 5),
                          'traffic': traffic, 'traffic_fetch_doubled': traffic_up,

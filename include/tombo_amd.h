@@ -121,6 +121,9 @@ int  tba_device_count(void);
 /* free / total bytes of the engine's device (hipMemGetInfo): what a batch planner budgets against */
 int  tba_device_mem(tba_engine *e, int64_t *free_bytes, int64_t *total_bytes);
 
+/* device bytes held by this engine's (grow-only) batch buffers */
+int  tba_engine_held_bytes(tba_engine *e, int64_t *bytes);
+
 /* canonical k-mer level table, lexicographic k-mer order (TomboModel, tombo_stats.py:580-919;
  * lookup replaces get_exp_levels_from_seq :834-862) */
 int tba_set_model(tba_engine *e, const double *kmer_means, const double *kmer_sds,
@@ -396,6 +399,11 @@ int tba_identify_stalls(tba_engine *e, const void *raw, int raw_dtype, int64_t n
 int tba_pack_reads(int64_t n_reads, const void *const *raw_ptrs, int raw_dtype, int reverse,
     const int64_t *raw_off, void *raw_out, const char *const *seq_ptrs, const int64_t *seq_off,
     uint8_t *seq_out, int n_threads);
+
+/* ... and back: count[i] elements of elem_bytes bytes from src + src_off[i] (elements) into
+ * dst_ptrs[i], n_threads threads (per-read result arrays out of one flat download) */
+int tba_unpack_reads(int64_t n_reads, const void *src, int64_t elem_bytes, const int64_t *src_off,
+    const int64_t *count, void *const *dst_ptrs, int n_threads);
 
 /* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build: lets a
  * binding without a C compiler (ctypes) check its struct mirrors */

@@ -1,0 +1,49 @@
+"""`python bench.py --gpus 2` end to end on CPU with a stub engine: the self-launch, the gloo
+control plane, the shared work queue, the feeder / streaming slots and the JSON line of an N > 1
+run (cpu_baseline, roofline and per_rank must be there at every N)."""
+import os
+import sys
+import json
+import subprocess
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def _run(extra):
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'TBA_STORE_PORT'):
+        env.pop(k, None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1', '--reads', '12',
+         '--bases', '400', '--cpu-sample', '2', '--cpu-per-core', '0', '--stream-batch', '5',
+         '--engine-stub', os.path.join(ROOT, 'tests', 'stub_engine.py')] + extra,
+        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [x for x in out.stdout.decode().splitlines() if x.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_line_is_complete():
+    r = _run(['--gpus', '2'])
+    assert r['n_gpus'] == 2 and r['steps'] == 4 and r['scaling'] == 'weak' and r['unit'] == 'reads/s'
+    assert r['cpu_baseline']['kind'] == 'port' and r['cpu_baseline']['value'] > 0
+    assert r['roofline']['bound'] == 'hbm' and r['roofline']['frac'] > 0
+    assert 'traffic' in r['roofline'] and 'kernel' in r['roofline']
+    pr = r['per_rank']
+    assert [x['rank'] for x in pr] == [0, 1]
+    assert all(k in pr[0] for k in ('device', 'steps', 'resident_reads_per_s', 'stream_reads_per_s'))
+    # the queue hands out exactly K * N resident passes and the streamed batches, each once
+    assert sum(x['steps'] for x in pr) == 8
+    assert sum(x['stream_batches'] for x in pr) == r['end_to_end']['batches']
+    assert r['end_to_end']['reads'] > 0 and r['end_to_end']['success_rate'] == 1.0
+    assert 'gloo' in r['config']['parallelism'] and 'RCCL' not in json.dumps(r)
+    assert r['value'] > 0 and r['per_rank_reads_per_s']['min'] <= r['per_rank_reads_per_s']['max']
+
+
+def test_single_rank_bench_line_keys():
+    r = _run(['--api-reads', '0'])
+    assert r['n_gpus'] == 1 and len(r['per_rank']) == 1 and r['per_rank'][0]['steps'] == 4
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+              'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'end_to_end'):
+        assert k in r, k

@@ -215,6 +215,9 @@ class Engine(object):
                                                      self._L.tba_last_error().decode()))
 
     def close(self):
+        if getattr(self, '_stage', None) is not None:
+            self._stage.close()
+            self._stage = None
         if self._h:
             self._L.tba_engine_destroy(self._h)
             self._h = C.c_void_p()
@@ -261,14 +264,7 @@ class Engine(object):
         raw = np.ascontiguousarray(np.concatenate(raws), dtype=dt) \
             if n > 1 else np.ascontiguousarray(raws[0], dtype=dt)
         seq = np.ascontiguousarray(np.concatenate(seqs), dtype=np.uint8)
-        st = sto = None
-        if stall_ints is not None:
-            cnt = [0 if s is None else len(s) for s in stall_ints]
-            sto = np.zeros(n + 1, dtype=np.int64)
-            np.cumsum(cnt, out=sto[1:])
-            rows = [np.array([[int(a), int(b)] for a, b in s], dtype=np.int64).reshape(-1, 2)
-                    for s in stall_ints if s is not None and len(s)]
-            st = np.ascontiguousarray(np.concatenate(rows)) if rows else np.zeros((1, 2), np.int64)
+        st, sto = pack_stalls(stall_ints)
         self.upload_packed(params, opts, raw, raw_off, seq, seq_off, sv_in=sv_in,
                            sv_flags=sv_flags, samp_ind=samp_ind, stall_ints=st, stall_off=sto,
                            wait=True)
@@ -331,6 +327,19 @@ class Engine(object):
         a, b = i64(0), i64(0)
         self._check(self._L.tba_device_mem(self._h, C.byref(a), C.byref(b)), 'tba_device_mem')
         return a.value, b.value
+
+    def held_bytes(self):
+        """device bytes of this engine's grow-only batch buffers"""
+        a = i64(0)
+        self._check(self._L.tba_engine_held_bytes(self._h, C.byref(a)), 'tba_engine_held_bytes')
+        return a.value
+
+    def host_stage(self):
+        """this engine's reusable page-locked staging arrays (PinnedStage)"""
+        st = getattr(self, '_stage', None)
+        if st is None:
+            st = self._stage = PinnedStage()
+        return st
 
     def query(self):
         """True while work of this engine is still in flight (never blocks)"""
@@ -484,37 +493,125 @@ def identify_stalls(eng, raw, sp):
     return out[:cnt.value]
 
 
-def pack_reads(raws, seqs, reverse=False, pinned=False, n_threads=None):
+def pack_stalls(stall_ints):
+    """per-read stall interval lists (None / empty allowed) -> (int64 [m, 2], int64 offsets[n + 1]),
+    or (None, None) for None"""
+    if stall_ints is None:
+        return None, None
+    cnt = [0 if s is None else len(s) for s in stall_ints]
+    sto = np.zeros(len(cnt) + 1, dtype=np.int64)
+    np.cumsum(cnt, out=sto[1:])
+    rows = [np.array([[int(a), int(b)] for a, b in s], dtype=np.int64).reshape(-1, 2)
+            for s in stall_ints if s is not None and len(s)]
+    st = np.ascontiguousarray(np.concatenate(rows)) if rows else np.zeros((1, 2), np.int64)
+    return st, sto
+
+
+class PinnedStage(object):
+    """Grow-only page-locked arrays by name (the staging buffers of one batch slot): `get(name,
+    count, dtype)` returns a view of `count` elements, reallocating (with 1/8 slack) only when the
+    held buffer is too small or of another dtype."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, name, count, dtype):
+        dtype = np.dtype(dtype)
+        count = int(count)
+        pa = self._bufs.get(name)
+        if pa is None or pa.a.dtype != dtype or pa.a.shape[0] < count:
+            if pa is not None:
+                pa.close()
+            pa = PinnedArray(count + count // 8 + 16, dtype)
+            self._bufs[name] = pa
+        return pa.a[:count]
+
+    def close(self):
+        for pa in self._bufs.values():
+            pa.close()
+        self._bufs.clear()
+
+
+def _addr(a):
+    return a.__array_interface__['data'][0]
+
+
+_str_ptr = C.pythonapi.PyUnicode_AsUTF8
+_str_ptr.argtypes = [C.py_object]
+_str_ptr.restype = C.c_void_p
+
+
+def pack_reads(raws, seqs, reverse=False, pinned=False, n_threads=None, stage=None):
     """tba_pack_reads: per-read sample arrays (one dtype of RAW_DTYPES, else float64) and
     sequences (str / bytes of ACGT) -> (raw, raw_off, seq, seq_off, keep) CSR arrays, copied by
-    native threads; `pinned`: the big arrays live in page-locked memory (keep them referenced
-    through `keep`)."""
+    native threads with the GIL released.  `stage` (a PinnedStage): the big arrays are views of its
+    reusable page-locked buffers; else `pinned`: fresh page-locked memory (keep it referenced
+    through `keep`); else plain numpy arrays."""
     L = lib()
     n = len(raws)
-    raws = [np.asarray(r) for r in raws]
-    dts = set(r.dtype for r in raws)
-    dt = next(iter(dts)) if len(dts) == 1 and next(iter(dts)) in RAW_DTYPES else np.dtype(np.float64)
-    raws = [r if r.dtype == dt and r.flags.c_contiguous else np.ascontiguousarray(r, dtype=dt)
-            for r in raws]
-    seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    dt = None
+    for r in raws:
+        if not isinstance(r, np.ndarray) or (dt is not None and r.dtype != dt) or \
+                not r.flags.c_contiguous:
+            dt = False
+            break
+        dt = r.dtype
+    if dt is False or dt is None or dt not in RAW_DTYPES:
+        raws = [np.asarray(r) for r in raws]
+        dts = set(r.dtype for r in raws)
+        dt = next(iter(dts)) if len(dts) == 1 and next(iter(dts)) in RAW_DTYPES else np.dtype(np.float64)
+        raws = [r if r.dtype == dt and r.flags.c_contiguous else np.ascontiguousarray(r, dtype=dt)
+                for r in raws]
+    # sequences: the UTF-8 view of a str is its own buffer for ASCII text (no copy); the strings
+    # themselves stay referenced by the caller's list for the duration of the call
+    seq_ptr = [_str_ptr(s) if type(s) is str else None for s in seqs]
+    if None in seq_ptr:
+        seqs = [s if type(s) is str else bytes(s) for s in seqs]
+        seq_ptr = [_str_ptr(s) if type(s) is str else C.cast(C.c_char_p(s), C.c_void_p).value
+                   for s in seqs]
     raw_off = np.zeros(n + 1, np.int64)
     np.cumsum([r.shape[0] for r in raws], out=raw_off[1:])
     seq_off = np.zeros(n + 1, np.int64)
     np.cumsum([len(s) for s in seqs], out=seq_off[1:])
+    if any(not s.isascii() for s in seqs if type(s) is str):
+        raise ValueError('sequences must be ASCII')
     keep = []
-    if pinned:
+    if stage is not None:
+        raw, seq = stage.get('raw', raw_off[-1], dt), stage.get('seq', seq_off[-1], np.uint8)
+    elif pinned:
         pr, ps = PinnedArray(int(raw_off[-1]), dt), PinnedArray(int(seq_off[-1]), np.uint8)
         keep = [pr, ps]
         raw, seq = pr.a, ps.a
     else:
         raw, seq = np.empty(int(raw_off[-1]), dt), np.empty(int(seq_off[-1]), np.uint8)
-    rp = (C.c_void_p * n)(*[r.ctypes.data for r in raws])
-    sp = (C.c_char_p * n)(*seqs)
+    rp = (C.c_void_p * n)(*[_addr(r) for r in raws])
+    sp = (C.c_void_p * n)(*seq_ptr)
     if n_threads is None:
         n_threads = min(16, os.cpu_count() or 1)
     rc = L.tba_pack_reads(i64(n), rp, C.c_int(RAW_DTYPES[dt]), C.c_int(int(bool(reverse))),
-                          _p(raw_off, i64), raw.ctypes.data_as(C.c_void_p), sp, _p(seq_off, i64),
-                          seq.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(int(n_threads)))
+                          _p(raw_off, i64), C.c_void_p(_addr(raw)), sp, _p(seq_off, i64),
+                          C.cast(C.c_void_p(_addr(seq)), C.POINTER(C.c_uint8)), C.c_int(int(n_threads)))
     if rc != 0:
         raise EngineError('tba_pack_reads failed (%d): %s' % (rc, L.tba_last_error().decode()))
     return raw, raw_off, seq, seq_off, keep
+
+
+def unpack_reads(src, src_off, count, dtype=None, n_threads=None):
+    """tba_unpack_reads: [src[src_off[i]:src_off[i] + count[i]].copy() for i], the copies made
+    by native threads into fresh per-read arrays"""
+    L = lib()
+    n = len(count)
+    dt = src.dtype if dtype is None else np.dtype(dtype)
+    outs = [np.empty(int(c), dt) for c in count]
+    if n == 0:
+        return outs
+    so = np.ascontiguousarray(src_off, dtype=np.int64)
+    cnt = np.ascontiguousarray(count, dtype=np.int64)
+    dp = (C.c_void_p * n)(*[_addr(o) for o in outs])
+    if n_threads is None:
+        n_threads = min(16, os.cpu_count() or 1)
+    rc = L.tba_unpack_reads(i64(n), C.c_void_p(_addr(src)), i64(dt.itemsize), _p(so, i64),
+                            _p(cnt, i64), dp, C.c_int(int(n_threads)))
+    if rc != 0:
+        raise EngineError('tba_unpack_reads failed (%d): %s' % (rc, L.tba_last_error().decode()))
+    return outs

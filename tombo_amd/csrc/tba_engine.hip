@@ -1684,3 +1684,48 @@ extern "C" int tba_abi_sizes(int64_t *out, int64_t n)
     out[2] = (int64_t)sizeof(tba_read_result);
     return 0;
 }
+
+// the other direction: slices of one flat result array -> one destination array per read
+extern "C" int tba_unpack_reads(int64_t n_reads, const void *src, int64_t elem_bytes,
+    const int64_t *src_off, const int64_t *count, void *const *dst_ptrs, int n_threads)
+{
+    if (n_reads < 0 || elem_bytes < 1 || (n_reads > 0 && (!src || !src_off || !count || !dst_ptrs)))
+        return set_err(TBA_E_ARG, "bad arguments");
+    auto work = [&](i64 a, i64 b) {
+        for (i64 i = a; i < b; i++)
+            if (count[i] > 0 && dst_ptrs[i])
+                memcpy(dst_ptrs[i], (const char *)src + (size_t)src_off[i] * (size_t)elem_bytes,
+                       (size_t)count[i] * (size_t)elem_bytes);
+    };
+    const int nt = std::max(1, std::min<int>(n_threads, (int)std::min<i64>(n_reads, 256)));
+    if (nt == 1) { work(0, n_reads); return 0; }
+    std::vector<i64> acc((size_t)n_reads + 1, 0);
+    for (i64 i = 0; i < n_reads; i++) acc[(size_t)i + 1] = acc[(size_t)i] + std::max<i64>(count[i], 0) + 64;
+    std::vector<std::thread> th;
+    i64 a = 0;
+    for (int t = 0; t < nt; t++) {
+        const i64 goal = acc[(size_t)n_reads] / nt * (t + 1);
+        i64 b = t == nt - 1 ? n_reads : (i64)(std::upper_bound(acc.begin(), acc.end(), goal) - acc.begin()) - 1;
+        b = std::max(a, std::min(b, n_reads));
+        if (b > a) th.emplace_back(work, a, b);
+        a = b;
+    }
+    for (auto &x : th) x.join();
+    return 0;
+}
+
+// device bytes this engine's grow-only buffers hold right now (a planner budgets against the
+// free memory PLUS this: a batch that fitted before still fits)
+extern "C" int tba_engine_held_bytes(tba_engine *e, int64_t *bytes)
+{
+    if (!e || !bytes) return set_err(TBA_E_ARG, "bad arguments");
+    size_t tot = 0;
+    DevBuf *all[] = {&e->d_rs, &e->d_dp, &e->d_kmeans, &e->d_ksds, &e->d_raw, &e->d_norm, &e->d_norm_out, &e->d_csum,
+                     &e->d_score, &e->d_state, &e->d_cpts, &e->d_evm, &e->d_seq, &e->d_refm, &e->d_refs, &e->d_bst,
+                     &e->d_lo, &e->d_hi, &e->d_readtb, &e->d_dpsegs, &e->d_segs, &e->d_win, &e->d_absz,
+                     &e->d_sv_in, &e->d_samp, &e->d_stall, &e->d_lastrow, &e->d_startvals, &e->d_smoves,
+                     &e->d_moves, &e->d_dscr, &e->d_wide, &e->d_stat, &e->d_res, &e->d_segs32, &e->d_skipq};
+    for (DevBuf *b : all) tot += b->cap;
+    *bytes = (int64_t)tot;
+    return 0;
+}

@@ -54,17 +54,30 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                      min_event_to_seq_ratio=MIN_EVENT_TO_SEQ_RATIO, const_scale=None,
                      skip_seq_scaling=False,
                      seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False),
-                     samp_inds=None, engine=None, return_debug=False, mem_budget=None):
+                     samp_inds=None, engine=None, return_debug=False, mem_budget=None,
+                     reverse_raw=False, stall_params=None, subsample_seed=None):
     """resquiggle_read over a list of `resquiggleResults` (mapping results).
 
     Returns a list with, per read, either a `resquiggleResults` or a `TomboError` instance
     (same message the reference raises).  `samp_inds[i]`: optional precomputed Theil-Sen
     subsample for read i (1000 indices); when omitted it is drawn from numpy's global RNG in
-    read order for every read longer than 1000 bases.
+    read order for every read longer than 1000 bases -- or, with `subsample_seed` (an int), on
+    the device by a keyed permutation (the reference's production RNG is unseeded; the numpy
+    draw costs 0.1 ms per 10 kb read on the host and is the default for seeded callers).
+
+    `reverse_raw` / `stall_params`: the worker's RNA preparation (`adjust_map_res`,
+    resquiggle.py:1506-1530) as part of the batch: the signal is flipped and
+    `ts.identify_stalls` runs on the device; the returned results then carry the flipped
+    signal's `stall_ints` like the worker's `map_res` does.
 
     A list of any size is accepted: when its device footprint (`tba_batch_footprint`) exceeds
-    `mem_budget` bytes (default: 60 % of the device memory that is free right now) the list is
-    cut into consecutive sub-batches that fit and the results are returned in input order.
+    `mem_budget` bytes (default: 60 % of the device memory that is free or already held by this
+    engine) the list is cut into consecutive sub-batches that fit and the results are returned
+    in input order.
+
+    Marshalling is native: the per-read arrays are packed into page-locked CSR staging by
+    threads (`tba_pack_reads`), transfers are DMA, and the per-read result arrays are cut out of
+    the flat downloads by threads (`tba_unpack_reads`).
     """
     eng = get_engine() if engine is None else engine
     n = len(map_results)
@@ -72,100 +85,121 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
         return []
     eng.ensure_model(std_ref)
     K = std_ref.kmer_width
-    if n > 1 and not return_debug:
-        from . import planner
-        if mem_budget is None:
-            mem_budget = 0.6 * eng.device_mem()[0]
-        p_ = _native.make_params(rsqgl_params)
-        o_ = _native.make_opts(min_event_to_seq_ratio=min_event_to_seq_ratio)
-        n_raw = [0 if (mr.raw_signal if all_raw_signals is None or all_raw_signals[i] is None
-                       else all_raw_signals[i]) is None else
-                 len(mr.raw_signal if all_raw_signals is None or all_raw_signals[i] is None
-                     else all_raw_signals[i]) for i, mr in enumerate(map_results)]
-        seq_len = [len(mr.genome_seq) for mr in map_results]
-        if n > planner.MAX_READS or planner.exact_bytes(n_raw, seq_len, p_, o_, K) > mem_budget:
-            # consecutive cuts (sort=False): the Theil-Sen subsamples are drawn from the global
-            # RNG in read order, exactly as for one big batch
-            parts = planner.plan_batches(n_raw, seq_len, p_, o_, K, mem_budget, sort=False)
-            out = []
-            for idx in parts:
-                a, b = int(idx[0]), int(idx[-1]) + 1
-                out.extend(resquiggle_batch(
-                    map_results[a:b], std_ref, rsqgl_params, outlier_thresh=outlier_thresh,
-                    all_raw_signals=None if all_raw_signals is None else all_raw_signals[a:b],
-                    max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
-                    const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
-                    seq_samp_type=seq_samp_type,
-                    samp_inds=None if samp_inds is None else samp_inds[a:b], engine=eng,
-                    mem_budget=float('inf')))
-            return out
-    raws, seqs = [], []
+    raws = []
     pre_err = [None] * n
-    sv_in = np.zeros((n, 4))
-    sv_flags = np.zeros(n, np.int32)
-    any_sv = False
-    stalls = []
     for i, mr in enumerate(map_results):
         raw = mr.raw_signal if all_raw_signals is None or all_raw_signals[i] is None \
             else all_raw_signals[i]
         if raw is None:
             pre_err[i] = th.TomboError(errors.MESSAGES[21])
             raw = np.zeros(1)
-        # int16 DAC (the FAST5 `Signal`) and float32 go to the device as they are; the engine
-        # widens them to float64 exactly
-        raw = np.asarray(raw)
-        raws.append(np.ascontiguousarray(
-            raw, dtype=raw.dtype if raw.dtype in _native.RAW_DTYPES else np.float64))
-        codes = ts.encode_seq(mr.genome_seq)
-        seqs.append(codes)
-        if mr.scale_values is not None:
+        raws.append(raw if isinstance(raw, np.ndarray) else np.asarray(raw))
+    if n > 1 and not return_debug:
+        from . import planner
+        if mem_budget is None:
+            mem_budget = max(0.6 * (eng.device_mem()[0] + eng.held_bytes()), float(2 << 30))
+        p_ = _native.make_params(rsqgl_params)
+        o_ = _native.make_opts(min_event_to_seq_ratio=min_event_to_seq_ratio)
+        n_raw = [r.shape[0] for r in raws]
+        seq_len = [len(mr.genome_seq) for mr in map_results]
+        # (page-locked staging holds the batch once on the way in and once on the way out)
+        host_cap = 1 << 30   # samples per sub-batch
+        if n > planner.MAX_READS or sum(n_raw) > host_cap or \
+                planner.exact_bytes(n_raw, seq_len, p_, o_, K) > mem_budget:
+            # consecutive cuts (sort=False): the Theil-Sen subsamples are drawn from the global
+            # RNG in read order, exactly as for one big batch
+            parts = planner.plan_batches(n_raw, seq_len, p_, o_, K, mem_budget, sort=False)
+            cuts = []
+            for idx in parts:   # ... and by host staging
+                a0, acc = int(idx[0]), 0
+                for i in idx:
+                    if acc + n_raw[i] > host_cap and i > a0:
+                        cuts.append((a0, int(i)))
+                        a0, acc = int(i), 0
+                    acc += n_raw[i]
+                cuts.append((a0, int(idx[-1]) + 1))
+            if len(cuts) > 1:
+                out = []
+                for k, (a, b) in enumerate(cuts):
+                    out.extend(resquiggle_batch(
+                        map_results[a:b], std_ref, rsqgl_params, outlier_thresh=outlier_thresh,
+                        all_raw_signals=None if all_raw_signals is None else all_raw_signals[a:b],
+                        max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
+                        const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
+                        seq_samp_type=seq_samp_type,
+                        samp_inds=None if samp_inds is None else samp_inds[a:b], engine=eng,
+                        mem_budget=float('inf'), reverse_raw=reverse_raw, stall_params=stall_params,
+                        subsample_seed=None if subsample_seed is None else subsample_seed + 7919 * k))
+                return out
+    stage = eng.host_stage()
+    raw, raw_off, seq, seq_off, _ = _native.pack_reads(
+        raws, [mr.genome_seq for mr in map_results], stage=stage)
+    sv_in = sv_flags = None
+    if any(mr.scale_values is not None for mr in map_results):
+        sv_in = np.zeros((n, 4))
+        sv_flags = np.zeros(n, np.int32)
+        for i, mr in enumerate(map_results):
             sv = mr.scale_values
-            any_sv = True
+            if sv is None:
+                continue
             sv_in[i, 0], sv_in[i, 1] = sv.shift, sv.scale
             sv_flags[i] = 1
             if sv.lower_lim is not None and sv.upper_lim is not None:
                 sv_in[i, 2], sv_in[i, 3] = sv.lower_lim, sv.upper_lim
                 sv_flags[i] |= 2
-        stalls.append(mr.stall_ints)
-    any_stall = any(s is not None and len(s) for s in stalls)
+    st = sto = None
+    if stall_params is None:
+        stalls = [mr.stall_ints for mr in map_results]
+        if any(s is not None and len(s) for s in stalls):
+            st, sto = _native.pack_stalls(stalls)
+    nb = np.diff(seq_off) - K + 1
     si = None
-    if not skip_seq_scaling:
-        nb = [len(mr.genome_seq) - K + 1 for mr in map_results]
-        if any(b > MAX_POINTS_FOR_THEIL_SEN for b in nb):
-            si = np.zeros((n, MAX_POINTS_FOR_THEIL_SEN), np.int64)
-            for i, b in enumerate(nb):
-                if b > MAX_POINTS_FOR_THEIL_SEN:
-                    si[i] = _draw_samp_ind(b) if samp_inds is None or samp_inds[i] is None \
-                        else samp_inds[i]
+    if not skip_seq_scaling and subsample_seed is None and (nb > MAX_POINTS_FOR_THEIL_SEN).any():
+        si = stage.get('si', n * MAX_POINTS_FOR_THEIL_SEN, np.int64).reshape(n, MAX_POINTS_FOR_THEIL_SEN)
+        for i in np.flatnonzero(nb > MAX_POINTS_FOR_THEIL_SEN):
+            si[i] = _draw_samp_ind(int(nb[i])) if samp_inds is None or samp_inds[i] is None \
+                else samp_inds[i]
     p = _native.make_params(rsqgl_params)
     o = _native.make_opts(
         outlier_thresh=outlier_thresh, const_scale=const_scale,
         skip_seq_scaling=skip_seq_scaling,
         sig_match_thresh=None if seq_samp_type is None else SIG_MATCH_THRESH[seq_samp_type.name],
-        max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio)
-    eng.upload(p, o, raws, seqs, sv_in=sv_in if any_sv else None,
-               sv_flags=sv_flags if any_sv else None, samp_ind=si,
-               stall_ints=stalls if any_stall else None)
-    eng.run()
-    out = eng.download()
-    results = []
+        max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
+        reverse_raw=reverse_raw, stall_params=stall_params, subsample_seed=subsample_seed)
+    eng.upload_packed(p, o, raw, raw_off, seq, seq_off, sv_in=sv_in, sv_flags=sv_flags,
+                      samp_ind=si, stall_ints=st, stall_off=sto)
+    eng.enqueue()
+    if return_debug:
+        eng.sync()
+        out = eng.download()
+        o_res = None
+    else:
+        o_res = stage.get('res', n, _native.RESULT_DTYPE)
+        o_segs = stage.get('segs', int(eng.seg_off[-1]), np.int64)
+        o_norm = stage.get('norm', eng.n_raw_total, np.float64)
+        eng.download_async(results=o_res, segs64=o_segs, norm=o_norm)
+        eng.sync()
+        out = dict(status=o_res['status'], read_start=o_res['read_start_rel_to_raw'],
+                   norm_len=o_res['norm_len'], score=o_res['sig_match_score'],
+                   changed=o_res['norm_params_changed'],
+                   sv=np.stack([o_res['shift'], o_res['scale'], o_res['lower_lim'],
+                                o_res['upper_lim']], axis=1))
+    status = np.asarray(out['status'])
+    ok = np.flatnonzero((status == 0) & np.array([e is None for e in pre_err]))
+    if o_res is not None:
+        segs_l = _native.unpack_reads(o_segs, eng.seg_off[:-1][ok], nb[ok] + 1)
+        norm_l = _native.unpack_reads(o_norm, raw_off[:-1][ok], out['norm_len'][ok])
+    else:
+        segs_l = [out['segs'][eng.seg_off[i]:eng.seg_off[i + 1]].copy() for i in ok]
+        norm_l = [out['norm'][eng.raw_off[i]:eng.raw_off[i] + int(out['norm_len'][i])].copy() for i in ok]
+    dev_stalls = eng.stall_ints() if stall_params is not None else None
+    results = [None] * n
     cp = std_ref.central_pos
     dn = K - cp - 1
-    for i, mr in enumerate(map_results):
-        if pre_err[i] is not None:
-            results.append(pre_err[i])
-            continue
-        st = int(out['status'][i])
-        if st != 0:
-            if st in errors.MESSAGES:
-                results.append(th.TomboError(errors.MESSAGES[st]))
-            else:
-                results.append(RuntimeError('Unexpected error in resquiggle engine (status %d)' % st))
-            continue
-        segs = out['segs'][eng.seg_off[i]:eng.seg_off[i + 1]].copy()
-        nl = int(out['norm_len'][i])
-        norm = out['norm'][eng.raw_off[i]:eng.raw_off[i] + nl].copy()
-        sv = out['sv'][i]
+    svs, rstart, score, changed = out['sv'], out['read_start'], out['score'], out['changed']
+    for k, i in enumerate(ok):
+        mr = map_results[i]
+        sv = svs[i]
         lo = None if np.isnan(sv[2]) else float(sv[2])
         hi = None if np.isnan(sv[3]) else float(sv[3])
         # scaleValues.outlier_thresh: the reference stores the argument after sequence
@@ -176,12 +210,25 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                 ot = None
         else:
             ot = outlier_thresh
-        results.append(mr._replace(
-            read_start_rel_to_raw=int(out['read_start'][i]), segs=segs,
-            genome_seq=mr.genome_seq[cp:len(mr.genome_seq) - dn], raw_signal=norm,
+        res = mr._replace(
+            read_start_rel_to_raw=int(rstart[i]), segs=segs_l[k],
+            genome_seq=mr.genome_seq[cp:len(mr.genome_seq) - dn], raw_signal=norm_l[k],
             scale_values=th.scaleValues(float(sv[0]), float(sv[1]), lo, hi, ot),
-            sig_match_score=float(out['score'][i]),
-            norm_params_changed=bool(out['changed'][i])))
+            sig_match_score=float(score[i]), norm_params_changed=bool(changed[i]))
+        if dev_stalls is not None:
+            res = res._replace(stall_ints=[list(map(int, x)) for x in dev_stalls[i]])
+        results[i] = res
+    for i in range(n):
+        if results[i] is not None:
+            continue
+        if pre_err[i] is not None:
+            results[i] = pre_err[i]
+            continue
+        st_i = int(status[i])
+        if st_i in errors.MESSAGES:
+            results[i] = th.TomboError(errors.MESSAGES[st_i])
+        else:
+            results[i] = RuntimeError('Unexpected error in resquiggle engine (status %d)' % st_i)
     if return_debug:
         return results, out
     return results
@@ -397,11 +444,11 @@ def adjust_map_res(map_res, seq_samp_type):
 
 
 def _run_iters(map_results, idx, std_ref, params, outlier_thresh, const_scale, skip_seq_scaling,
-               seq_samp_type, max_scaling_iters, engine, n_passes):
+               seq_samp_type, max_scaling_iters, engine, n_passes, prep):
     """run_rsqgl_iters (resquiggle.py:1492-1504) for the reads `idx`, round by round"""
     res = dict(zip(idx, resquiggle_batch(
         [map_results[i] for i in idx], std_ref, params, outlier_thresh, const_scale=const_scale,
-        skip_seq_scaling=skip_seq_scaling, seq_samp_type=seq_samp_type, engine=engine)))
+        skip_seq_scaling=skip_seq_scaling, seq_samp_type=seq_samp_type, engine=engine, **prep)))
     for i in idx:
         n_passes[i] += 1
     n_iters = 1
@@ -415,7 +462,7 @@ def _run_iters(map_results, idx, std_ref, params, outlier_thresh, const_scale, s
         sub = resquiggle_batch(
             [map_results[i]._replace(scale_values=res[i].scale_values) for i in again], std_ref,
             params, outlier_thresh, all_raw_signals=[map_results[i].raw_signal for i in again],
-            seq_samp_type=seq_samp_type, engine=engine)
+            seq_samp_type=seq_samp_type, engine=engine, **prep)
         for i, r in zip(again, sub):
             res[i] = r
             n_passes[i] += 1
@@ -426,7 +473,8 @@ def _run_iters(map_results, idx, std_ref, params, outlier_thresh, const_scale, s
 def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
                            outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
                            seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False),
-                           max_scaling_iters=None, engine=None, return_passes=False):
+                           max_scaling_iters=None, engine=None, return_passes=False,
+                           device_prep=False, subsample_seed=None):
     """The per-read loop of `_resquiggle_worker` (resquiggle.py:1578-1589) over a batch.
 
     Every read is resquiggled; while `norm_params_changed` it is re-run with the fitted
@@ -438,20 +486,30 @@ def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
     so the Theil-Sen subsamples are drawn from numpy's global RNG in round-major order instead
     of the worker's read-major order; each individual pass is the same computation as
     `resquiggle_read` with the subsample it was handed.
+
+    `device_prep`: `map_results` are the mapped reads as `_io_and_map_read` left them (RNA signal
+    in acquisition order, no `stall_ints`) and `adjust_map_res` -- the flip and
+    `ts.identify_stalls` -- happens on the device inside every pass.
     """
     from ._default_parameters import MAX_SCALING_ITERS
     if max_scaling_iters is None:
         max_scaling_iters = MAX_SCALING_ITERS
     n = len(map_results)
     n_passes = [0] * n
+    prep = dict(subsample_seed=subsample_seed)
+    if device_prep:
+        from ._default_parameters import COLLAPSE_RNA_STALLS, STALL_PARAMS
+        rna = seq_samp_type is not None and seq_samp_type.name == RNA_SAMP_TYPE
+        prep.update(reverse_raw=rna, stall_params=th.stallParams(**STALL_PARAMS)
+                    if rna and COLLAPSE_RNA_STALLS else None)
     res = _run_iters(map_results, list(range(n)), std_ref, rsqgl_params, outlier_thresh,
                      const_scale, skip_seq_scaling, seq_samp_type, max_scaling_iters, engine,
-                     n_passes)
+                     n_passes, prep)
     failed = [i for i in range(n) if isinstance(res[i], Exception)]
     if failed and save_params is not None:
         res.update(_run_iters(map_results, failed, std_ref, save_params, outlier_thresh,
                               const_scale, skip_seq_scaling, seq_samp_type, max_scaling_iters,
-                              engine, n_passes))
+                              engine, n_passes, prep))
     out = [res[i] for i in range(n)]
     return (out, n_passes) if return_passes else out
 

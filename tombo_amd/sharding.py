@@ -10,12 +10,13 @@ assignment -- not a static split -- because batches differ in cost (read lengths
 speed.  A rank only ever materialises the batches it drew (`load_batch(b)` reads / generates
 them); results stay on the rank that produced them unless a `sink` ships them elsewhere.
 
-The counter lives in a `torch.distributed.TCPStore` of its own (public API; rank 0 hosts it on a
-free port that it announces through the default process group).  Without an initialised process
-group (world size 1) the queue is a plain local counter.
+The counter lives in a `torch.distributed.TCPStore` of its own (public API; rank 0 lets the
+kernel pick the port when it binds the store -- no bind / close / rebind race -- and announces
+it through the default process group).  Without an initialised process group (world size 1)
+the queue is a plain local counter.  The default process group only carries control messages
+(the port, queue ids): any backend works, `gloo` is what a resquiggle job needs.
 """
 import os
-import socket
 
 __all__ = ['BatchQueue', 'split_batches', 'run_sharded', 'resquiggle_sharded']
 
@@ -41,14 +42,16 @@ def _queue_store():
     rank, world = dist.get_rank(), dist.get_world_size()
     host = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = [0]
-    if rank == 0:
-        s = socket.socket()
-        s.bind(('', 0))
-        port[0] = s.getsockname()[1]
-        s.close()
+    store = None
+    if rank == 0:   # port 0: the listening socket is bound once, by the store itself
+        store = dist.TCPStore(host, 0, world, is_master=True, timeout=timedelta(seconds=300),
+                              wait_for_workers=False)
+        port[0] = store.port
     dist.broadcast_object_list(port, src=0)
-    _STORE = dist.TCPStore(host, int(port[0]), world, is_master=(rank == 0),
-                           timeout=timedelta(seconds=300), wait_for_workers=False)
+    if rank != 0:
+        store = dist.TCPStore(host, int(port[0]), world, is_master=False,
+                              timeout=timedelta(seconds=300))
+    _STORE = store
     dist.barrier()
     return _STORE
 
@@ -61,9 +64,11 @@ def split_batches(n_reads, batch_size):
 class BatchQueue(object):
     """Iterator over the batch indices this rank draws from the shared counter.
 
-    Every rank must construct its queues in the same order (the n-th queue of a process talks to
-    the n-th counter); a counter is used once, so calling the same job function twice never sees
-    a stale, already exhausted counter."""
+    Constructing a queue is a collective of the default process group: rank 0 announces the
+    queue's id (its own count of queues so far, the job key and the batch count) and every rank
+    checks it against its own -- a rank that skipped a job, or disagrees about its size, fails
+    loudly here instead of silently drawing from another job's counter.  A counter is used once,
+    so calling the same job function twice never sees a stale, already exhausted counter."""
 
     def __init__(self, n_batches, key=None):
         global _N_QUEUES
@@ -73,7 +78,14 @@ class BatchQueue(object):
         self.drawn = []
         if self._dist is not None and self._dist.get_world_size() > 1:
             self._store = _queue_store()
-            self._key = 'tombo_amd/queue/%d/%s' % (_N_QUEUES, key if key is not None else '')
+            mine = [_N_QUEUES, '' if key is None else str(key), self.n_batches]
+            ann = list(mine)
+            self._dist.broadcast_object_list(ann, src=0)
+            if ann != mine:
+                raise RuntimeError('work queues out of step: rank 0 opens queue %r, rank %d expected %r '
+                                   '(every rank must run the same jobs in the same order)' %
+                                   (ann, self._dist.get_rank(), mine))
+            self._key = 'tombo_amd/queue/%d/%s' % (ann[0], ann[1])
             _N_QUEUES += 1
         else:
             self._store = None

@@ -23,9 +23,10 @@ import numpy as np
 from . import _native
 from . import tombo_helper as th
 from ._default_parameters import (
-    MAX_RAW_CPTS, MIN_EVENT_TO_SEQ_RATIO, SIG_MATCH_THRESH, DNA_SAMP_TYPE)
+    MAX_RAW_CPTS, MIN_EVENT_TO_SEQ_RATIO, SIG_MATCH_THRESH, DNA_SAMP_TYPE,
+    MAX_POINTS_FOR_THEIL_SEN)
 
-__all__ = ['ReadBatch', 'BatchResults', 'StreamPipeline']
+__all__ = ['ReadBatch', 'BatchResults', 'StreamPipeline', 'ReadFeeder']
 
 
 class ReadBatch(object):
@@ -64,6 +65,13 @@ class ReadBatch(object):
             raw[raw_off[i]:raw_off[i + 1]] = raws[i]
             seq[seq_off[i]:seq_off[i + 1]] = seqs[i]
         si = None
+        if samp_inds is not None and any(s is None and len(q) > MAX_POINTS_FOR_THEIL_SEN + 16
+                                         for s, q in zip(samp_inds, seqs)):
+            # (zero-filled rows would fit a line through base 0 a thousand times: a silently
+            # wrong scale; the engine cannot tell a missing subsample from a given one)
+            raise ValueError('samp_inds has no entry for a read longer than %d bases; pass one per '
+                             'long read, or None for all and subsample_seed to the pipeline' %
+                             MAX_POINTS_FOR_THEIL_SEN)
         if samp_inds is not None and any(s is not None for s in samp_inds):
             if pinned:
                 psi = _native.PinnedArray((n, 1000), np.int64)
@@ -142,7 +150,7 @@ class StreamPipeline(object):
                  seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False), const_scale=None,
                  skip_seq_scaling=False, max_raw_cpts=MAX_RAW_CPTS,
                  min_event_to_seq_ratio=MIN_EVENT_TO_SEQ_RATIO, want_norm=False,
-                 segs_dtype=np.int32):
+                 segs_dtype=np.int32, reverse_raw=False, stall_params=None, subsample_seed=None):
         from . import resquiggle as rq
         if device is None:
             device = rq.default_device()
@@ -156,7 +164,9 @@ class StreamPipeline(object):
             skip_seq_scaling=skip_seq_scaling,
             sig_match_thresh=None if seq_samp_type is None else SIG_MATCH_THRESH[seq_samp_type.name],
             max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
-            skip_norm_out=not want_norm)
+            skip_norm_out=not want_norm, reverse_raw=reverse_raw, stall_params=stall_params,
+            subsample_seed=subsample_seed)
+        self.subsample_seed = subsample_seed
         self.want_norm = bool(want_norm)
         self.segs_dtype = np.dtype(segs_dtype)
         assert self.segs_dtype in (np.dtype(np.int32), np.dtype(np.int64))
@@ -181,6 +191,9 @@ class StreamPipeline(object):
         self._next = (self._next + 1) % len(self.slots)
         done = self._finish(slot) if slot.pending is not None else None
         eng = slot.eng
+        if self.subsample_seed is not None:   # another key for every batch of the job
+            self.opts.subsample_seed = (int(self.subsample_seed) + 0x9e3779b97f4a7c15 * self.n_submitted) \
+                & 0xffffffffffffffff
         eng.upload_packed(self.params, self.opts, batch.raw, batch.raw_off, batch.seq,
                           batch.seq_off, samp_ind=batch.samp_ind, stall_ints=batch.stall_ints,
                           stall_off=batch.stall_off)
@@ -224,3 +237,59 @@ class StreamPipeline(object):
                     pa.close()
                 o.clear()
             s.eng.close()
+
+
+class ReadFeeder(object):
+    """Per-read arrays -> `ReadBatch`es in reusable page-locked staging, one batch ahead.
+
+    The reader of the reference's worker pool (`_io_and_map_read`, resquiggle.py:1385-1486) hands
+    over one read at a time; a batch engine wants flat CSR buffers.  `pack(raws, seqs)` copies the
+    reads of one batch into the next of `n_stages` staging sets with native threads
+    (`tba_pack_reads`, GIL released); `prefetch` does the same on a helper thread while the caller
+    submits the previous batch.  A staging set may be reused once the batch packed into it has
+    been finished by the pipeline: with `n_slots` batches in flight and one being packed,
+    `n_slots + 2` sets rotate safely.
+    """
+
+    def __init__(self, n_slots=3, reverse=False, n_threads=None):
+        from concurrent.futures import ThreadPoolExecutor
+        self.stages = [_native.PinnedStage() for _ in range(int(n_slots) + 2)]
+        self.reverse, self.n_threads = bool(reverse), n_threads
+        self._k = 0
+        self._ex = ThreadPoolExecutor(1)
+        self._pending = None
+
+    def pack(self, raws, seqs, samp_inds=None, stalls=None, tag=None):
+        """one batch, packed now; seqs: str / bytes of ACGT"""
+        stage = self.stages[self._k % len(self.stages)]
+        self._k += 1
+        raw, raw_off, seq, seq_off, _ = _native.pack_reads(
+            raws, seqs, reverse=self.reverse, stage=stage, n_threads=self.n_threads)
+        si = None
+        if samp_inds is not None:
+            n = len(raws)
+            si = stage.get('si', n * MAX_POINTS_FOR_THEIL_SEN, np.int64).reshape(n, MAX_POINTS_FOR_THEIL_SEN)
+            for i, s in enumerate(samp_inds):
+                if s is not None:
+                    si[i] = s
+                elif len(seqs[i]) > MAX_POINTS_FOR_THEIL_SEN + 16:
+                    raise ValueError('no Theil-Sen subsample for a read longer than %d bases' %
+                                     MAX_POINTS_FOR_THEIL_SEN)
+        st, sto = _native.pack_stalls(stalls) if stalls is not None and \
+            any(s is not None and len(s) for s in stalls) else (None, None)
+        return ReadBatch(raw, raw_off, seq, seq_off, si, st, sto, tag)
+
+    def prefetch(self, raws, seqs, **kw):
+        """start packing a batch on the helper thread; `take()` returns it"""
+        assert self._pending is None
+        self._pending = self._ex.submit(self.pack, raws, seqs, **kw)
+
+    def take(self):
+        fut, self._pending = self._pending, None
+        return None if fut is None else fut.result()
+
+    def close(self):
+        self.take()
+        self._ex.shutdown()
+        for st in self.stages:
+            st.close()
