@@ -26,7 +26,7 @@ def golden_names():
     # read-level cases; kernels_*.npz hold stand-alone kernel vectors (test_oracle_kernels_golden),
     # dacq_*.npz the reference's runs on DAC-quantised reads (test_dac_quantised)
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))
-                  if not os.path.basename(f).startswith(('kernels_', 'dacq_', 'stats_')))
+                  if not os.path.basename(f).startswith(('kernels_', 'dacq_', 'stats_', 'loop_')))
 
 
 class GoldenCase(object):
@@ -40,8 +40,11 @@ class GoldenCase(object):
         m = self.meta
         self.samp = th.seqSampleType(m['samp'], False)
         self.model = ts.TomboModel(seq_samp_type=self.samp)
-        self.params = ts.load_resquiggle_parameters(self.samp)._replace(
+        # (round-3 fixtures carry --signal-align-parameters / --segmentation-parameters overrides)
+        self.params = ts.load_resquiggle_parameters(
+            self.samp, m.get('sig_aln_params'), m.get('seg_params'))._replace(
             bandwidth=m['bandwidth'], band_bound_thresh=m['band_bound_thresh'])
+        self.max_raw_cpts = m.get('max_raw_cpts') or 200
         seq, raw, _ = synth.synth_read(self.model, m['n_bases'], m['seed'], **m['synth_kw'])
         if m['noise_body']:
             rng = np.random.default_rng(m['seed'] + 12345)

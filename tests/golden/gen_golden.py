@@ -72,12 +72,15 @@ class Capture(object):
 
 def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=None,
              synth_kw=None, full=False, outlier_thresh=5.0, skip_seq_scaling=False,
-             const_scale=None, second_iter=False, noise_body=False):
+             const_scale=None, second_iter=False, noise_body=False, sig_aln_params=None,
+             seg_params=None, max_raw_cpts=None):
+    """sig_aln_params / seg_params: --signal-align-parameters / --segmentation-parameters style
+    overrides (tombo/_option_parsers.py:375-385,606-617 -> load_resquiggle_parameters)"""
     samp = th.seqSampleType(samp_name, False)
     my_samp = my_th.seqSampleType(samp_name, False)
     my_model = my_ts.TomboModel(seq_samp_type=my_samp)
     std_ref = ref_model(my_model, samp)
-    params = ts.load_resquiggle_parameters(samp)
+    params = ts.load_resquiggle_parameters(samp, sig_aln_params, seg_params)
     if bandwidth is not None:
         params = params._replace(bandwidth=bandwidth)
     if band_bound_thresh is not None:
@@ -105,7 +108,8 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
                 bandwidth=int(params.bandwidth), band_bound_thresh=int(params.band_bound_thresh),
                 synth_kw=kw, outlier_thresh=outlier_thresh, skip_seq_scaling=skip_seq_scaling,
                 const_scale=const_scale, noise_body=noise_body, second_iter=second_iter,
-                np_seed=seed)
+                np_seed=seed, sig_aln_params=sig_aln_params, seg_params=seg_params,
+                max_raw_cpts=max_raw_cpts)
     out['raw__sha'] = sha(raw)
     out['raw__len'] = np.int64(raw.shape[0])
     if stall_ints is not None:
@@ -146,7 +150,6 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
         d['band_event_starts'] = a[2].astype(np.int64).copy()
         d['fwd_last_row'] = a[0][-1].copy()
         d['fwd_pass__sha'] = sha(a[0])
-        d['fwd_pass_move__sha'] = sha(a[1].astype(np.int8))
         d['adapt_start_seq_pos'] = np.int64(a[9] if len(a) > 9 else k['start_seq_pos'])
     origs.append((th, 'adaptive_banded_forward_pass',
                   cap.wrap(th, 'adaptive_banded_forward_pass', post_adapt)))
@@ -173,6 +176,8 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
 
     def do_call(mr, **kws):
         np.random.seed(seed)
+        if max_raw_cpts is not None:
+            kws['max_raw_cpts'] = max_raw_cpts
         return rq.resquiggle_read(mr, std_ref, params, outlier_thresh, seq_samp_type=samp, **kws)
 
     try:
@@ -260,6 +265,32 @@ CASES = [
     dict(name='dna_no_outlier', samp_name='DNA', n_bases=800, seed=14, outlier_thresh=None),
     dict(name='rna_b600_w500', samp_name='RNA', n_bases=600, seed=20, second_iter=True),
     dict(name='rna_b3000_w500', samp_name='RNA', n_bases=3000, seed=21),
+    # ---- off the defaults (round 3): --segmentation-parameters / --signal-align-parameters ----
+    # (running_stat_width, min_obs_per_base, raw_min_obs_per_base, mean_obs_per_event)
+    dict(name='p_dna_seg_7_4_2_6', samp_name='DNA', n_bases=1500, seed=30, seg_params=(7, 4, 2, 6),
+         second_iter=True),                                  # generic k_peaks radius, raw m = 2 on DNA
+    dict(name='p_dna_seg_w33', samp_name='DNA', n_bases=1200, seed=31, seg_params=(33, 3, 1, 5)),  # 2w > 64
+    dict(name='p_dna_seg_3_2_1_4', samp_name='DNA', n_bases=1200, seed=32, seg_params=(3, 2, 1, 4)),
+    dict(name='p_rna_seg_10_5_3_12', samp_name='RNA', n_bases=700, seed=33, seg_params=(10, 5, 3, 12)),
+    # (match_evalue, skip_pen, bandwidth, save_bandwidth, max_half_z_score, band_bound_thresh,
+    #  start_bw, start_save_bw, start_n_bases)
+    dict(name='p_dna_aln_me35_sp5', samp_name='DNA', n_bases=1500, seed=34,
+         sig_aln_params=(3.5, 5.0, 300, 1500, 20.0, 40, 750, 2500, 250)),
+    dict(name='p_dna_aln_bw700_z10_bbt30', samp_name='DNA', n_bases=2500, seed=35,
+         sig_aln_params=(4.2, 4.2, 700, 2000, 10.0, 30, 750, 2500, 250)),
+    dict(name='p_dna_aln_start500_150', samp_name='DNA', n_bases=1500, seed=36,
+         sig_aln_params=(4.2, 4.2, 300, 1500, 20.0, 40, 500, 1800, 150)),
+    dict(name='p_dna_aln_start_retry', samp_name='DNA', n_bases=1500, seed=37, synth_kw=dict(lead=3500),
+         sig_aln_params=(4.2, 4.2, 300, 1500, 20.0, 40, 500, 1800, 150)),
+    dict(name='p_dna_aln_z3', samp_name='DNA', n_bases=1200, seed=38,
+         sig_aln_params=(4.2, 4.2, 300, 1500, 3.0, 40, 750, 2500, 250)),
+    dict(name='p_rna_aln_me5_sp3_bw300', samp_name='RNA', n_bases=700, seed=39,
+         sig_aln_params=(5.0, 3.0, 300, 1500, 15.0, 40, 800, 2500, 200)),
+    dict(name='p_dna_outlier3', samp_name='DNA', n_bases=1200, seed=40, outlier_thresh=3.0, second_iter=True),
+    dict(name='p_rna_outlier3', samp_name='RNA', n_bases=700, seed=41, outlier_thresh=3.0),
+    # (RNA with outlier_thresh=None is a TypeError in the reference -- get_scale_values_from_events,
+    # tombo_stats.py:228 -- i.e. an "unexpected error": TBA_INTERNAL here, tests/test_gpu_parity.py)
+    dict(name='p_dna_max_raw_cpts_4', samp_name='DNA', n_bases=1500, seed=43, max_raw_cpts=4),
 ]
 
 if __name__ == '__main__':

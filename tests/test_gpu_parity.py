@@ -22,7 +22,8 @@ def _engine():
 
 
 def _oracle_read(model, params, raw, seq, outlier_thresh, samp_name, stall_ints=None,
-                 samp_ind=None, scale_values=None, const_scale=None, skip_seq_scaling=False):
+                 samp_ind=None, scale_values=None, const_scale=None, skip_seq_scaling=False,
+                 max_raw_cpts=200):
     import oracle
     from tombo_amd import tombo_stats as ts
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
@@ -30,7 +31,7 @@ def _oracle_read(model, params, raw, seq, outlier_thresh, samp_name, stall_ints=
     o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=outlier_thresh,
                          const_scale=const_scale, scale_values=scale_values,
                          skip_seq_scaling=skip_seq_scaling,
-                         sig_match_thresh=SIG_MATCH_THRESH[samp_name])
+                         sig_match_thresh=SIG_MATCH_THRESH[samp_name], max_raw_cpts=max_raw_cpts)
     return oracle.resquiggle_read(raw, ts.encode_seq(seq), model.level_means, model.level_sds,
                                   p, o, stall_ints=stall_ints, samp_ind=samp_ind, debug=True)
 
@@ -114,7 +115,7 @@ def compare_batch(eng, oracles, out, label=''):
 
 
 def run_batch(model, params, samp_name, reads, outlier_thresh=5.0, const_scale=None,
-              skip_seq_scaling=False, scale_values=None, seed0=None):
+              skip_seq_scaling=False, scale_values=None, seed0=None, max_raw_cpts=200):
     """reads: list of (raw, seq, stall_ints, samp_ind).  Returns (engine, out, oracles)."""
     from tombo_amd import _native as N, tombo_stats as ts
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
@@ -124,7 +125,7 @@ def run_batch(model, params, samp_name, reads, outlier_thresh=5.0, const_scale=N
     p = N.make_params(params)
     o = N.make_opts(outlier_thresh=outlier_thresh, const_scale=const_scale,
                     skip_seq_scaling=skip_seq_scaling,
-                    sig_match_thresh=SIG_MATCH_THRESH[samp_name])
+                    sig_match_thresh=SIG_MATCH_THRESH[samp_name], max_raw_cpts=max_raw_cpts)
     si = np.zeros((n, 1000), np.int64)
     for i, r in enumerate(reads):
         if r[3] is not None:
@@ -145,7 +146,8 @@ def run_batch(model, params, samp_name, reads, outlier_thresh=5.0, const_scale=N
         oracles.append(_oracle_read(
             model, params, r[0], r[1], outlier_thresh, samp_name, stall_ints=r[2],
             samp_ind=r[3], const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
-            scale_values=None if scale_values is None else scale_values[i]))
+            scale_values=None if scale_values is None else scale_values[i],
+            max_raw_cpts=max_raw_cpts))
     return eng, out, oracles
 
 
@@ -159,7 +161,7 @@ def test_golden_case_on_gpu(golden_case, name):
     eng, out, oracles = run_batch(
         c.model, c.params, m['samp'], [(c.raw, c.seq, c.stall_ints, c.samp_ind())],
         outlier_thresh=m['outlier_thresh'], const_scale=m['const_scale'],
-        skip_seq_scaling=m['skip_seq_scaling'])
+        skip_seq_scaling=m['skip_seq_scaling'], max_raw_cpts=c.max_raw_cpts)
     bad = compare_batch(eng, oracles, out, name)
     assert not bad, '\n'.join(bad)
     g = c.g

@@ -18,7 +18,7 @@ def run_oracle(c, scale_values=None, debug=True):
         const_scale=None if scale_values is not None else m['const_scale'],
         scale_values=scale_values,
         skip_seq_scaling=False if scale_values is not None else m['skip_seq_scaling'],
-        sig_match_thresh=SIG_MATCH_THRESH[m['samp']])
+        sig_match_thresh=SIG_MATCH_THRESH[m['samp']], max_raw_cpts=c.max_raw_cpts)
     return oracle.resquiggle_read(
         c.raw, ts.encode_seq(c.seq), c.model.level_means, c.model.level_sds, p, o,
         stall_ints=c.stall_ints, samp_ind=c.samp_ind(), debug=debug)
@@ -70,7 +70,8 @@ def test_oracle_matches_reference(golden_case, name):
 
 
 @pytest.mark.parametrize('name', [n for n in golden_names()
-                                  if n in ('dna_b600_w300', 'dna_b2000_w300', 'rna_b600_w500')])
+                                  if n in ('dna_b600_w300', 'dna_b2000_w300', 'rna_b600_w500',
+                                           'p_dna_seg_7_4_2_6', 'p_dna_outlier3')])
 def test_oracle_second_iteration(golden_case, name):
     """run_rsqgl_iters semantics (resquiggle.py:1492-1504): re-run with the fitted scale values"""
     from tombo_amd import tombo_helper as th

@@ -154,6 +154,7 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
             st, sto = _native.pack_stalls(stalls)
     nb = np.diff(seq_off) - K + 1
     si = None
+    rng_state = np.random.get_state() if n == 1 else None
     if not skip_seq_scaling and subsample_seed is None and (nb > MAX_POINTS_FOR_THEIL_SEN).any():
         si = stage.get('si', n * MAX_POINTS_FOR_THEIL_SEN, np.int64).reshape(n, MAX_POINTS_FOR_THEIL_SEN)
         for i in np.flatnonzero(nb > MAX_POINTS_FOR_THEIL_SEN):
@@ -185,6 +186,11 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                    sv=np.stack([o_res['shift'], o_res['scale'], o_res['lower_lim'],
                                 o_res['upper_lim']], axis=1))
     status = np.asarray(out['status'])
+    if rng_state is not None and int(status[0]) not in (0, 19, 20):
+        # a batch of one is the reference's call: it only touches the RNG once the read reaches
+        # sequence rescaling (calc_kmer_fitted_shift_scale), so a read that failed earlier leaves
+        # the seeded stream where it was
+        np.random.set_state(rng_state)
     ok = np.flatnonzero((status == 0) & np.array([e is None for e in pre_err]))
     if o_res is not None:
         segs_l = _native.unpack_reads(o_segs, eng.seg_off[:-1][ok], nb[ok] + 1)
@@ -244,18 +250,13 @@ def resquiggle_read(map_res, std_ref, rsqgl_params, outlier_thresh=None, all_raw
         map_res = map_res._replace(raw_signal=all_raw_signal)
     if map_res.raw_signal is None:
         raise th.TomboError(errors.MESSAGES[21])
-    rng_state = np.random.get_state()
     res = resquiggle_batch(
         [map_res], std_ref, rsqgl_params, outlier_thresh=outlier_thresh,
         max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
         const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
         seq_samp_type=seq_samp_type)[0]
     if isinstance(res, Exception):
-        # the reference only touches the RNG once the read reaches sequence rescaling
-        if not (isinstance(res, th.TomboError) and str(res) in (
-                errors.MESSAGES[19], errors.MESSAGES[20])):
-            np.random.set_state(rng_state)
-        raise res
+        raise res    # (a batch of one rewinds the RNG itself when the read failed before rescaling)
     return res
 
 
@@ -474,7 +475,7 @@ def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
                            outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
                            seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False),
                            max_scaling_iters=None, engine=None, return_passes=False,
-                           device_prep=False, subsample_seed=None):
+                           device_prep=False, subsample_seed=None, rng_order='round_major'):
     """The per-read loop of `_resquiggle_worker` (resquiggle.py:1578-1589) over a batch.
 
     Every read is resquiggled; while `norm_params_changed` it is re-run with the fitted
@@ -486,6 +487,15 @@ def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
     so the Theil-Sen subsamples are drawn from numpy's global RNG in round-major order instead
     of the worker's read-major order; each individual pass is the same computation as
     `resquiggle_read` with the subsample it was handed.
+
+    `rng_order='read_major'`: the reads are taken one at a time, exactly the worker's sequence of
+    `resquiggle_read` calls, so that under a seeded numpy RNG every read gets the subsamples the
+    reference's loop would have drawn for it (bit-identical `raw_signal` / `scale_values`; pinned on
+    a loop recorded from the live reference, tests/golden/loop_dna.npz).  Which pass of which read
+    draws next depends on the results of the passes before it, so this order cannot be batched;
+    it is the parity mode, `round_major` the throughput mode: another draw means a fitted scale that
+    differs in the third digit, and in a re-run pass that can move a handful of event boundaries
+    (3 of 1801 on one read of the recorded loop) -- the spread the reference shows between two seeds.
 
     `device_prep`: `map_results` are the mapped reads as `_io_and_map_read` left them (RNA signal
     in acquisition order, no `stall_ints`) and `adjust_map_res` -- the flip and
@@ -502,6 +512,19 @@ def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
         rna = seq_samp_type is not None and seq_samp_type.name == RNA_SAMP_TYPE
         prep.update(reverse_raw=rna, stall_params=th.stallParams(**STALL_PARAMS)
                     if rna and COLLAPSE_RNA_STALLS else None)
+    if rng_order == 'read_major':
+        res = {}
+        for i in range(n):
+            res.update(_run_iters(map_results, [i], std_ref, rsqgl_params, outlier_thresh, const_scale,
+                                  skip_seq_scaling, seq_samp_type, max_scaling_iters, engine, n_passes, prep))
+            if isinstance(res[i], Exception) and save_params is not None:
+                res.update(_run_iters(map_results, [i], std_ref, save_params, outlier_thresh, const_scale,
+                                      skip_seq_scaling, seq_samp_type, max_scaling_iters, engine,
+                                      n_passes, prep))
+        out = [res[i] for i in range(n)]
+        return (out, n_passes) if return_passes else out
+    if rng_order != 'round_major':
+        raise ValueError("rng_order is 'round_major' or 'read_major'")
     res = _run_iters(map_results, list(range(n)), std_ref, rsqgl_params, outlier_thresh,
                      const_scale, skip_seq_scaling, seq_samp_type, max_scaling_iters, engine,
                      n_passes, prep)
