@@ -104,3 +104,33 @@ def test_sequence_helpers():
     assert th.invalid_seq('ACGU') and not th.invalid_seq('ACGT')
     assert th.rev_transcribe('ACGUU') == 'ACGTT'
     assert th.get_mean_q_score('5I#') == np.mean([20, 40, 2])
+
+
+def test_unexpected_per_read_errors_do_not_abort_the_batch():
+    """_io_and_map_read records any non-Tombo exception of a read as (traceback, 'subgrp:::fn',
+    False) and goes on (resquiggle.py:1476-1479): a truncated Fastq, a missing Signal dataset and
+    an aligner that raises are three failures, not an aborted batch"""
+    import numpy as np
+    import gen_golden_map as gm
+    from scripted_aligner import ScriptedAligner
+    from tombo_amd import mapping, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    trunc = gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 1)
+    g = trunc['/Analyses/Basecall_1D_000/BaseCalled_template']
+    del g.items['Fastq']
+    g.create_dataset('Fastq', data=np.bytes_(b'@r1\nACGTACGTACGT'))      # no '+' / quality lines
+    nosig = gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 2)
+    del next(iter(nosig['/Raw/Reads'].values())).items['Signal']
+
+    class Boom(ScriptedAligner):
+        def map(self, *a, **k):
+            raise OSError('aligner died')
+    ok_but_boom = gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 3)
+    index, failures = mapping.process_fast5_batch(
+        [(trunc, 'a.fast5'), (nosig, 'b.fast5'), (ok_but_boom, 'c.fast5')], Boom({}, {}), model, params, samp)
+    assert index == [] and len(failures) == 3
+    assert [f[1] for f in failures] == ['BaseCalled_template:::%s.fast5' % c for c in 'abc']
+    assert all(f[2] is False and 'Traceback' in f[0] for f in failures)
+    assert 'aligner died' in failures[2][0]

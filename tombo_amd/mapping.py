@@ -15,6 +15,8 @@ Reference:  get_read_seq          tombo/resquiggle.py:1221-1276
             _io_and_map_read      tombo/resquiggle.py:1385-1413 (signal + channel extraction),
                                   :1438-1465 (filters and the index record)
 """
+import traceback
+
 import numpy as np
 
 from . import tombo_helper as th
@@ -209,11 +211,18 @@ def process_fast5_batch(fast5s, aligner, std_ref, rsqgl_params, seq_samp_type, s
         except th.TomboError as e:
             failures.append((str(e), bc_subgrp + ':::' + fn, True))
             continue
-        mapped.append(rq.adjust_map_res(mr, seq_samp_type))
+        except Exception:
+            # any other per-read failure (truncated Fastq, missing dataset, aligner error) is
+            # that read's failure, not the batch's: _io_and_map_read, resquiggle.py:1476-1479
+            failures.append((traceback.format_exc(), bc_subgrp + ':::' + fn, False))
+            continue
+        mapped.append(mr)
         owners.append(k)
+    # adjust_map_res (RNA flip + stall detection, resquiggle.py:1506-1530) runs on the device as
+    # part of every pass
     results = rq.resquiggle_batch_iters(
         mapped, std_ref, rsqgl_params, save_params=save_params, outlier_thresh=outlier_thresh,
-        seq_samp_type=seq_samp_type, engine=engine) if mapped else []
+        seq_samp_type=seq_samp_type, engine=engine, device_prep=True) if mapped else []
     index_records = []
     for k, res in zip(owners, results):
         f5, fn = fast5s[k]
@@ -231,6 +240,9 @@ def process_fast5_batch(fast5s, aligner, std_ref, rsqgl_params, seq_samp_type, s
                                          rna=seq_samp_type.rev_sig)
             except th.TomboError as e:
                 failures.append((str(e), bc_subgrp + ':::' + fn, True))
+                continue
+            except Exception:
+                failures.append((traceback.format_exc(), bc_subgrp + ':::' + fn, False))
                 continue
         index_records.append(filter_and_index_record(res, fn, corr_grp, bc_subgrp, seq_samp_type,
                                                      sig_match_thresh, obs_filter))
