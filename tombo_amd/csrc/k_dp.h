@@ -31,6 +31,37 @@ __host__ __device__ inline int cpl_class(i64 W)
 
 enum { DP_START_TRY = 0, DP_START_RETRY = 1, DP_MAIN = 2, DP_DIRECT = 3 };
 
+// Narrow adaptive bands are run several reads per wavefront (k_dp_multi.h): the class of a
+// bandwidth there (cells per lane, reads per wavefront; cpl == 0: none, k_dp takes the read)
+struct DpMultiClass { int cpl, rpw; };
+__host__ __device__ inline DpMultiClass dp_multi_class(i64 W)
+{
+#ifdef TBA_NO_DP_MULTI
+    (void)W;
+    return {0, 0};
+#else
+    // Measured (MI355X, 10 k reads x 10 kb unless noted; profiles/r03_dp_multi_classes.txt):
+    //   W = 100 (2 kb reads): 2 reads x 32 lanes x 4 cells 7.6 ms, 4 x 16 x 8 8.0 ms, k_dp<4> 8.4 ms
+    //           (40 k reads per launch: 24.7 / 28.9 / 28.8 ms)
+    //   W = 200: 2 x 32 x 8 cells 74 ms (LDS bank conflicts: a lane stride of 64 bytes puts 32 lanes
+    //           on 4 bank pairs, SQ_LDS_BANK_CONFLICT = 82 % of the LDS cycles), k_dp<4> 42 ms
+    //   W = 300: 2 x 32 x 10 cells 62 ms (508 VALU instructions per 2-read row = 254 per read against
+    //           ~290, but 2.75 waves per SIMD instead of 4 and an LDS round trip on the row chain:
+    //           66 % VALU utilisation), k_dp<5> 57 ms
+    // so only the narrowest class is dispatched; -DTBA_DPM_WIDE builds the other two for A/B runs.
+#ifdef TBA_DPM_128_84
+    if (W <= 128) return {8, 4};
+#else
+    if (W <= 128) return {4, 2};
+#endif
+#ifdef TBA_DPM_WIDE
+    if (W <= 256) return {8, 2};
+    if (W <= 320) return {10, 2};
+#endif
+    return {0, 0};
+#endif
+}
+
 // one forward pass described explicitly (per-kernel C ABI entry points, tba_c_*): same row
 // engine, geometry taken from here instead of ReadState
 struct DpJob {
@@ -226,6 +257,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             if (r.path == PATH_NONE) return;
             W = (int)r.W;
             if (cpl_class(W) != CPL) return;
+            // an adaptive read at a narrow batch bandwidth belongs to k_dp_multi
+            if (r.path == PATH_ADAPTIVE && r.W == P.bandwidth && dp_multi_class(P.bandwidth).cpl != 0) return;
             n_rows = (int)r.B;
             n_static = (int)r.n_static;
             ev_base = r.ev_off + r.clip;
@@ -350,7 +383,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     fetch_row(row0);
 
 #ifdef TBA_SWEEP_STATS
-    i64 sw_total = 0, sw_lanes = 0, sw_depth[4] = {0, 0, 0, 0};
+    i64 sw_total = 0;
 #endif
     for (int row = row0; row < n_rows; row++) {
         double mu = 0, sd = 1, y = 1;
@@ -437,38 +470,49 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             default: if constexpr (S >= 8) cand_row<CPL, 8>(v, left, z, skip_pen, fs, l0, cv, tk); break;
             }
         }
-        // stay chain: monotone fixed-point sweeps, chunk exit values shifted one lane up
+        // stay chain: monotone fixed-point sweeps, chunk exit values shifted one lane up.
+        // Sweep 1 starts every lane from -inf and gives v0[j], the value of cell j without anything
+        // coming in from the left.  x -> (x - stay_pen) + z is monotone, and a monotone map commutes
+        // with max, so with an incoming value `in` cell j holds max(v0[j], c_j(in)), c_j = the pure
+        // stay chain from `in` through cells 0..j: the later sweeps only carry that chain (2
+        // instructions per cell instead of 3) to get the lane's exit value max(v0[CPL-1], c_{CPL-1}),
+        // and the cells themselves are written once, in the pass that also derives the move flags.
+        // The sequence of incoming values is the same as with full sweeps, so is the sweep count.
         double in = NEG_INF;
         bool converged = false;
-        for (int it = 0; it < 66; it++) { // <= 64 sweeps by induction over lanes (NaN-proof bound)
-            double x = in;
-#ifdef TBA_SWEEP_STATS
-            int depth = 0;
+        double exit0;
+        {
+            double x = NEG_INF;
 #pragma unroll
-            for (int j = 0; j < CPL; j++) {
-                x = __builtin_fmax(cv[j], (x - stay_pen) + z[j]);
-                if (it > 0 && x != v[j]) depth = j + 1;
-                v[j] = x;
-            }
-            if (it > 0) { int dm = depth; for (int o = 32; o >= 1; o >>= 1) { int t = __shfl_xor(dm, o, 64); dm = t > dm ? t : dm; } sw_depth[it < 4 ? it : 3] += dm; sw_lanes += __popcll(__ballot(depth > 0)); }
-            sw_total++;
-#else
-#pragma unroll
-            for (int j = 0; j < CPL; j++) {
-                x = max_f64_raw(cv[j], (x - stay_pen) + z[j]);
-                v[j] = x;
-            }
-#endif
-            const double nin = wave_shr1_f64(x, NEG_INF);
-            if (__ballot(nin != in) == 0) { converged = true; break; }
-            in = nin;
+            for (int j = 0; j < CPL; j++) x = max_f64_raw(cv[j], (x - stay_pen) + z[j]);
+            exit0 = x;
         }
+#ifdef TBA_SWEEP_STATS
+        i64 sw_row = 1;
+#endif
+        {
+            double nin = wave_shr1_f64(exit0, NEG_INF);
+            for (int it = 0; it < 66; it++) { // <= 64 sweeps by induction over lanes (NaN-proof bound)
+                if (__ballot(nin != in) == 0) { converged = true; break; }
+                in = nin;
+                double c = in;
+#pragma unroll
+                for (int j = 0; j < CPL; j++) c = (c - stay_pen) + z[j];
+                nin = wave_shr1_f64(max_f64_raw(exit0, c), NEG_INF);
+#ifdef TBA_SWEEP_STATS
+                sw_row++;
+#endif
+            }
+        }
+#ifdef TBA_SWEEP_STATS
+        sw_total += sw_row;
+#endif
         if (!converged) { // only reachable with NaNs in the signal
             if (lane == 0) { if (DIRECT) job->status = TBA_INTERNAL; else r.status = TBA_INTERNAL; }
             return;
         }
-        // move codes (0 stay, 1 skip, 2 diag; pyx:216-231) packed 2 bits per cell, lane-local
-        // argmax (pyx:186-197; -inf cells never win)
+        // the cells, their move codes (0 stay, 1 skip, 2 diag; pyx:216-231) packed 2 bits per cell,
+        // lane-local argmax (pyx:186-197; -inf cells never win)
         u32 mvw[(CPL + 15) / 16];
 #pragma unroll
         for (int q = 0; q < (CPL + 15) / 16; q++) mvw[q] = 0;
@@ -480,7 +524,8 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 const double s = (x - stay_pen) + z[j];
                 const u32 f = cv[j] > s ? (tk[j] ? 1u : 2u) : 0u;
                 mvw[j / 16] |= f << (2 * (j % 16));
-                x = v[j];
+                x = max_f64_raw(cv[j], s);
+                v[j] = x;
                 lmax = max_f64_raw(lmax, x);
             }
         }
@@ -548,8 +593,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     }
 #ifdef TBA_SWEEP_STATS
     if (!DIRECT && mode == DP_MAIN && lane == 0) {
-        r.dbg[0] = n_rows - row0; r.dbg[1] = sw_total; r.dbg[2] = sw_lanes;
-        r.dbg[3] = sw_depth[1]; r.dbg[4] = sw_depth[2]; r.dbg[5] = sw_depth[3];
+        r.dbg[0] = n_rows - row0; r.dbg[1] = sw_total;
     }
 #endif
     // last row + traceback start (np.argmax of the last row, resquiggle.py:728,1032)

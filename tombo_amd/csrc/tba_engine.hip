@@ -6,6 +6,7 @@
 #include "k_segment.h"
 #include "k_prep_raw.h"
 #include "k_dp.h"
+#include "k_dp_multi.h"
 #include "k_tail.h"
 #include "k_cabi.h"
 
@@ -99,15 +100,17 @@ struct tba_engine {
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
-        d_moves, d_dscr, d_wide, d_stat;
+        d_moves, d_dscr, d_wide, d_stat, d_order;
+    PinBuf h_order;               // read indices by decreasing length (k_dp_multi's grouping)
     void release_all()
     {
         DevBuf *all[] = {&d_rs, &d_dp, &d_kmeans, &d_ksds, &d_raw, &d_norm, &d_norm_out, &d_csum,
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq};
+                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq, &d_order};
         for (DevBuf *b : all) b->release();
+        h_order.release();
         h_rs.release();
         h_dp.release();
     }
@@ -332,6 +335,7 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     if (z.wide_w) BUF(d_wide, (size_t)WIDE_BLOCKS * 2 * (size_t)z.wide_w * 8);
     if (z.n_stall > 0) BUF(d_stall, (size_t)z.n_stall * 16);
     BUF(d_skipq, 64 + 3 * (N * 32 + 4096) * 8);
+    BUF(d_order, N * 4);
     BUF(d_res, N * sizeof(tba_read_result));
     BUF(d_segs32, (Bt + N) * 4);
 #undef BUF
@@ -434,6 +438,14 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
 
     hipStream_t s = e->stream;
     const size_t N = (size_t)n;
+    { // reads by decreasing length (stable): the groups of a k_dp_multi wavefront finish together
+        if (e->h_order.ensure(N * 4)) return TBA_E_NOMEM;
+        i32 *ord = e->h_order.as<i32>();
+        const ReadState *hrs = e->h_rs.as<ReadState>();
+        for (i64 i = 0; i < n; i++) ord[i] = (i32)i;
+        std::stable_sort(ord, ord + n, [hrs](i32 a, i32 b) { return hrs[a].B > hrs[b].B; });
+        HIP_TRY(hipMemcpyAsync(e->d_order.p, ord, N * 4, hipMemcpyHostToDevice, s));
+    }
     memcpy(e->h_dp.p, &e->hp, sizeof(DevParams));
     HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.p, N * sizeof(ReadState), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(e->d_dp.p, e->h_dp.p, sizeof(DevParams), hipMemcpyHostToDevice, s));
@@ -483,6 +495,22 @@ static void launch_dp_t(tba_engine *e, int mode)
         e->d_hi.as<i32>(),
         mode == DP_MAIN ? e->d_moves.as<unsigned char>() : e->d_smoves.as<unsigned char>(),
         e->start_moves_stride, e->d_lastrow.as<double>(), nullptr);
+}
+template <int CPL, int RPW>
+static void launch_dp_multi_t(tba_engine *e)
+{
+    k_dp_multi<CPL, RPW><<<dim3((unsigned)((e->n_reads + RPW - 1) / RPW)), dim3(64), 0, e->stream>>>(
+        e->d_rs.as<ReadState>(), e->n_reads, e->d_order.as<i32>(), e->d_dp.as<DevParams>(),
+        e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(),
+        e->d_lo.as<i32>(), e->d_hi.as<i32>(), e->d_moves.as<unsigned char>(), e->d_lastrow.as<double>());
+}
+static void launch_dp_multi(tba_engine *e)
+{
+    const DpMultiClass c = dp_multi_class(e->hp.p.bandwidth);
+    if (c.cpl == 8 && c.rpw == 4) launch_dp_multi_t<8, 4>(e);
+    else if (c.cpl == 4 && c.rpw == 2) launch_dp_multi_t<4, 2>(e);
+    else if (c.cpl == 8 && c.rpw == 2) launch_dp_multi_t<8, 2>(e);
+    else if (c.cpl == 10 && c.rpw == 2) launch_dp_multi_t<10, 2>(e);
 }
 static void launch_dp(tba_engine *e, int cpl, int mode)
 {
@@ -596,6 +624,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     if (ON(TBA_STAGE_ASSIGN)) {
         const int cls[] = {4, 5, 8, 12, 16, 24, 32, 48};
         for (int c : cls) launch_dp(e, c, DP_MAIN);
+        launch_dp_multi(e); // narrow adaptive bands: several reads per wavefront
         if (e->wide_w) // a static band wider than every class is possible in this batch
             k_dp_wide<<<WIDE_BLOCKS, 64, 0, s>>>(rs, n, dp, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), e->d_moves.as<unsigned char>(), e->d_wide.as<double>(), e->wide_w);
     }
