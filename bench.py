@@ -333,6 +333,8 @@ def main():
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
                          'engine / stream (kernels of different sub-batches overlap)')
+    ap.add_argument('--tail-bases', type=int, default=30000,
+                    help='longtail preset: reads longer than this form batches of their own (planner.plan_batches)')
     ap.add_argument('--api-reads', type=int, default=2000, help='reads of the resquiggle_batch API leg (0: skip)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes behind roofline.traffic')
     ap.add_argument('--pmc-reads', type=int, default=1024, help='reads of the counter passes')
@@ -353,6 +355,8 @@ def main():
     longtail = a.preset == 'longtail'
     if longtail and a.reads == 10000:
         a.reads = 16000   # enough work per pass to hide the serial time of a 200 kb read
+    if longtail and a.slots == 3:
+        a.slots = 4       # (measured: 3 -> 39.2 k, 4 -> 40.9 k, 6 -> 27 k reads/s end to end)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -452,7 +456,7 @@ def main():
         # of the batch holding the longest reads run for a long time, the other batches fill the machine
         tot = planner.exact_bytes(n_raw, seq_len, p, o, model.kmer_width)
         plan = planner.plan_batches(n_raw, seq_len, p, o, model.kmer_width,
-                                    min(0.2 * free_b, max(tot / 6.0, 2e9)))
+                                    min(0.2 * free_b, max(tot / 6.0, 2e9)), tail_bases=a.tail_bases)
     else:
         plan = [x for x in np.array_split(np.arange(a.reads), max(1, a.resident_split)) if len(x)]
     engines = [probe] + [_native.Engine(dev) for _ in plan[1:]]
@@ -524,8 +528,10 @@ def main():
         if longtail:
             o_s = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name],
                                     skip_norm_out=compact)
-            splan = planner.plan_batches(n_raw, seq_len, p, o_s, model.kmer_width, 0.2 * free_b,
-                                         np.int16 if compact else np.float64, max_reads=a.stream_batch)
+            splan = planner.plan_batches(n_raw, seq_len, p, o_s, model.kmer_width,
+                                         min(0.2, 0.6 / a.slots) * free_b,
+                                         np.int16 if compact else np.float64, max_reads=a.stream_batch,
+                                         tail_bases=a.tail_bases)
         else:
             splan = [np.arange(s, min(s + a.stream_batch, a.reads)) for s in range(0, a.reads, a.stream_batch)]
         host_draw = a.subsample == 'numpy' and si is not None
@@ -533,7 +539,8 @@ def main():
                                         seq_samp_type=samp, want_norm=not compact,
                                         segs_dtype=np.int32 if compact else np.int64,
                                         reverse_raw=dev_flip, stall_params=stall_params,
-                                        subsample_seed=None if host_draw else 20260927 + rank)
+                                        subsample_seed=None if host_draw else 20260927 + rank,
+                                        in_order=not longtail)
         feeder = streaming.ReadFeeder(n_slots=a.slots, n_threads=workers)
         pools = [([src[i] for i in idx], [seqs[i] for i in idx], idx) for idx in splan]
         cnt = dict(reads=0, ok=0, out=0, moved=0, submit_s=0.0, pack_wait_s=0.0, nb=0)
@@ -548,6 +555,9 @@ def main():
             feeder.prefetch(sub_r, sub_s, samp_inds=smp, tag=k)
 
         def consume(res):
+            if os.environ.get('TBA_BENCH_VERBOSE'):
+                print('batch', res.tag, 'reads', res.n, ' '.join('%s=%.1f' % (k, v) for k, v in zip(
+                    _native.STAGE_NAMES, res.stage_ms[:16]) if v > 0.5), file=sys.stderr)
             cnt['reads'] += res.n
             cnt['nb'] += 1
             est[:] += res.stage_ms
@@ -571,6 +581,10 @@ def main():
                 ts0 = time.perf_counter()
                 done = pipe.submit(batch)
                 cnt['submit_s'] += time.perf_counter() - ts0
+                if os.environ.get('TBA_BENCH_VERBOSE'):
+                    print('t=%.3f submit tag %s took %.3f (pack wait %.3f) -> done %s' % (
+                        time.perf_counter() - t_start, batch.tag, time.perf_counter() - ts0, ts0 - tw,
+                        None if done is None else done.tag), file=sys.stderr)
                 if done is not None:
                     consume(done)
             for done in pipe.flush():
@@ -580,6 +594,16 @@ def main():
         big = max(range(len(pools)), key=lambda k: int(n_raw[pools[k][2]].sum()))
         t_pin = time.perf_counter()
         stream([big] * (2 * a.slots + 2))
+        pipe.reserve(max(len(x[2]) for x in pools), max(int(bases[x[2]].sum()) + len(x[2]) for x in pools),
+                     max(int(n_raw[x[2]].sum()) for x in pools))
+        if len(pools) > 1:
+            # ragged pools: every slot sees every batch shape once (upload only), so that no engine
+            # buffer has to grow -- hipFree / hipMalloc stall the whole device -- inside the clock
+            for k in range(len(pools)):
+                wbk = feeder.pack(pools[k][0], pools[k][1])
+                for sl_ in pipe.slots:
+                    sl_.eng.upload_packed(pipe.params, pipe.opts, wbk.raw, wbk.raw_off, wbk.seq, wbk.seq_off, wait=True)
+                wbk.release()
         t_pin = time.perf_counter() - t_pin
         wb = feeder.pack(pools[big][0], pools[big][1])
         dev_sync()
@@ -587,8 +611,10 @@ def main():
         pipe.slots[0].eng.upload_packed(pipe.params, pipe.opts, wb.raw, wb.raw_off, wb.seq, wb.seq_off, wait=True)
         th2d = time.perf_counter() - th2d
         t_pk = time.perf_counter()
-        feeder.pack(pools[big][0], pools[big][1])
+        wb2 = feeder.pack(pools[big][0], pools[big][1])
         t_pk = time.perf_counter() - t_pk
+        wb.release()
+        wb2.release()
         big_bytes = wb.raw.nbytes + wb.seq.nbytes
         for k in cnt:
             cnt[k] = 0 if isinstance(cnt[k], int) else 0.0

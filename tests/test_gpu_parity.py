@@ -346,6 +346,32 @@ def test_rna_batch_on_gpu():
     assert sum(o['status'] == 0 for o in oracles) >= 6
 
 
+def test_long_read_kernels_vs_oracle_on_gpu():
+    """k_long.h: reads past TBA_LONG_RAW samples / TBA_LONG_BASES bases get a workgroup-per-read
+    cumulative sum and a wavefront-per-read traceback -- 60 kb and 29 kb reads (long by both / by
+    samples only), a 26 kb read at bandwidth 300 whose band runs off the events (failure path),
+    next to ordinary ones in the same batch; tile edges: lengths around multiples of the 1856-sample
+    scan tile"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    for bw, specs in ((500, ((60000, {}), (900, {}), (29200, {}), (31000, dict(mean_dwell=12)))),
+                      (300, ((26000, {}), (26500, dict(mean_dwell=30)), (1200, {})))):
+        params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=bw)
+        reads = []
+        for seed, (nb, kw) in enumerate(specs):
+            k = dict(synth.DNA_SYNTH)
+            k.update(kw)
+            seq, raw, _ = synth.synth_read(model, nb, 66000 + seed + bw, **k)
+            if seed == 0:   # an exact multiple of the scan tile, then one more sample
+                raw = raw[:(raw.shape[0] // 1856) * 1856 + (1 if bw == 300 else 0)]
+            reads.append((raw, seq, None, _si(nb, seed)))
+        eng, out, oracles = run_batch(model, params, 'DNA', reads)
+        bad = compare_batch(eng, oracles, out, 'long%d' % bw)
+        assert not bad, '\n'.join(bad[:40])
+        assert sum(o['status'] == 0 for o in oracles) >= len(specs) - 1
+
+
 def test_long_rna_reads_vs_oracle_on_gpu():
     """RNA reads of 6 and 9 kb (260 k / 390 k samples: dozens of event-detection tiles at radius
     5, every LDS class of the skipped-base windows, a stall in the longer one)"""

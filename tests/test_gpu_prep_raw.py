@@ -256,3 +256,34 @@ def test_device_subsample_uniformity():
     # every index is drawn with probability 0.1 per key: binomial(400, 0.1), mean 40, sd 6
     assert abs(hits.mean() - 40.0) < 1e-9 and 4.5 < hits.std() < 7.5, (hits.mean(), hits.std())
     assert hits.max() < 80 and hits.min() > 10
+
+
+def test_stall_detection_of_a_long_read_in_a_batch():
+    """a read past TBA_LONG_RAW samples takes the workgroup-per-read cumulative sum
+    (k_cumsum_scores_long, MODE 1) under the stall detector: float64 and int16"""
+    from tombo_amd import _native as N, synth, tombo_stats as ts, tombo_helper as th
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH, STALL_PARAMS
+    samp = th.seqSampleType('RNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    rng = np.random.default_rng(8)
+    reads = []
+    for k, nb in enumerate((7000, 500, 6400)):
+        seq, raw, _ = synth.synth_read(model, nb, 31000 + k, **synth.RNA_SYNTH)
+        for _ in range(3):
+            a = int(rng.integers(1000, raw.shape[0] - 5000))
+            raw = np.concatenate([raw[:a], raw[a] + rng.normal(0, 3.0, int(rng.integers(300, 2500))), raw[a:]])
+        reads.append((raw, seq))
+    assert max(r[0].shape[0] for r in reads) > 262144
+    eng = _engine()
+    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+    for dt in (np.float64, np.int16):
+        raws = [r[0] if dt == np.float64 else np.round(r[0]).astype(np.int16) for r in reads]
+        o = N.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH['RNA'],
+                        stall_params=th.stallParams(**STALL_PARAMS), subsample_seed=3)
+        eng.upload(N.make_params(params), o, raws, [ts.encode_seq(r[1]) for r in reads])
+        eng.run()
+        got = eng.stall_ints()
+        for i, raw in enumerate(raws):
+            want = _ints(oracle.identify_stalls(np.asarray(raw, np.float64)))
+            assert len(want) >= 1 and np.array_equal(got[i], want), (dt, i)

@@ -948,6 +948,7 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, cons
     ReadState &r = rs[ri];
     if (r.status != TBA_OK) return;
     if (r.path == PATH_NONE) { r.status = TBA_INTERNAL; return; }
+    if (r.is_long && r.path == PATH_ADAPTIVE && r.W <= 1024) return; // k_main_tb_long (k_long.h)
     const i64 B = r.B;
     const int Wi = (int)r.W;
     const int rowb = (int)mv_row_bytes(r.W);            // bytes per packed row (multiple of 64)

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 
     const int w = (int)dp->p.running_stat_width, w2 = 2 * w;
     if (tid < CS_READS) {
         const i64 ri = r0 + tid;
-        const bool live = ri < n_reads && rs[ri].status == TBA_OK;
+        // (long reads have a workgroup of their own: k_cumsum_scores_long, k_long.h)
+        const bool live = ri < n_reads && rs[ri].status == TBA_OK && !rs[ri].is_long;
         s_off[tid] = live ? rs[ri].raw_off : 0;
         s_n[tid] = live ? rs[ri].n_raw : 0;
         if (MODE == 1 && live) score[rs[ri].raw_off + ri] = 0.0; // c[0]

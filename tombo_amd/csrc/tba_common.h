@@ -47,7 +47,8 @@ struct ReadState {
     i64 ev_off, num_events;   // into valid_cpts / event_means (capacity num_events per read)
     i64 stall_off, n_stall;
     i32 status, path, start_state, sv_flags;
-    i32 n_start_calls, changed, pad0, pad1;
+    i32 n_start_calls, changed, pad0;
+    i32 is_long;              // more than TBA_LONG_RAW samples or TBA_LONG_BASES bases (k_long.h)
     double shift, scale, lower, upper; // scale values in force after segment_signal
     i32 has_lims, pad2;
     i64 n_cpts, n_ev;

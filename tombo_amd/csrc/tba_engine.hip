@@ -7,6 +7,7 @@
 #include "k_prep_raw.h"
 #include "k_dp.h"
 #include "k_dp_multi.h"
+#include "k_long.h"
 #include "k_tail.h"
 #include "k_cabi.h"
 
@@ -100,17 +101,20 @@ struct tba_engine {
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
-        d_moves, d_dscr, d_wide, d_stat, d_order;
+        d_moves, d_dscr, d_wide, d_stat, d_order, d_long;
     PinBuf h_order;               // read indices by decreasing length (k_dp_multi's grouping)
+    PinBuf h_long;                // indices of the long reads (k_long.h)
+    i64 n_long = 0;
     void release_all()
     {
         DevBuf *all[] = {&d_rs, &d_dp, &d_kmeans, &d_ksds, &d_raw, &d_norm, &d_norm_out, &d_csum,
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq, &d_order};
+                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq, &d_order, &d_long};
         for (DevBuf *b : all) b->release();
         h_order.release();
+        h_long.release();
         h_rs.release();
         h_dp.release();
     }
@@ -269,6 +273,7 @@ static int plan_batch(const tba_params *p, const tba_opts *o, i64 K, i64 n, cons
         if (num_events <= 1 || n_raw < 4 * p->running_stat_width + 2) { r.status = TBA_INTERNAL; continue; }
         z.max_raw = std::max(z.max_raw, n_raw);
         z.max_B = std::max(z.max_B, B);
+        r.is_long = n_raw > TBA_LONG_RAW || B > TBA_LONG_BASES;
         const i64 n_ev = num_events - 1;
         const bool short_read = n_ev < p->start_bw + p->start_n_bases || B < p->start_n_bases;
         // packed move rows: the adaptive band, or the whole-read static band of a short read
@@ -336,6 +341,7 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     if (z.n_stall > 0) BUF(d_stall, (size_t)z.n_stall * 16);
     BUF(d_skipq, 64 + 3 * (N * 32 + 4096) * 8);
     BUF(d_order, N * 4);
+    BUF(d_long, N * 4);
     BUF(d_res, N * sizeof(tba_read_result));
     BUF(d_segs32, (Bt + N) * 4);
 #undef BUF
@@ -445,6 +451,12 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
         for (i64 i = 0; i < n; i++) ord[i] = (i32)i;
         std::stable_sort(ord, ord + n, [hrs](i32 a, i32 b) { return hrs[a].B > hrs[b].B; });
         HIP_TRY(hipMemcpyAsync(e->d_order.p, ord, N * 4, hipMemcpyHostToDevice, s));
+        // the long reads, longest first (is_long was set by plan_batch)
+        if (e->h_long.ensure(N * 4)) return TBA_E_NOMEM;
+        i32 *lg = e->h_long.as<i32>();
+        e->n_long = 0;
+        for (i64 i = 0; i < n; i++) if (hrs[ord[i]].is_long) lg[e->n_long++] = ord[i];
+        if (e->n_long > 0) HIP_TRY(hipMemcpyAsync(e->d_long.p, lg, (size_t)e->n_long * 4, hipMemcpyHostToDevice, s));
     }
     memcpy(e->h_dp.p, &e->hp, sizeof(DevParams));
     HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.p, N * sizeof(ReadState), hipMemcpyHostToDevice, s));
@@ -565,6 +577,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         u64 *bits = e->d_state.as<u64>();
         if (cs_reads_for(n) == 20) RAW_DISPATCH(rdt, (k_cumsum_scores<20, RT, 1><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
         else RAW_DISPATCH(rdt, (k_cumsum_scores<32, RT, 1><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
+        if (e->n_long > 0) RAW_DISPATCH(rdt, (k_cumsum_scores_long<RT, 1><<<(unsigned)e->n_long, 256, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_raw.as<RT>(), csum)));
         if (e->hp.o.stall_n_windows == 7) k_stall_metric<7><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, csum, bits);
         else k_stall_metric<0><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, csum, bits);
         k_stall_runs<<<dim3(gx(e->max_raw / 64 + 1), nb), 256, 0, s>>>(rs, dp, bits, e->d_stall.as<i64>());
@@ -580,6 +593,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         if (fused_scores) {
             if (cs_reads_for(n) == 20) k_cumsum_scores<20><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
             else k_cumsum_scores<32><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
+            if (e->n_long > 0) k_cumsum_scores_long<double, 0><<<(unsigned)e->n_long, 256, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_norm.as<double>(), e->d_score.as<double>());
         }
         else k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
     }
@@ -631,6 +645,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     MARK(); // 10 main tb
     if (ON(TBA_STAGE_ASSIGN)) {
         k_main_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        if (e->n_long > 0) k_main_tb_long<<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         k_tb_gather<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
     }
     MARK(); // 11 skip resolve

@@ -74,7 +74,7 @@ _FIXED = 512 << 20  # arenas' constant slack (moves 64 MB + skip 256 MB + roundi
 
 
 def plan_batches(n_raw, seq_len, params, opts, kmer_width, mem_budget, raw_dtype=np.float64,
-                 max_reads=MAX_READS, sort=True):
+                 max_reads=MAX_READS, sort=True, tail_bases=None):
     """Cut reads 0..n-1 into batches.
 
     params / opts: `_native.Params` / `_native.Opts` of the job; mem_budget: device bytes one
@@ -83,6 +83,14 @@ def plan_batches(n_raw, seq_len, params, opts, kmer_width, mem_budget, raw_dtype
     without it the input order is kept and the list is only cut (callers that need results in input order
     scatter by the returned indices either way).  A single read that exceeds the budget on its own
     still gets a batch (the engine will report what it cannot do).
+
+    tail_bases: reads with more bases than this go into batches of their own, in front.  The
+    banded DP and the traceback of a read are serial chains (about 1.5 us per base for a lone
+    wavefront: 0.3 s for 200 kb), so a batch is only done when its longest read is; a batch that
+    mixes the tail with thousands of ordinary reads holds most of the machine's wave slots for that
+    long and starves the batches running beside it (measured: co-running kernels 10x slower).  A
+    tail batch of a few hundred reads occupies a few hundred wave slots; the ordinary batches run
+    at full speed next to it and the tail batches of successive passes overlap each other.
     """
     S = np.asarray(n_raw, dtype=np.int64)
     L = np.asarray(seq_len, dtype=np.int64)
@@ -90,6 +98,13 @@ def plan_batches(n_raw, seq_len, params, opts, kmer_width, mem_budget, raw_dtype
     if n == 0:
         return []
     B = np.maximum(L - int(kmer_width) + 1, 0)
+    if tail_bases is not None and sort:
+        tail = np.flatnonzero(B > int(tail_bases))
+        if 0 < tail.shape[0] < n:
+            rest = np.flatnonzero(B <= int(tail_bases))
+            head = plan_batches(S[tail], L[tail], params, opts, kmer_width, mem_budget, raw_dtype, max_reads)
+            body = plan_batches(S[rest], L[rest], params, opts, kmer_width, mem_budget, raw_dtype, max_reads)
+            return [tail[x] for x in head] + [rest[x] for x in body]
     order = np.lexsort((-S, -B)) if sort else np.arange(n)
     est = estimate_bytes(S, L, params, opts, kmer_width, raw_dtype)[order]
     budget = max(float(mem_budget) - _FIXED, 1.0)

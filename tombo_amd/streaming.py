@@ -18,6 +18,8 @@ record per read + int32 base boundaries (4 bytes / base); the normalised signal 
 (`want_norm`) -- Tombo itself stores only scale values and boundaries and re-normalises the raw
 signal when a resquiggled read is loaded (tombo_helper.py:2341-2460, tombo_stats.py:482-573).
 """
+import time
+
 import numpy as np
 
 from . import _native
@@ -123,6 +125,7 @@ class _Slot(object):
     def __init__(self, device):
         self.eng = _native.Engine(device)
         self.pending = None       # (batch, output set index)
+        self.seq = 0              # submission number of the batch it holds
         self.outs = [dict(), dict()]
         self.flip = 0
 
@@ -150,7 +153,8 @@ class StreamPipeline(object):
                  seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False), const_scale=None,
                  skip_seq_scaling=False, max_raw_cpts=MAX_RAW_CPTS,
                  min_event_to_seq_ratio=MIN_EVENT_TO_SEQ_RATIO, want_norm=False,
-                 segs_dtype=np.int32, reverse_raw=False, stall_params=None, subsample_seed=None):
+                 segs_dtype=np.int32, reverse_raw=False, stall_params=None, subsample_seed=None,
+                 in_order=True):
         from . import resquiggle as rq
         if device is None:
             device = rq.default_device()
@@ -172,12 +176,30 @@ class StreamPipeline(object):
         assert self.segs_dtype in (np.dtype(np.int32), np.dtype(np.int64))
         self._next = 0
         self.n_submitted = 0
+        # in_order=False: a batch goes to ANY slot that is free or has finished (polled, never
+        # blocking while one is idle) and results come back as they complete (match them by `tag`).
+        # With ragged jobs -- a batch of 100 kb reads runs ten times longer than its neighbours --
+        # round-robin slots make the host wait behind the long batch while other slots sit idle.
+        self.in_order = bool(in_order)
+        self._seq = 0
+
+    def reserve(self, max_reads, max_segs, max_raw=0):
+        """Size the page-locked output arrays of every slot for batches of up to `max_reads` reads,
+        `max_segs` boundaries (bases + reads) and `max_raw` samples now.  Growing one later means
+        hipHostFree, which waits for ALL work on the device: with ragged batches landing on any slot
+        (`in_order=False`) that stalls the pipeline behind the longest batch in flight."""
+        for s in self.slots:
+            for which in (0, 1):
+                s.out_arrays(which, int(max_reads), int(max_segs), int(max_raw), self.segs_dtype, self.want_norm)
 
     def _finish(self, slot):
         batch, which, res, segs, norm = slot.pending
         slot.pending = None
         eng = slot.eng
         eng.sync()
+        rel = getattr(batch, 'release', None)
+        if rel is not None:   # the batch's staging buffers (ReadFeeder) are free again
+            rel()
         n_segs = int(eng.seg_off[-1])
         return BatchResults(batch.tag, eng.n, res[:eng.n], segs[:n_segs], eng.seg_off,
                             None if norm is None else norm[:eng.n_raw_total], eng.raw_off,
@@ -187,9 +209,18 @@ class StreamPipeline(object):
         """Enqueue one batch (upload, kernels, download -- nothing here waits for them) on the
         next slot.  If that slot still held an earlier batch, that one is finished first and its
         results are returned (else None)."""
-        slot = self.slots[self._next]
-        self._next = (self._next + 1) % len(self.slots)
+        if self.in_order:
+            slot = self.slots[self._next]
+            self._next = (self._next + 1) % len(self.slots)
+        else:
+            slot = next((s for s in self.slots if s.pending is None), None)
+            while slot is None:   # all busy: take the first one to finish, whichever it is
+                slot = next((s for s in self.slots if not s.eng.query()), None)
+                if slot is None:
+                    time.sleep(0.0002)
         done = self._finish(slot) if slot.pending is not None else None
+        self._seq += 1
+        slot.seq = self._seq
         eng = slot.eng
         if self.subsample_seed is not None:   # another key for every batch of the job
             self.opts.subsample_seed = (int(self.subsample_seed) + 0x9e3779b97f4a7c15 * self.n_submitted) \
@@ -212,8 +243,9 @@ class StreamPipeline(object):
     def flush(self):
         """finish everything in flight, oldest first"""
         out = []
-        for k in range(len(self.slots)):
-            slot = self.slots[(self._next + k) % len(self.slots)]
+        order = [self.slots[(self._next + k) % len(self.slots)] for k in range(len(self.slots))] \
+            if self.in_order else sorted(self.slots, key=lambda s: s.seq)
+        for slot in order:
             if slot.pending is not None:
                 out.append(self._finish(slot))
         return out
@@ -246,23 +278,40 @@ class ReadFeeder(object):
     over one read at a time; a batch engine wants flat CSR buffers.  `pack(raws, seqs)` copies the
     reads of one batch into the next of `n_stages` staging sets with native threads
     (`tba_pack_reads`, GIL released); `prefetch` does the same on a helper thread while the caller
-    submits the previous batch.  A staging set may be reused once the batch packed into it has
-    been finished by the pipeline: with `n_slots` batches in flight and one being packed,
-    `n_slots + 2` sets rotate safely.
+    submits the previous batch.  A staging set is busy from `pack` until the pipeline has finished
+    the batch packed into it (`StreamPipeline._finish` calls the batch's `release`); batches may
+    finish in any order, and a new set is allocated when all are busy (`n_slots + 2` in steady
+    state: `n_slots` in flight, one being submitted, one being packed).
     """
 
     def __init__(self, n_slots=3, reverse=False, n_threads=None):
+        import threading
         from concurrent.futures import ThreadPoolExecutor
         self.stages = [_native.PinnedStage() for _ in range(int(n_slots) + 2)]
+        self._busy = [False] * len(self.stages)
+        self._lock = threading.Lock()
         self.reverse, self.n_threads = bool(reverse), n_threads
-        self._k = 0
         self._ex = ThreadPoolExecutor(1)
         self._pending = None
 
+    def _take_stage(self):
+        with self._lock:
+            for k, b in enumerate(self._busy):
+                if not b:
+                    self._busy[k] = True
+                    return k
+            self.stages.append(_native.PinnedStage())
+            self._busy.append(True)
+            return len(self.stages) - 1
+
+    def _release_stage(self, k):
+        with self._lock:
+            self._busy[k] = False
+
     def pack(self, raws, seqs, samp_inds=None, stalls=None, tag=None):
         """one batch, packed now; seqs: str / bytes of ACGT"""
-        stage = self.stages[self._k % len(self.stages)]
-        self._k += 1
+        k = self._take_stage()
+        stage = self.stages[k]
         raw, raw_off, seq, seq_off, _ = _native.pack_reads(
             raws, seqs, reverse=self.reverse, stage=stage, n_threads=self.n_threads)
         si = None
@@ -277,7 +326,9 @@ class ReadFeeder(object):
                                      MAX_POINTS_FOR_THEIL_SEN)
         st, sto = _native.pack_stalls(stalls) if stalls is not None and \
             any(s is not None and len(s) for s in stalls) else (None, None)
-        return ReadBatch(raw, raw_off, seq, seq_off, si, st, sto, tag)
+        b = ReadBatch(raw, raw_off, seq, seq_off, si, st, sto, tag)
+        b.release = lambda: self._release_stage(k)
+        return b
 
     def prefetch(self, raws, seqs, **kw):
         """start packing a batch on the helper thread; `take()` returns it"""
