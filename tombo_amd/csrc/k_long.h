@@ -121,10 +121,13 @@ __global__ __launch_bounds__(256) void k_cumsum_scores_long(const ReadState *rs,
 // ---- c_banded_traceback (pyx:281-310) + _trim_traceback (resquiggle.py:754-764) of a long read on
 // the adaptive path, one WAVEFRONT per read.  k_main_tb walks a read with one lane (~95 dependent
 // instructions per row); here the 64 lanes hold the packed moves of a whole row (one dword = 16
-// cells per lane: bands up to 1024 cells), "the highest non-stay cell at or below the position" is
-// one masked compare + ballot + two scalar bit scans, and the rows of a block of 16 are fetched
-// together (16 coalesced row loads in flight, the band starts in one).  ~25 instructions per row on
-// the dependent chain.  grid: one block of 64 per entry of `long_idx`; reads it does not take
+// cells per lane: bands up to 1024 cells) and the walk itself runs on the SCALAR unit: the two
+// dwords around the position are read into scalar registers (v_readlane with a scalar lane index),
+// "the highest non-stay cell at or below the position" is a mask and a find-first-bit there (a
+// dependent scalar operation costs a few cycles, a vector one in a lone wavefront ~8 and a
+// cross-lane one more); stay runs longer than the 16-31 cells below the position fall back to a
+// masked compare + ballot over the whole row.  The rows of a block of 16 are fetched together (16
+// coalesced row loads in flight, the band starts in one).  grid: one block of 64 per entry of `long_idx`; reads it does not take
 // (status, path, band wider than 1024) are left to k_main_tb.
 #define TBL_R 16
 __device__ __forceinline__ bool tb_long_takes(const ReadState &r)
@@ -155,16 +158,25 @@ __global__ __launch_bounds__(64) void k_main_tb_long(ReadState *rs, const i32 *l
     if (cur_ev + 1 >= 0) first_nonneg = B;
     if (lane == 0) tb[B] = v_top;
     int last_val = v_top;
-    for (int r0 = B; r0 >= 1 && rc == TBA_OK; r0 -= TBL_R) {
-        // fetch the block: my dword of every row, the band starts (lane k: row r0 - k)
-        u32 d[TBL_R];
+    // a block: my dword of each of its 16 rows and the band starts (lane k: row r0 - k); the next
+    // block is fetched while this one is walked
+    u32 d[TBL_R], dn[TBL_R];
+    int st_v, st_n;
+    auto fetch = [&](int r0, u32 (&dd)[TBL_R], int &sv) {
 #pragma unroll
         for (int k = 0; k < TBL_R; k++) {
             const int rr = r0 - k >= 1 ? r0 - k : 1;
-            d[k] = lane < roww ? *(const u32 *)(mv + (i64)rr * rowb + 4 * lane) : 0u;
+            dd[k] = lane < roww ? *(const u32 *)(mv + (i64)rr * rowb + 4 * lane) : 0u;
         }
         const int rs_k = r0 - lane >= 1 ? r0 - lane : 1;
-        const int st_v = lane < TBL_R ? (int)st[rs_k - 1] : 0;
+        sv = lane < TBL_R ? (int)st[rs_k - 1] : 0;
+    };
+    fetch(B, dn, st_n);
+    for (int r0 = B; r0 >= 1 && rc == TBA_OK; r0 -= TBL_R) {
+#pragma unroll
+        for (int k = 0; k < TBL_R; k++) d[k] = dn[k];
+        st_v = st_n;
+        if (r0 - TBL_R >= 1) fetch(r0 - TBL_R, dn, st_n);
         int res = 0; // lane k: the value of tb[r0 - k - 1]
 #pragma unroll
         for (int k = 0; k < TBL_R; k++) {
@@ -173,7 +185,27 @@ __global__ __launch_bounds__(64) void k_main_tb_long(ReadState *rs, const i32 *l
             const int stv = __builtin_amdgcn_readlane(st_v, k);
             int bp = cur_ev - stv;
             int m;
+            bool found = false;
             if (__builtin_expect(bp >= 0 && bp < Wi, 1)) {
+                // scalar fast path: the dword holding the position and the one below it (32 cells)
+                // are read into scalar registers; "highest non-stay cell at or below" is a mask and
+                // a find-first-bit on the scalar unit, whose dependent operations cost a few cycles
+                const int q = bp >> 4;
+                const u32 hi = (u32)__builtin_amdgcn_readlane((int)d[k], q);
+                const u32 lo = q > 0 ? (u32)__builtin_amdgcn_readlane((int)d[k], q - 1) : 0u;
+                const u64 win = ((u64)hi << 32) | lo; // cells [16 (q - 1), 16 (q + 1))
+                u64 nz = (win | (win >> 1)) & 0x5555555555555555ull;
+                const int top = 34 + 2 * (bp & 15); // bits of the fields at or below the position
+                nz = top >= 64 ? nz : (nz & ((1ull << top) - 1ull));
+                if (__builtin_expect(nz != 0, 1)) {
+                    const int f = (63 - __builtin_clzll(nz)) >> 1;
+                    bp = 16 * (q - 1) + f;
+                    m = (int)((win >> (2 * f)) & 3ull);
+                    found = true;
+                }
+            }
+            if (found) {
+            } else if (__builtin_expect(bp >= 0 && bp < Wi, 1)) { // a stay run of more than 16-31 cells: the whole row
                 const int q = bp >> 4, s2 = 2 * (bp & 15) + 2;
                 const u32 e = (d[k] | (d[k] >> 1)) & 0x55555555u;
                 const u32 em = lane < q ? e : (lane == q ? (s2 >= 32 ? e : (e & ((1u << s2) - 1u))) : 0u);
@@ -199,11 +231,14 @@ __global__ __launch_bounds__(64) void k_main_tb_long(ReadState *rs, const i32 *l
                 int mm = 0;
                 for (;;) {
                     const int bb = bp < 0 ? bp + Wi : bp;
-                    mm = (row[bb >> 2] >> (2 * (bb & 3))) & 3;
+                    mm = uni((int)((row[bb >> 2] >> (2 * (bb & 3))) & 3)); // (every lane reads the same byte)
                     if (mm != 0) break;
                     bp--;
                     if (bp < -Wi) { rc = TBA_INTERNAL; break; }
                 }
+                // (every lane walked the same cells: tell the compiler, or the whole loop state is
+                // kept in vector registers under exec masks)
+                rc = uni(rc); bp = uni(bp); mm = uni(mm);
                 if (rc != TBA_OK) continue;
                 m = mm;
             }
