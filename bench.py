@@ -793,7 +793,7 @@ def main():
                 insts = float(vc[key]['k_dp_valu_wave_insts_per_read']) * a.reads
                 peak = 1024 * float(vc['clock_ghz']) * 1e9 / 4.0  # 1024 SIMDs, one f64 VALU op / 4 cycles
                 res['roofline_valu'] = {
-                    'bound': 'valu_f64_issue', 'kernel': 'k_dp (main adaptive banded forward pass)',
+                    'bound': 'valu_f64_issue', 'kernel': vc[key].get('kernel', 'k_dp') + ' (main adaptive banded forward pass)',
                     'achieved': round(insts / (dp_ms * 1e-3) / 1e9, 2), 'peak': round(peak / 1e9, 2),
                     'unit': 'G wave-instr/s', 'frac': round(insts / (dp_ms * 1e-3) / peak, 4),
                     'valu_insts_per_dp_row': vc[key].get('valu_insts_per_row'),

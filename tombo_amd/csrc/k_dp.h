@@ -228,7 +228,13 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
     constexpr int S = CPL < 8 ? CPL : 8;     // band offsets 0..S take the register-renaming path
     constexpr int RING = CPL <= 4 ? 512 : CPL <= 8 ? 1024 : CPL <= 16 ? 2048 : CPL <= 32 ? 4096 : 8192; // power of two >= 128*CPL
     constexpr int BPL = mv_bpl(CPL);
+#ifdef TBA_DP_LDS_PAD
+    // experiment: cap the kernel at fewer waves per SIMD through its LDS footprint, so that the
+    // memory-bound kernels of another sub-batch (other stream) find registers beside it
+    __shared__ double ring[RING + CPL + TBA_DP_LDS_PAD];
+#else
     __shared__ double ring[RING + CPL];      // + mirror of the first CPL slots: reads never wrap
+#endif
     ReadState &r = rs[DIRECT ? 0 : blockIdx.x];
     if (!DIRECT && r.status != TBA_OK) return;
     const tba_params &P = dp->p;

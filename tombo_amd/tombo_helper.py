@@ -247,61 +247,70 @@ def read_index(index_fn, basedir=''):
     return out
 
 
+# The on-disk layout of a resquiggled read (tombo_helper.py:2341-2460; docs/resquiggle.rst:172-194)
+# as DATA: (attribute name, getter, written only when not None).  Names and order are the format.
+_SUBGROUP_ATTRS = (
+    ('status', lambda r, x: 'success', False),
+    ('rna', lambda r, x: x['rna'], False),
+    ('signal_match_score', lambda r, x: r.sig_match_score, True),
+    ('shift', lambda r, x: r.scale_values.shift, False),
+    ('scale', lambda r, x: r.scale_values.scale, False),
+    ('norm_type', lambda r, x: x['norm_type'], False),
+    ('lower_lim', lambda r, x: r.scale_values.lower_lim, True),
+    ('upper_lim', lambda r, x: r.scale_values.upper_lim, True),
+    ('outlier_threshold', lambda r, x: r.scale_values.outlier_thresh, True),
+)
+_ALIGNMENT_ATTRS = (
+    ('mapped_start', lambda r: r.genome_loc.Start),
+    ('mapped_end', lambda r: r.genome_loc.Start + len(r.segs) - 1),
+    ('mapped_strand', lambda r: r.genome_loc.Strand),
+    ('mapped_chrom', lambda r: r.genome_loc.Chrom),
+)
+_ALIGN_INFO_ATTRS = (   # only when the read carries an alignInfo
+    ('clipped_bases_start', 'ClipStart'), ('clipped_bases_end', 'ClipEnd'),
+    ('num_insertions', 'Insertions'), ('num_deletions', 'Deletions'),
+    ('num_matches', 'Matches'), ('num_mismatches', 'Mismatches'),
+)
+
+
 def write_new_fast5_group(fast5_data, corr_grp_slot, rsqgl_res, norm_type, compute_sd,
                           alignVals=None, old_segs=None, rna=False, event_data=None):
-    """Write a resquiggled read into an open FAST5 file -- groups, attributes and the `Events`
-    dataset exactly as tombo_helper.write_new_fast5_group (tombo_helper.py:2341-2460) lays them
-    out.  `fast5_data` is anything with the h5py group interface (`__getitem__`, `create_group`,
+    """Write a resquiggled read into an open FAST5 file: the groups, attributes and `Events`
+    dataset of the tables above (the reference's writer: tombo_helper.py:2341-2460).
+    `fast5_data` is anything with the h5py group interface (`__getitem__`, `create_group`,
     `create_dataset`, `.attrs`): an `h5py.File` where h5py is installed, or an in-memory stand-in
-    (the image this engine is built in has no HDF5 library; tests use a dict-backed group).
+    (the image this engine is built in has no HDF5 library; tests use a dict-backed group and
+    compare the tree with the one the reference's own writer leaves on it).
     `event_data`: the Events table if already computed on the device
     (`resquiggle_batch_events`), else it is computed here through the HIP kernels."""
     import numpy as np
     try:
         if event_data is None:
             event_data = get_event_data(rsqgl_res, compute_sd)
+        datasets = []
         if alignVals is not None:
-            r_align_vals, g_align_vals = zip(*alignVals)
-            np_read_align = np.array(r_align_vals, dtype='S1')
-            np_genome_align = np.array(g_align_vals, dtype='S1')
+            for name, col in zip(('read_alignment', 'genome_alignment'), zip(*alignVals)):
+                datasets.append((name, np.array(col, dtype='S1')))
+        if old_segs is not None:
+            datasets.append(('read_segments', old_segs))
     except Exception:
         raise TomboError('Error computing new events')
     try:
-        corr_grp = fast5_data['/Analyses'][corr_grp_slot]
-        corr_subgrp = corr_grp.create_group(rsqgl_res.align_info.Subgroup)
-        corr_subgrp.attrs['status'] = 'success'
-        corr_subgrp.attrs['rna'] = rna
-        if rsqgl_res.sig_match_score is not None:
-            corr_subgrp.attrs['signal_match_score'] = rsqgl_res.sig_match_score
-        sv = rsqgl_res.scale_values
-        corr_subgrp.attrs['shift'] = sv.shift
-        corr_subgrp.attrs['scale'] = sv.scale
-        corr_subgrp.attrs['norm_type'] = norm_type
-        if sv.lower_lim is not None:
-            corr_subgrp.attrs['lower_lim'] = sv.lower_lim
-        if sv.upper_lim is not None:
-            corr_subgrp.attrs['upper_lim'] = sv.upper_lim
-        if sv.outlier_thresh is not None:
-            corr_subgrp.attrs['outlier_threshold'] = sv.outlier_thresh
-        aln = corr_subgrp.create_group('Alignment')
-        aln.attrs['mapped_start'] = rsqgl_res.genome_loc.Start
-        aln.attrs['mapped_end'] = rsqgl_res.genome_loc.Start + len(rsqgl_res.segs) - 1
-        aln.attrs['mapped_strand'] = rsqgl_res.genome_loc.Strand
-        aln.attrs['mapped_chrom'] = rsqgl_res.genome_loc.Chrom
-        ai = rsqgl_res.align_info
-        if ai is not None:
-            aln.attrs['clipped_bases_start'] = ai.ClipStart
-            aln.attrs['clipped_bases_end'] = ai.ClipEnd
-            aln.attrs['num_insertions'] = ai.Insertions
-            aln.attrs['num_deletions'] = ai.Deletions
-            aln.attrs['num_matches'] = ai.Matches
-            aln.attrs['num_mismatches'] = ai.Mismatches
-        if alignVals is not None:
-            aln.create_dataset('read_alignment', data=np_read_align, compression='gzip')
-            aln.create_dataset('genome_alignment', data=np_genome_align, compression='gzip')
-        if old_segs is not None:
-            aln.create_dataset('read_segments', data=old_segs, compression='gzip')
-        ev = corr_subgrp.create_dataset('Events', data=event_data, compression='gzip')
+        sub = fast5_data['/Analyses'][corr_grp_slot].create_group(rsqgl_res.align_info.Subgroup)
+        ctx = dict(rna=rna, norm_type=norm_type)
+        for name, get, optional in _SUBGROUP_ATTRS:
+            value = get(rsqgl_res, ctx)
+            if not (optional and value is None):
+                sub.attrs[name] = value
+        aln = sub.create_group('Alignment')
+        for name, get in _ALIGNMENT_ATTRS:
+            aln.attrs[name] = get(rsqgl_res)
+        if rsqgl_res.align_info is not None:
+            for name, field in _ALIGN_INFO_ATTRS:
+                aln.attrs[name] = getattr(rsqgl_res.align_info, field)
+        for name, data in datasets:
+            aln.create_dataset(name, data=data, compression='gzip')
+        ev = sub.create_dataset('Events', data=event_data, compression='gzip')
         ev.attrs['read_start_rel_to_raw'] = rsqgl_res.read_start_rel_to_raw
     except Exception:
         raise TomboError('Error writing resquiggle information back into fast5 file.')

@@ -6,7 +6,10 @@
 #include "../tombo_amd/csrc/tba_common.h"
 #include "../tombo_amd/csrc/k_select.h"
 #include "../tombo_amd/csrc/k_segment.h"
+#include "../tombo_amd/csrc/k_prep_raw.h"
 #include "../tombo_amd/csrc/k_dp.h"
+#include "../tombo_amd/csrc/k_dp_multi.h"
+#include "../tombo_amd/csrc/k_long.h"
 #include "../tombo_amd/csrc/k_tail.h"
 #include <cstdio>
 
@@ -34,6 +37,14 @@ int main()
     report("k_dp<8,false>", k_dp<8, false>, 64);
     report("k_dp<5,false>", k_dp<5, false>, 64);
     report("k_dp<12,false>", k_dp<12, false>, 64);
+    report("k_dp_multi<4,2>", k_dp_multi<4, 2>, 64);
+    report("k_dp_multi<8,4>", k_dp_multi<8, 4>, 64);
+    report("k_dp_multi<8,2>", k_dp_multi<8, 2>, 64);
+    report("k_dp_multi<10,2>", k_dp_multi<10, 2>, 64);
+    report("k_cumsum_scores<32,i16,1>", k_cumsum_scores<32, int16_t, 1>, 256);
+    report("k_stall_metric<7>", k_stall_metric<7>, 256);
+    report("k_cumsum_scores_long<f64,0>", k_cumsum_scores_long<double, 0>, 256);
+    report("k_main_tb_long", k_main_tb_long, 64);
     report("k_main_tb", k_main_tb, 64);
     report("k_skip_dp", k_skip_dp, 64);
     report("k_theil_sen", k_theil_sen, SEL_NT);

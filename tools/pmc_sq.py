@@ -26,7 +26,7 @@ def main(db, reads, rows, key=None):
         if kname.startswith('__amd'):
             continue
         print('%-40s %s' % (kname[:40], ' '.join('%18.4g' % tab[kname].get(x, (0, 0))[0] for x in ctrs)))
-    dp = [k for k in tab if k.startswith('k_dp<') and 'SQ_INSTS_VALU' in tab[k]]
+    dp = [k for k in tab if k.startswith(('k_dp<', 'k_dp_multi<')) and 'SQ_INSTS_VALU' in tab[k]]
     if dp:
         main_dp = max(dp, key=lambda k: tab[k]['SQ_INSTS_VALU'][0])
         v, n = tab[main_dp]['SQ_INSTS_VALU']
