@@ -598,20 +598,24 @@ def pack_reads(raws, seqs, reverse=False, pinned=False, n_threads=None, stage=No
 
 def unpack_reads(src, src_off, count, dtype=None, n_threads=None):
     """tba_unpack_reads: [src[src_off[i]:src_off[i] + count[i]].copy() for i], the copies made
-    by native threads into fresh per-read arrays"""
+    by native threads.  The per-read arrays are views of ONE fresh allocation (a single large
+    mapping takes huge pages where the kernel offers them: first-touch page faults, not the copy,
+    bound this step with one malloc per read), so they keep each other's memory alive."""
     L = lib()
     n = len(count)
     dt = src.dtype if dtype is None else np.dtype(dtype)
-    outs = [np.empty(int(c), dt) for c in count]
-    if n == 0:
-        return outs
-    so = np.ascontiguousarray(src_off, dtype=np.int64)
     cnt = np.ascontiguousarray(count, dtype=np.int64)
-    dp = (C.c_void_p * n)(*[_addr(o) for o in outs])
+    if n == 0:
+        return []
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(cnt, out=off[1:])
+    arena = np.empty(int(off[-1]), dt)
+    so = np.ascontiguousarray(src_off, dtype=np.int64)
+    dp = (np.uint64(_addr(arena)) + off[:-1].astype(np.uint64) * np.uint64(dt.itemsize)).astype(np.uint64)
     if n_threads is None:
-        n_threads = min(16, os.cpu_count() or 1)
+        n_threads = min(32, os.cpu_count() or 1)
     rc = L.tba_unpack_reads(i64(n), C.c_void_p(_addr(src)), i64(dt.itemsize), _p(so, i64),
-                            _p(cnt, i64), dp, C.c_int(int(n_threads)))
+                            _p(cnt, i64), dp.ctypes.data_as(C.POINTER(C.c_void_p)), C.c_int(int(n_threads)))
     if rc != 0:
         raise EngineError('tba_unpack_reads failed (%d): %s' % (rc, L.tba_last_error().decode()))
-    return outs
+    return np.split(arena, off[1:-1])
