@@ -333,6 +333,8 @@ def main():
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
                          'engine / stream (kernels of different sub-batches overlap)')
+    ap.add_argument('--longtail-max-bases', type=int, default=200000,
+                    help='longtail preset: clip of the log-normal read lengths (round 2 used 100000)')
     ap.add_argument('--tail-bases', type=int, default=30000,
                     help='longtail preset: reads longer than this form batches of their own (planner.plan_batches)')
     ap.add_argument('--api-reads', type=int, default=2000, help='reads of the resquiggle_batch API leg (0: skip)')
@@ -386,7 +388,7 @@ def main():
     stall_params = th.stallParams(**STALL_PARAMS) if rna else None
     workers = max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))
     seed0 = 1000003 * (rank + 1)    # every rank has its own, distinct reads
-    bases = longtail_bases(a.reads, seed0) if longtail else np.full(a.reads, a.bases, np.int64)
+    bases = longtail_bases(a.reads, seed0, a.longtail_max_bases) if longtail else np.full(a.reads, a.bases, np.int64)
     want_dac = a.e2e == 'compact' or a.api_reads > 0
     t_gen = time.perf_counter()
     seqs, raws, dacs = make_reads(bases, seed0, workers, samp_name, want_dac)
@@ -739,7 +741,7 @@ def main():
         res = {
             'metric': 'resquiggle reads/s (%s, bw=%d)' % (
                 '10 kb DNA' if (samp_name, a.bases, longtail) == ('DNA', 10000, False) else
-                'long-tailed 1-200 kb DNA' if longtail else
+                'long-tailed 1-%d kb DNA' % (a.longtail_max_bases // 1000) if longtail else
                 '%g kb %s' % (a.bases / 1000.0, samp_name), a.bandwidth), 'value': round(value, 2),
             'unit': 'reads/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
@@ -747,7 +749,7 @@ def main():
             'config': {'workload': '%d synthetic %s %s reads per GPU per step, bandwidth=%d, full '
                                    'resquiggle_read path%s, float64 inputs resident in HBM; %d passes '
                                    'drawn from the host work queue by %d rank(s)' % (
-                                       a.reads, 'long-tailed (1-200 kb)' if longtail else '%d-base' % a.bases,
+                                       a.reads, 'long-tailed (1-%d kb)' % (a.longtail_max_bases // 1000) if longtail else '%d-base' % a.bases,
                                        samp_name, a.bandwidth,
                                        ' incl. the worker\'s stall detection (ts.identify_stalls) on the device' if rna else '',
                                        a.steps * world, world),
