@@ -316,3 +316,100 @@ def test_stream_pipeline_slot_logic_with_stub_engines(monkeypatch):
         if e[0] == 'up' and e[2] >= 2:
             assert ('sync', e[1], e[2] - 2) in log[:k]
     pipe.close()
+
+
+def test_planner_tail_batches():
+    """reads above tail_bases get batches of their own, in front; every read exactly once"""
+    from tombo_amd import planner, _native, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    p = _native.make_params(ts.load_resquiggle_parameters(samp)._replace(bandwidth=500))
+    o = _native.make_opts(outlier_thresh=5.0)
+    rng = np.random.default_rng(4)
+    B = np.clip(np.exp(rng.normal(np.log(8000.0), 0.9, 3000)), 1000, 200000).astype(np.int64)
+    S, L = B * 9 + 300, B + 5
+    plan = planner.plan_batches(S, L, p, o, 6, 3e9, tail_bases=30000)
+    assert np.array_equal(np.sort(np.concatenate(plan)), np.arange(3000))
+    n_tail = int((B > 30000).sum())
+    assert 0 < n_tail < 3000
+    seen = 0
+    for idx in plan:   # tail batches first, and never mixed with ordinary reads
+        is_tail = B[idx] > 30000
+        assert is_tail.all() or not is_tail.any()
+        if seen < n_tail:
+            assert is_tail.all()
+        seen += len(idx)
+    assert planner.plan_batches(S, L, p, o, 6, 3e9, tail_bases=10 ** 9)[0].shape[0] > 0   # no tail: plain plan
+
+
+def test_stream_pipeline_any_slot_and_feeder_staging(monkeypatch):
+    """in_order=False: a batch takes the first slot that is free or has finished (never waiting
+    behind a long one while another is idle), results come back as they complete; ReadFeeder hands
+    a staging set out again only after the batch packed into it was finished"""
+    from tombo_amd import streaming, _native, tombo_stats as ts, tombo_helper as th
+    clock = [0.0]
+
+    class StubEngine(object):
+        def __init__(self, device):
+            self.kmer_width = 6
+            self.busy_until = 0.0
+
+        def ensure_model(self, m):
+            pass
+
+        def upload_packed(self, p, o, raw, raw_off, seq, seq_off, **kw):
+            self.n = len(raw_off) - 1
+            self.raw_off = np.asarray(raw_off)
+            self.seg_off = np.arange(self.n + 1) * 3
+            self.n_raw_total = int(raw_off[-1])
+            self.dur = float(raw[0])          # the batch's first sample says how long it "runs"
+
+        def enqueue(self):
+            self.busy_until = clock[0] + self.dur
+
+        def download_async(self, results=None, **kw):
+            results['status'][:self.n] = 0
+
+        def query(self):
+            return clock[0] < self.busy_until
+
+        def sync(self):
+            clock[0] = max(clock[0], self.busy_until)
+
+        def get(self, what):
+            return np.zeros(32, np.float32)
+
+        def close(self):
+            pass
+
+    class StubPinned(object):
+        def __init__(self, shape, dtype):
+            self.a = np.zeros(shape, dtype)
+
+        def close(self):
+            pass
+    monkeypatch.setattr(_native, 'Engine', StubEngine)
+    monkeypatch.setattr(_native, 'PinnedArray', StubPinned)
+    monkeypatch.setattr(streaming.time, 'sleep', lambda dt: clock.__setitem__(0, clock[0] + 1.0))
+    params = ts.load_resquiggle_parameters(th.seqSampleType('DNA', False))
+    pipe = streaming.StreamPipeline(None, params, n_slots=3, device=0, outlier_thresh=5.0, in_order=False)
+    pipe.reserve(8, 64)
+    feeder = streaming.ReadFeeder(n_slots=3)
+    assert len(feeder.stages) == 5
+    done_tags = []
+    durs = [100, 5, 5, 5, 5, 5, 5]          # batch 0 is the long one
+    batches = []
+    for k, d in enumerate(durs):
+        b = feeder.pack([np.full(4, d, np.int16), np.full(3, d, np.int16)], ['ACGTACGTAC', 'ACGTACGTACG'], tag=k)
+        batches.append(b)
+        out = pipe.submit(b)
+        if out is not None:
+            done_tags.append(out.tag)
+    done_tags += [r.tag for r in pipe.flush()]
+    assert sorted(done_tags) == list(range(len(durs)))
+    assert done_tags[:4] == [1, 2, 3, 4] and done_tags.index(0) >= 4   # the short ones overtook the long one
+    assert clock[0] < 140                                           # nobody queued up behind it
+    # staging: 7 batches went through 5 sets without growing -- sets of finished batches were reused,
+    # and the set of the long batch was not handed out while it was still in flight
+    assert len(feeder.stages) == 5 and not any(feeder._busy)
+    feeder.close()
+    pipe.close()

@@ -2,8 +2,9 @@
 //   _resquiggle_worker.adjust_map_res   tombo/resquiggle.py:1506-1530  (RNA flip, stall detection)
 //   ts.identify_stalls, mean-window     tombo/tombo_stats.py:269-368
 // The cumulative sum under the stall metric is k_cumsum_scores<.., RT, 1> (k_segment.h): its
-// left-to-right float64 order is part of the metric's bits for float input (int16 DAC sums are
-// exact in any order and take the same kernel).
+// left-to-right float64 order is part of the metric's bits for float input; int16 DAC input --
+// exact integer sums in any order -- has a path of its own without a cumulative sum in memory
+// (k_stall_metric_i16, below).
 #pragma once
 #include "tba_common.h"
 
@@ -202,4 +203,93 @@ __device__ inline i64 keyed_perm(i64 t, i64 n, u64 key)
         x = ((u64)L << hb) | R;
     } while (x >= (u64)n);
     return (i64)x;
+}
+
+// The same metric for int16 DAC input -- what a FAST5 file holds -- without the cumulative sum in
+// memory: integer window sums are exact in any order, so a workgroup takes a chunk of SI_T metric
+// positions, loads the SI_T + window_size samples under it into LDS (2 bytes per sample from HBM,
+// once), turns them into an exclusive int32 prefix sum there (block scan) and reads every 50-sample
+// window sum as a difference of two prefix values.  np.cumsum on an int16 array is int64
+// (tombo_stats.py:277), the difference of two of its entries the exact window sum, `/
+// mini_window_size` its float64 quotient: the doubles that enter the mean differences are the same
+// bits as on the float path.  grid: (blocks, reads); window_size <= SI_MAXW (else the float path).
+#define SI_T 2048
+#define SI_MAXW 1024
+template <int NW>
+__global__ __launch_bounds__(256) void k_stall_metric_i16(const ReadState *rs, const DevParams *dp,
+    const int16_t *raw, u64 *bits)
+{
+    __shared__ i32 P[SI_T + SI_MAXW + 8];
+    __shared__ i32 s_wave[4];
+    const ReadState &r = rs[blockIdx.y];
+    if (r.status != TBA_OK) return;
+    const tba_opts &o = dp->o;
+    const i64 n = r.n_raw;
+    const int ws = (int)o.stall_window_size, mw = (int)o.stall_mini_window_size;
+    const int nw = NW > 0 ? NW : (int)o.stall_n_windows;
+    const i64 n_words = (n + 63) >> 6;
+    u64 *bw = bits + stall_word_base(r, blockIdx.y);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 n_pos = n - ws + 1;
+    const i64 start_offset = (i64)((double)ws * 0.5);
+    const int16_t *x = raw + r.raw_off;
+    const double dmw = (double)mw, rmw = 1.0 / dmw;
+    const double dnd = (double)(nw * (nw - 1) / 2), rnd = 1.0 / dnd;
+    const double thr = o.stall_threshold;
+    const int N = SI_T + ws;                 // samples under a chunk
+    const int per = (N + 255) / 256;         // per thread, contiguous
+    for (i64 q0 = (i64)blockIdx.x * SI_T; q0 < (n_words << 6); q0 += (i64)gridDim.x * SI_T) {
+        const i64 p0 = q0 - start_offset;    // sample index of the chunk's first window start
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {
+            const i64 k = p0 + i;
+            P[i] = (k >= 0 && k < n) ? (i32)x[k] : 0;
+        }
+        __syncthreads();
+        // exclusive prefix sum of P[0..N) in place, P[N] = total
+        const int a = tid * per, b = a + per < N ? a + per : N;
+        i32 mine = 0;
+        for (int i = a; i < b; i++) mine += P[i];
+        i32 inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const i32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        i32 off = inc - mine;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        __syncthreads(); // (everyone has read its own elements' sum; now they are overwritten)
+        for (int i = a; i < b; i++) { const i32 t = P[i]; P[i] = off; off += t; }
+        if (tid == 0) P[N] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]; // the total
+        __syncthreads();
+        // metric of the chunk's positions, 64 per ballot word
+        for (int wq = wave; wq < SI_T / 64; wq += 4) {
+            const i64 w = (q0 >> 6) + wq;
+            if (w >= n_words) break;
+            const int i = wq * 64 + lane;   // offset of my window start inside the chunk
+            const i64 p = p0 + i;
+            const bool valid = p >= 0 && p < n_pos;
+            bool below = false;
+            if (valid) {
+                double m[NW > 0 ? NW : 16];
+                i32 prev = P[i];
+#pragma unroll
+                for (int k = 0; k < (NW > 0 ? NW : 16); k++) {
+                    if (NW > 0 || k < nw) {
+                        const i32 nxt = P[i + mw * (k + 1)];
+                        m[k] = div_by_recip((double)(nxt - prev), dmw, rmw);
+                        prev = nxt;
+                    }
+                }
+                double acc = fabs(m[0] - m[1]); // diffs[0].copy()
+#pragma unroll
+                for (int ii = 0; ii < (NW > 0 ? NW : 16); ii++)
+#pragma unroll
+                    for (int jj = ii + 1; jj < (NW > 0 ? NW : 16); jj++)
+                        if (NW > 0 || jj < nw) acc = acc + fabs(m[ii] - m[jj]);
+                below = div_by_recip(acc, dnd, rnd) <= thr;
+            }
+            const u64 word = __ballot(below);
+            if (lane == 0) bw[w] = word;
+        }
+    }
 }
