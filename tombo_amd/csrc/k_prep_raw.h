@@ -42,10 +42,15 @@ __device__ __forceinline__ i64 stall_word_base(const ReadState &r, i64 read_inde
 //   metric[ws // 2 ... + p] = diff_sums / len(diffs), NaN elsewhere   (:312-327)
 // The two divisions have loop-invariant divisors: div_by_recip (tba_common.h) is IEEE division.
 // NW > 0: n_windows as a compile-time constant (7 = MEAN_STALL_PARAMS), else <= 16 at run time.
+#define SM_T 2048   // metric positions per workgroup step
+#define SM_MAXW 1024 // widest window staged in LDS (wider: straight from memory)
 template <int NW>
 __global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const DevParams *dp,
     const double *csum, u64 *bits)
 {
+    // the SM_T + window_size sums under a chunk of positions are staged in LDS once (a position
+    // reads 8 of them 50 apart: from L2 that was 64 bytes per position and 8.6 ms per 10 k RNA reads)
+    __shared__ double C[SM_T + SM_MAXW + 1];
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
     const tba_opts &o = dp->o;
@@ -53,38 +58,54 @@ __global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const
     const int nw = NW > 0 ? NW : (int)o.stall_n_windows;
     const i64 n_words = (n + 63) >> 6;
     u64 *bw = bits + stall_word_base(r, blockIdx.y);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 n_pos = n - ws + 1;              // <= 0: read shorter than the window, no metric
     const i64 start_offset = (i64)((double)ws * 0.5);
     const double *c = csum + r.raw_off + blockIdx.y;
     const double dmw = (double)mw, rmw = 1.0 / dmw;
     const double dnd = (double)(nw * (nw - 1) / 2), rnd = 1.0 / dnd;
     const double thr = o.stall_threshold;
-    for (i64 w = (i64)blockIdx.x * 4 + wave; w < n_words; w += (i64)gridDim.x * 4) {
-        const i64 q = (w << 6) + lane, p = q - start_offset;
-        const bool valid = p >= 0 && p < n_pos;
-        bool below = false;
-        if (valid) {
-            double m[NW > 0 ? NW : 16];
-            double prev = c[p];
-#pragma unroll
-            for (int k = 0; k < (NW > 0 ? NW : 16); k++) {
-                if (NW > 0 || k < nw) {
-                    const double nxt = c[p + mw * (k + 1)];
-                    m[k] = div_by_recip(nxt - prev, dmw, rmw);
-                    prev = nxt;
-                }
+    const bool staged = ws <= SM_MAXW;
+    const int N = SM_T + (int)(staged ? ws : 0) + 1;
+    for (i64 q0 = (i64)blockIdx.x * SM_T; q0 < (n_words << 6); q0 += (i64)gridDim.x * SM_T) {
+        const i64 p0 = q0 - start_offset;
+        if (staged) {
+            __syncthreads();
+            for (int i = tid; i < N; i += 256) {
+                const i64 k = p0 + i;
+                C[i] = (k >= 0 && k <= n) ? c[k] : 0.0;
             }
-            double acc = fabs(m[0] - m[1]); // diffs[0].copy()
-#pragma unroll
-            for (int i = 0; i < (NW > 0 ? NW : 16); i++)
-#pragma unroll
-                for (int j = i + 1; j < (NW > 0 ? NW : 16); j++)
-                    if (NW > 0 || j < nw) acc = acc + fabs(m[i] - m[j]);
-            below = div_by_recip(acc, dnd, rnd) <= thr;
+            __syncthreads();
         }
-        const u64 word = __ballot(below);
-        if (lane == 0) bw[w] = word;
+        for (int wq = wave; wq < SM_T / 64; wq += 4) {
+            const i64 w = (q0 >> 6) + wq;
+            if (w >= n_words) break;
+            const int i = wq * 64 + lane;
+            const i64 p = p0 + i;
+            const bool valid = p >= 0 && p < n_pos;
+            bool below = false;
+            if (valid) {
+                double m[NW > 0 ? NW : 16];
+                double prev = staged ? C[i] : c[p];
+#pragma unroll
+                for (int k = 0; k < (NW > 0 ? NW : 16); k++) {
+                    if (NW > 0 || k < nw) {
+                        const double nxt = staged ? C[i + (int)mw * (k + 1)] : c[p + mw * (k + 1)];
+                        m[k] = div_by_recip(nxt - prev, dmw, rmw);
+                        prev = nxt;
+                    }
+                }
+                double acc = fabs(m[0] - m[1]); // diffs[0].copy()
+#pragma unroll
+                for (int ii = 0; ii < (NW > 0 ? NW : 16); ii++)
+#pragma unroll
+                    for (int jj = ii + 1; jj < (NW > 0 ? NW : 16); jj++)
+                        if (NW > 0 || jj < nw) acc = acc + fabs(m[ii] - m[jj]);
+                below = div_by_recip(acc, dnd, rnd) <= thr;
+            }
+            const u64 word = __ballot(below);
+            if (lane == 0) bw[w] = word;
+        }
     }
 }
 

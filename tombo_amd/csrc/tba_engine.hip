@@ -583,8 +583,8 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         if (cs_reads_for(n) == 20) RAW_DISPATCH(rdt, (k_cumsum_scores<20, RT, 1><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
         else RAW_DISPATCH(rdt, (k_cumsum_scores<32, RT, 1><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
         if (e->n_long > 0) RAW_DISPATCH(rdt, (k_cumsum_scores_long<RT, 1><<<(unsigned)e->n_long, 256, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_raw.as<RT>(), csum)));
-        if (e->hp.o.stall_n_windows == 7) k_stall_metric<7><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, csum, bits);
-        else k_stall_metric<0><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, csum, bits);
+        if (e->hp.o.stall_n_windows == 7) k_stall_metric<7><<<dim3(gq, nb), 256, 0, s>>>(rs, dp, csum, bits);
+        else k_stall_metric<0><<<dim3(gq, nb), 256, 0, s>>>(rs, dp, csum, bits);
         }
         k_stall_runs<<<dim3(gx(e->max_raw / 64 + 1), nb), 256, 0, s>>>(rs, dp, bits, e->d_stall.as<i64>());
         k_stall_merge<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_stall.as<i64>());
@@ -1637,15 +1637,15 @@ extern "C" int tba_identify_stalls(tba_engine *e, const void *raw, int raw_dtype
     C_TRY(hipMemcpyAsync(d_raw.p, raw, (size_t)n * raw_elem_bytes(raw_dtype), hipMemcpyHostToDevice, s));
     ReadState *rs = d_r.as<ReadState>();
     const DevParams *dp = d_p.as<DevParams>();
-    const unsigned g = grid_for(n / 4 + 1);
     if (raw_dtype == TBA_RAW_I16 && window_size <= SI_MAXW) {
         const unsigned gq = (unsigned)std::min<i64>(std::max<i64>((n + SI_T - 1) / SI_T, 1), 1024);
         if (n_windows == 7) k_stall_metric_i16<7><<<dim3(gq, 1), 256, 0, s>>>(rs, dp, d_raw.as<int16_t>(), d_bits.as<u64>());
         else k_stall_metric_i16<0><<<dim3(gq, 1), 256, 0, s>>>(rs, dp, d_raw.as<int16_t>(), d_bits.as<u64>());
     } else {
         RAW_DISPATCH(raw_dtype, (k_cumsum_scores<32, RT, 1><<<1, 256, 0, s>>>(rs, 1, dp, d_raw.as<RT>(), d_csum.as<double>())));
-        if (n_windows == 7) k_stall_metric<7><<<dim3(g, 1), 256, 0, s>>>(rs, dp, d_csum.as<double>(), d_bits.as<u64>());
-        else k_stall_metric<0><<<dim3(g, 1), 256, 0, s>>>(rs, dp, d_csum.as<double>(), d_bits.as<u64>());
+        const unsigned gq2 = (unsigned)std::min<i64>(std::max<i64>((n + SM_T - 1) / SM_T, 1), 1024);
+        if (n_windows == 7) k_stall_metric<7><<<dim3(gq2, 1), 256, 0, s>>>(rs, dp, d_csum.as<double>(), d_bits.as<u64>());
+        else k_stall_metric<0><<<dim3(gq2, 1), 256, 0, s>>>(rs, dp, d_csum.as<double>(), d_bits.as<u64>());
     }
     k_stall_runs<<<dim3(grid_for(n / 64 + 1), 1), 256, 0, s>>>(rs, dp, d_bits.as<u64>(), d_ints.as<i64>());
     k_stall_merge<<<1, 64, 0, s>>>(rs, 1, dp, d_ints.as<i64>());
