@@ -180,6 +180,25 @@ def cpu_baseline(seqs, raws, params, model, n_bases, samp_name, n_single, n_per_
     return legs
 
 
+def cpu_child(job):
+    """The CPU legs in a process of their own: it regenerates the reads it needs (same seeds, so the
+    same reads as the parent's first ones) instead of inheriting the parent's gigabytes -- forking
+    one worker per host core out of a process that holds the whole synthetic batch cost more than
+    the legs themselves (56 s of set-up for 14 s of measurement on the 256-thread host)."""
+    j = json.loads(job)
+    from tombo_amd import tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType(j['samp'], j['samp'] == 'RNA')
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=j['bandwidth'])
+    if j['bandwidth'] <= 100:
+        params = params._replace(band_bound_thresh=10)
+    bases = np.array(j['bases'], np.int64)
+    workers = max(1, min(32, os.cpu_count() or 8))
+    seqs, raws, _ = make_reads(bases, j['seed0'], workers, j['samp'], False)
+    legs = cpu_baseline(seqs, raws, params, model, bases, j['samp'], j['n_single'], j['n_per_core'])
+    print(json.dumps(legs))
+
+
 # ---- PMC traffic (whole pipeline) of the configuration being run ---------------------------
 def pmc_child(path):
     """child of measure_pmc_traffic: load the reads the parent saved, one upload + one pass"""
@@ -341,10 +360,13 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes behind roofline.traffic')
     ap.add_argument('--pmc-reads', type=int, default=1024, help='reads of the counter passes')
     ap.add_argument('--pmc-child', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-child', default=None, help=argparse.SUPPRESS)  # JSON job of the CPU legs
     ap.add_argument('--engine-stub', default=None, help=argparse.SUPPRESS)  # tests/: host logic without a GPU
     a = ap.parse_args()
     if a.pmc_child:
         return pmc_child(a.pmc_child)
+    if a.cpu_child:
+        return cpu_child(a.cpu_child)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(a.gpus)
     samp_name = 'DNA'
@@ -408,7 +430,17 @@ def main():
     cpu_legs = None
     t_cpu = time.perf_counter()
     if rank == 0 and not a.no_cpu_baseline:
-        cpu_legs = cpu_baseline(seqs, raws, params, model, bases, samp_name, a.cpu_sample, a.cpu_per_core)
+        cores = os.cpu_count() or 1
+        n_cpu = min(a.reads, max(a.cpu_sample, a.cpu_per_core * cores if cores > 1 else 0, 1))
+        job = json.dumps(dict(samp=samp_name, bandwidth=a.bandwidth, bases=[int(b) for b in bases[:n_cpu]],
+                              seed0=seed0, n_single=a.cpu_sample, n_per_core=a.cpu_per_core))
+        env = dict(os.environ)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'TBA_STORE_PORT'):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', job], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1200)
+        lines = [x for x in out.stdout.decode().splitlines() if x.startswith('[')]
+        cpu_legs = json.loads(lines[-1]) if out.returncode == 0 and lines else None
     t_cpu = time.perf_counter() - t_cpu
 
     dist = init_control_plane(rank, world) if world > 1 else None
