@@ -8,6 +8,7 @@
 #include "k_dp.h"
 #include "k_dp_multi.h"
 #include "k_long.h"
+#include "k_dp_wg.h"
 #include "k_tail.h"
 #include "k_cabi.h"
 
@@ -632,7 +633,14 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 7
     if (ON(TBA_STAGE_START)) {
-        launch_dp(e, cpl_class(P.start_save_bw), DP_START_RETRY);
+        // the retry of the few reads whose first try failed: one workgroup per read (k_dp_wg.h)
+        const int wcpl = P.start_n_bases <= WG_MAX_ROWS ? dp_wg_cpl(P.start_save_bw) : 0;
+#define WG_ARGS rs, dp, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_lastrow.as<double>()
+        if (wcpl == 4) k_dp_wg<4><<<nb, 256, 0, s>>>(WG_ARGS);
+        else if (wcpl == 8) k_dp_wg<8><<<nb, 256, 0, s>>>(WG_ARGS);
+        else if (wcpl == 12) k_dp_wg<12><<<nb, 256, 0, s>>>(WG_ARGS);
+        else launch_dp(e, cpl_class(P.start_save_bw), DP_START_RETRY);
+#undef WG_ARGS
         k_start_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, DP_START_RETRY, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_smoves.as<unsigned char>(), e->start_moves_stride, e->d_readtb.as<i64>(), e->d_startvals.as<double>());
     }
     MARK(); // 8 prep
