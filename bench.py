@@ -349,6 +349,8 @@ def main():
     ap.add_argument('--stream-batch', type=int, default=None,
                     help='reads per streamed batch (default: 10000 compact, 5000 full: its float64 outputs are page-locked per slot)')
     ap.add_argument('--slots', type=int, default=3, help='engine slots per GPU of the streaming pipeline')
+    ap.add_argument('--serial-compute', action='store_true',
+                    help='streaming: kernel sequences of the slots back to back (tba_batch_wait_for) instead of interleaved')
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
                          'engine / stream (kernels of different sub-batches overlap)')
@@ -574,7 +576,8 @@ def main():
                                         segs_dtype=np.int32 if compact else np.int64,
                                         reverse_raw=dev_flip, stall_params=stall_params,
                                         subsample_seed=None if host_draw else 20260927 + rank,
-                                        in_order=not longtail)
+                                        in_order=not longtail,
+                                        serial_compute=a.serial_compute and not longtail)
         feeder = streaming.ReadFeeder(n_slots=a.slots, n_threads=workers)
         pools = [([src[i] for i in idx], [seqs[i] for i in idx], idx) for idx in splan]
         cnt = dict(reads=0, ok=0, out=0, moved=0, submit_s=0.0, pack_wait_s=0.0, nb=0)
@@ -655,7 +658,9 @@ def main():
         est[:] = 0
         # batches of the whole job: K passes over the pool, but never so few that filling and
         # draining the slots is most of the measurement
-        n_stream = max(len(pools) * a.steps, 2 * a.slots + 2) * world
+        # (filling and draining the slots costs about one batch time: at 8 batches that is 10 % of the
+        # measurement -- 80-85 k reads/s at cfg2 against 91-93 k over 24 batches; at least 16 here)
+        n_stream = max(len(pools) * a.steps, 16 if not longtail else 2 * a.slots + 2) * world
         queue = sharding.BatchQueue(n_stream, key='stream')
         barrier()
         t0 = time.perf_counter()

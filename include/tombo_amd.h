@@ -182,6 +182,10 @@ int tba_batch_run(tba_engine *e);
 /* same, but only enqueues (for timing with events / overlapping); pair with tba_batch_sync */
 int tba_batch_enqueue(tba_engine *e);
 int tba_batch_sync(tba_engine *e);
+/* the kernel sequence enqueued NEXT on e starts after the one last enqueued on `other` has
+ * finished (copies are not ordered): a streaming caller keeps the batches' kernels back to back
+ * instead of interleaved while uploads and downloads of other slots overlap them */
+int tba_batch_wait_for(tba_engine *e, tba_engine *other);
 /* 0: the engine's stream is idle; 1: work still in flight (never blocks) */
 int tba_batch_query(tba_engine *e);
 /* Outputs (any pointer may be NULL):

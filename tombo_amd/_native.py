@@ -322,6 +322,10 @@ class Engine(object):
     def sync(self):
         self._check(self._L.tba_batch_sync(self._h), 'tba_batch_sync')
 
+    def wait_for(self, other):
+        """kernels enqueued next on this engine start after `other`'s last enqueued sequence"""
+        self._check(self._L.tba_batch_wait_for(self._h, other._h), 'tba_batch_wait_for')
+
     def device_mem(self):
         """(free, total) bytes of this engine's device"""
         a, b = i64(0), i64(0)

@@ -703,6 +703,18 @@ static int enqueue_stages(tba_engine *e, int first, int last)
 
 extern "C" int tba_batch_enqueue(tba_engine *e) { return enqueue_stages(e, TBA_STAGE_SEGMENT, TBA_STAGE_RESCALE); }
 
+// The kernels this engine enqueues next start only after `other`'s last enqueued kernel sequence has
+// finished (its transfers are not waited for): a streaming caller keeps the kernel sequences of its
+// slots back to back instead of interleaved, while their copies still overlap.
+extern "C" int tba_batch_wait_for(tba_engine *e, tba_engine *other)
+{
+    if (!e || !other) return set_err(TBA_E_ARG, "engine is NULL");
+    if (!other->ran || e == other) return 0; // nothing enqueued there yet
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamWaitEvent(e->stream, other->ev[14], 0));
+    return 0;
+}
+
 extern "C" int tba_batch_run_stages(tba_engine *e, int first_stage, int last_stage)
 {
     int rc = enqueue_stages(e, first_stage, last_stage);

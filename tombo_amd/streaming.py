@@ -154,7 +154,7 @@ class StreamPipeline(object):
                  skip_seq_scaling=False, max_raw_cpts=MAX_RAW_CPTS,
                  min_event_to_seq_ratio=MIN_EVENT_TO_SEQ_RATIO, want_norm=False,
                  segs_dtype=np.int32, reverse_raw=False, stall_params=None, subsample_seed=None,
-                 in_order=True):
+                 in_order=True, serial_compute=False):
         from . import resquiggle as rq
         if device is None:
             device = rq.default_device()
@@ -182,6 +182,13 @@ class StreamPipeline(object):
         # round-robin slots make the host wait behind the long batch while other slots sit idle.
         self.in_order = bool(in_order)
         self._seq = 0
+        # serial_compute: the kernel sequence of a batch starts when the previous batch's has
+        # finished (tba_batch_wait_for) -- uploads and downloads still overlap compute, but the
+        # kernels of two batches do not interleave.  Measured at cfg2 over 24 batches: 2 slots back
+        # to back 93.3 k reads/s, 3 slots back to back 91.0 k, 3 slots interleaved 93.0 k, 2 slots
+        # interleaved 84.5 k -- with three slots it makes no difference, so it stays an option.
+        self.serial_compute = bool(serial_compute)
+        self._last_eng = None
 
     def reserve(self, max_reads, max_segs, max_raw=0):
         """Size the page-locked output arrays of every slot for batches of up to `max_reads` reads,
@@ -228,7 +235,10 @@ class StreamPipeline(object):
         eng.upload_packed(self.params, self.opts, batch.raw, batch.raw_off, batch.seq,
                           batch.seq_off, samp_ind=batch.samp_ind, stall_ints=batch.stall_ints,
                           stall_off=batch.stall_off)
+        if self.serial_compute and self._last_eng is not None and hasattr(eng, 'wait_for'):
+            eng.wait_for(self._last_eng)
         eng.enqueue()
+        self._last_eng = eng
         which = slot.flip
         slot.flip ^= 1
         res, segs, norm = slot.out_arrays(which, eng.n, int(eng.seg_off[-1]), eng.n_raw_total,
