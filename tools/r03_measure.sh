@@ -5,7 +5,7 @@ O=$R/gpurun_out/r03
 mkdir -p $O
 cd $R
 for cfg in cfg2 cfg3 cfg1 cfg4; do
-  python bench.py --preset $cfg --steps 8 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+  python bench.py --preset $cfg --steps 20 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
 done
 python bench.py --preset longtail --steps 4 --no-pmc --api-reads 0 > $O/bench_longtail.json 2> $O/bench_longtail.err
 python bench.py --gpus 2 --steps 6 > $O/bench_cfg5_rehearsal_2ranks_on_1gpu.json 2> $O/bench_n2.err
