@@ -225,6 +225,11 @@ class StreamPipeline(object):
                 slot = next((s for s in self.slots if not s.eng.query()), None)
                 if slot is None:
                     time.sleep(0.0002)
+        if batch.samp_ind is None and self.subsample_seed is None and not self.opts.skip_seq_scaling and \
+                int(np.max(np.diff(batch.seq_off), initial=0)) - (slot.eng.kmer_width or 1) + 1 > MAX_POINTS_FOR_THEIL_SEN:
+            # (on the device this is the generic TBA_INTERNAL status of every long read; say it here)
+            raise ValueError('batch %r has reads longer than %d bases but no Theil-Sen subsamples: pass '
+                             'samp_inds, or subsample_seed to the pipeline' % (batch.tag, MAX_POINTS_FOR_THEIL_SEN))
         done = self._finish(slot) if slot.pending is not None else None
         self._seq += 1
         slot.seq = self._seq
