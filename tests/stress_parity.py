@@ -1,13 +1,13 @@
 """One-off stress run of the engine against the oracle beyond the default test budget: a larger
 hypothesis sweep of the parameter box, start-retry-heavy reads (long leaders, every k_dp_wg class),
-stall detection at awkward lengths for every boundary type.  GPU box:  python tools/stress_parity.py"""
+stall detection at awkward lengths for every boundary type.  GPU box:  python tests/stress_parity.py  (not collected by pytest: no test_ prefix)"""
 import os
 import sys
 import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))  # (this directory)
 import oracle  # noqa: E402  (checker)
 from tombo_amd import synth, tombo_stats as ts, tombo_helper as th  # noqa: E402
 from test_gpu_parity import run_batch, compare_batch  # noqa: E402
