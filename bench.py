@@ -29,6 +29,7 @@ With --gpus N > 1 and no torchrun environment the script launches its own N rank
 per GPU).  Prints ONE JSON line on rank 0.
 """
 import os
+import gc
 import sys
 import json
 import time
@@ -358,7 +359,7 @@ def main():
                     help='longtail preset: clip of the log-normal read lengths (round 2 used 100000)')
     ap.add_argument('--tail-bases', type=int, default=30000,
                     help='longtail preset: reads longer than this form batches of their own (planner.plan_batches)')
-    ap.add_argument('--api-reads', type=int, default=2000, help='reads of the resquiggle_batch API leg (0: skip)')
+    ap.add_argument('--api-reads', type=int, default=5000, help='reads of the resquiggle_batch API leg (0: skip)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes behind roofline.traffic')
     ap.add_argument('--pmc-reads', type=int, default=1024, help='reads of the counter passes')
     ap.add_argument('--pmc-child', default=None, help=argparse.SUPPRESS)
@@ -712,12 +713,25 @@ def main():
         kw = dict(outlier_thresh=5.0, seq_samp_type=samp, engine=eng, reverse_raw=rna, stall_params=stall_params)
         api = {'reads': n_api, 'raw_dtype': 'int16', 'returns': 'list of resquiggleResults (float64 '
                'normalised signal + int64 boundaries per read), same as the reference'}
-        for mode, extra in (('numpy_subsample', {}), ('device_subsample', dict(subsample_seed=1))):
+        for mode, extra in (('numpy_subsample', {}), ('device_subsample', dict(subsample_seed=1)),
+                            ('device_subsample_no_signal', dict(subsample_seed=1, return_signal=False))):
             rq.resquiggle_batch(mrs[:64], model, params, **kw, **extra)    # staging sized, code paged in
             rq.resquiggle_batch(mrs, model, params, **kw, **extra)
+            res = None   # (the previous results -- gigabytes of per-read arrays -- are freed outside the clock)
+            gc.collect()
+            prof = None
+            if os.environ.get('TBA_BENCH_VERBOSE'):
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
             t0 = time.perf_counter()
             res = rq.resquiggle_batch(mrs, model, params, **kw, **extra)
             dta = time.perf_counter() - t0
+            if prof is not None:
+                import pstats
+                prof.disable()
+                print('api leg', mode, '%.1f ms' % (dta * 1e3), file=sys.stderr)
+                pstats.Stats(prof, stream=sys.stderr).sort_stats('cumulative').print_stats(8)
             api['resquiggle_batch_' + mode] = {
                 'reads_per_s': round(n_api / dta, 1), 'seconds': round(dta, 4),
                 'ok': sum(not isinstance(r, Exception) for r in res)}

@@ -480,3 +480,24 @@ def test_wide_static_band_matches_oracle():
     assert (path[:3, 0] == 2).all() and (path[:3, 2] > 3072).all(), path   # wide static bands
     assert path[3, 2] <= 3072 and path[4, 0] == 1
     assert sum(o['status'] == 0 for o in oracles) >= 4
+
+
+def test_resquiggle_batch_without_signal():
+    """return_signal=False: same boundaries, scale values and scores, raw_signal None, nothing
+    materialised for it on the device"""
+    from tombo_amd import resquiggle as rq, synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    mrs = [synth.synth_map_res(model, nb, 9100 + nb, **synth.DNA_SYNTH) for nb in (700, 1300, 20, 950)]
+    a = rq.resquiggle_batch(mrs, model, params, 5.0, seq_samp_type=samp, subsample_seed=4)
+    b = rq.resquiggle_batch(mrs, model, params, 5.0, seq_samp_type=samp, subsample_seed=4, return_signal=False)
+    assert sum(not isinstance(x, Exception) for x in a) >= 3
+    for x, y in zip(a, b):
+        assert isinstance(x, Exception) == isinstance(y, Exception)
+        if isinstance(x, Exception):
+            assert str(x) == str(y)
+            continue
+        assert y.raw_signal is None and x.raw_signal is not None
+        assert np.array_equal(x.segs, y.segs) and x.scale_values == y.scale_values
+        assert x.sig_match_score == y.sig_match_score and x.read_start_rel_to_raw == y.read_start_rel_to_raw

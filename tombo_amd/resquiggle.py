@@ -55,7 +55,7 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                      skip_seq_scaling=False,
                      seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False),
                      samp_inds=None, engine=None, return_debug=False, mem_budget=None,
-                     reverse_raw=False, stall_params=None, subsample_seed=None):
+                     reverse_raw=False, stall_params=None, subsample_seed=None, return_signal=True):
     """resquiggle_read over a list of `resquiggleResults` (mapping results).
 
     Returns a list with, per read, either a `resquiggleResults` or a `TomboError` instance
@@ -74,6 +74,12 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
     `mem_budget` bytes (default: 60 % of the device memory that is free or already held by this
     engine) the list is cut into consecutive sub-batches that fit and the results are returned
     in input order.
+
+    `return_signal=False`: the results carry `raw_signal=None` -- the float64 normalised signal
+    (0.74 MB per 10 kb read, most of what crosses PCIe on the way back) is neither materialised nor
+    downloaded.  Tombo itself stores only boundaries and scale values and re-normalises the raw
+    signal when a read is loaded (tombo_helper.py:2341-2460); `resquiggle_batch_events` /
+    `batch_de_novo_stats` compute what needs the signal on the device.
 
     Marshalling is native: the per-read arrays are packed into page-locked CSR staging by
     threads (`tba_pack_reads`), transfers are DMA, and the per-read result arrays are cut out of
@@ -129,7 +135,8 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                         seq_samp_type=seq_samp_type,
                         samp_inds=None if samp_inds is None else samp_inds[a:b], engine=eng,
                         mem_budget=float('inf'), reverse_raw=reverse_raw, stall_params=stall_params,
-                        subsample_seed=None if subsample_seed is None else subsample_seed + 7919 * k))
+                        subsample_seed=None if subsample_seed is None else subsample_seed + 7919 * k,
+                        return_signal=return_signal))
                 return out
     stage = eng.host_stage()
     raw, raw_off, seq, seq_off, _ = _native.pack_reads(
@@ -166,7 +173,8 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
         skip_seq_scaling=skip_seq_scaling,
         sig_match_thresh=None if seq_samp_type is None else SIG_MATCH_THRESH[seq_samp_type.name],
         max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
-        reverse_raw=reverse_raw, stall_params=stall_params, subsample_seed=subsample_seed)
+        reverse_raw=reverse_raw, stall_params=stall_params, subsample_seed=subsample_seed,
+        skip_norm_out=not return_signal and not return_debug)
     eng.upload_packed(p, o, raw, raw_off, seq, seq_off, sv_in=sv_in, sv_flags=sv_flags,
                       samp_ind=si, stall_ints=st, stall_off=sto)
     eng.enqueue()
@@ -177,7 +185,7 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
     else:
         o_res = stage.get('res', n, _native.RESULT_DTYPE)
         o_segs = stage.get('segs', int(eng.seg_off[-1]), np.int64)
-        o_norm = stage.get('norm', eng.n_raw_total, np.float64)
+        o_norm = stage.get('norm', eng.n_raw_total, np.float64) if return_signal else None
         eng.download_async(results=o_res, segs64=o_segs, norm=o_norm)
         eng.sync()
         out = dict(status=o_res['status'], read_start=o_res['read_start_rel_to_raw'],
@@ -194,7 +202,8 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
     ok = np.flatnonzero((status == 0) & np.array([e is None for e in pre_err]))
     if o_res is not None:
         segs_l = _native.unpack_reads(o_segs, eng.seg_off[:-1][ok], nb[ok] + 1)
-        norm_l = _native.unpack_reads(o_norm, raw_off[:-1][ok], out['norm_len'][ok])
+        norm_l = _native.unpack_reads(o_norm, raw_off[:-1][ok], out['norm_len'][ok]) if return_signal \
+            else [None] * len(ok)
     else:
         segs_l = [out['segs'][eng.seg_off[i]:eng.seg_off[i + 1]].copy() for i in ok]
         norm_l = [out['norm'][eng.raw_off[i]:eng.raw_off[i] + int(out['norm_len'][i])].copy() for i in ok]

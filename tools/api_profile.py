@@ -14,7 +14,7 @@ seqs, raws, dacs = bench.make_reads(np.full(n, 10000), 5, 32, 'DNA', True)
 mrs = [th.resquiggleResults(align_info=th.alignInfo('r%d' % i, 'BaseCalled_template', 0, 0, 0, 0, 10000, 0),
                             genome_loc=th.genomeLocation(0, '+', 'c'), genome_seq=seqs[i], mean_q_score=10.0,
                             raw_signal=dacs[i]) for i in range(n)]
-kw = dict(outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=1)
+kw = dict(outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=1, return_signal=os.environ.get('NO_SIGNAL') is None)
 rq.resquiggle_batch(mrs[:64], model, params, **kw)
 rq.resquiggle_batch(mrs, model, params, **kw)
 t0 = time.perf_counter(); rq.resquiggle_batch(mrs, model, params, **kw); print('wall %.1f ms' % ((time.perf_counter() - t0) * 1e3))
