@@ -24,9 +24,10 @@ def sha(a):
 
 def golden_names():
     # read-level cases; kernels_*.npz hold stand-alone kernel vectors (test_oracle_kernels_golden),
-    # dacq_*.npz the reference's runs on DAC-quantised reads (test_dac_quantised)
+    # dacq_*.npz the reference's runs on DAC-quantised reads (test_dac_quantised), stalls_*.npz
+    # identify_stalls off its defaults (test_stalls_golden), loop_*.npz the worker loop
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))
-                  if not os.path.basename(f).startswith(('kernels_', 'dacq_', 'stats_', 'loop_')))
+                  if not os.path.basename(f).startswith(('kernels_', 'dacq_', 'stats_', 'loop_', 'stalls_')))
 
 
 class GoldenCase(object):
@@ -45,7 +46,8 @@ class GoldenCase(object):
             self.samp, m.get('sig_aln_params'), m.get('seg_params'))._replace(
             bandwidth=m['bandwidth'], band_bound_thresh=m['band_bound_thresh'])
         self.max_raw_cpts = m.get('max_raw_cpts') or 200
-        seq, raw, _ = synth.synth_read(self.model, m['n_bases'], m['seed'], **m['synth_kw'])
+        seq, raw, starts = synth.synth_read(self.model, m['n_bases'], m['seed'], **m['synth_kw'])
+        seq, raw = synth.edit_read(seq, raw, starts, m.get('edit'))
         if m['noise_body']:
             rng = np.random.default_rng(m['seed'] + 12345)
             raw = rng.normal(0.0, 1.0, size=raw.shape[0]) * m['synth_kw']['scale'] + \
@@ -63,7 +65,8 @@ class GoldenCase(object):
 
     def samp_ind(self, n_bases=None):
         """np.random.choice(B, 1000, replace=False) under the recorded seed."""
-        n = self.meta['n_bases'] if n_bases is None else n_bases
+        # (an edited read's sequence may be longer than the synthetic one it was made from)
+        n = len(self.seq) - self.model.kmer_width + 1 if n_bases is None else n_bases
         if n <= 1000:
             return None
         st = np.random.get_state()

@@ -73,7 +73,7 @@ class Capture(object):
 def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=None,
              synth_kw=None, full=False, outlier_thresh=5.0, skip_seq_scaling=False,
              const_scale=None, second_iter=False, noise_body=False, sig_aln_params=None,
-             seg_params=None, max_raw_cpts=None):
+             seg_params=None, max_raw_cpts=None, edit=None):
     """sig_aln_params / seg_params: --signal-align-parameters / --segmentation-parameters style
     overrides (tombo/_option_parsers.py:375-385,606-617 -> load_resquiggle_parameters)"""
     samp = th.seqSampleType(samp_name, False)
@@ -88,6 +88,7 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
     kw = dict(synth.DNA_SYNTH if samp_name == 'DNA' else synth.RNA_SYNTH)
     kw.update(synth_kw or {})
     seq, raw, true_starts = synth.synth_read(my_model, n_bases, seed, **kw)
+    seq, raw = synth.edit_read(seq, raw, true_starts, edit)
     if noise_body:
         rng = np.random.default_rng(seed + 12345)
         raw = rng.normal(0.0, 1.0, size=raw.shape[0]) * kw['scale'] + kw['offset']
@@ -109,7 +110,7 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
                 synth_kw=kw, outlier_thresh=outlier_thresh, skip_seq_scaling=skip_seq_scaling,
                 const_scale=const_scale, noise_body=noise_body, second_iter=second_iter,
                 np_seed=seed, sig_aln_params=sig_aln_params, seg_params=seg_params,
-                max_raw_cpts=max_raw_cpts)
+                max_raw_cpts=max_raw_cpts, edit=edit)
     out['raw__sha'] = sha(raw)
     out['raw__len'] = np.int64(raw.shape[0])
     if stall_ints is not None:
@@ -197,7 +198,7 @@ def run_case(name, samp_name, n_bases, seed, bandwidth=None, band_bound_thresh=N
                 sv.shift, sv.scale, sv.lower_lim, sv.upper_lim)], dtype=np.float64)
             out['sig_match_score'] = np.float64(res.sig_match_score)
             out['norm_params_changed'] = np.bool_(res.norm_params_changed)
-            meta['median_abs_boundary_err'] = float(np.median(np.abs(
+            meta['median_abs_boundary_err'] = -1.0 if edit else float(np.median(np.abs(
                 res.read_start_rel_to_raw + res.segs - true_starts)))
             if second_iter:
                 cap.d = {}
@@ -291,6 +292,21 @@ CASES = [
     # (RNA with outlier_thresh=None is a TypeError in the reference -- get_scale_values_from_events,
     # tombo_stats.py:228 -- i.e. an "unexpected error": TBA_INTERNAL here, tests/test_gpu_parity.py)
     dict(name='p_dna_max_raw_cpts_4', samp_name='DNA', n_bases=1500, seed=43, max_raw_cpts=4),
+    # ---- sequence and signal that disagree; the remaining error reachable through resquiggle_read ----
+    dict(name='e_dna_dwell2_fewer_cpts', samp_name='DNA', n_bases=1500, seed=51,
+         synth_kw=dict(mean_dwell=2, min_dwell=1)),          # int(1.1 B) events asked of ~3 B samples
+    dict(name='e_dna_seg_fewer_cpts', samp_name='DNA', n_bases=1200, seed=52, seg_params=(5, 6, 2, 4)),
+    dict(name='e_rna_seg_fewer_cpts', samp_name='RNA', n_bases=500, seed=62, seg_params=(12, 9, 3, 8)),
+    dict(name='e_dna_cut30', samp_name='DNA', n_bases=1500, seed=54, edit=dict(kind='cut', n=30)),
+    dict(name='e_dna_cut60_bandfail', samp_name='DNA', n_bases=1500, seed=54, edit=dict(kind='cut', n=60)),
+    dict(name='e_dna_insert40', samp_name='DNA', n_bases=1500, seed=55, edit=dict(kind='insert', n=40, seed=5)),
+    dict(name='e_dna_trunc95', samp_name='DNA', n_bases=2000, seed=50, edit=dict(kind='truncate', frac=0.95)),
+    dict(name='e_dna_trunc85_bandfail', samp_name='DNA', n_bases=2000, seed=50,
+         edit=dict(kind='truncate', frac=0.85)),
+    dict(name='e_dna_lead12000_static', samp_name='DNA', n_bases=400, seed=59, synth_kw=dict(lead=12000)),
+    dict(name='e_rna_dwell8', samp_name='RNA', n_bases=800, seed=61, synth_kw=dict(mean_dwell=8, min_dwell=2)),
+    dict(name='e_rna_trunc70_bandfail', samp_name='RNA', n_bases=800, seed=60,
+         edit=dict(kind='truncate', frac=0.7)),
 ]
 
 if __name__ == '__main__':

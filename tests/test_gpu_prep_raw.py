@@ -21,18 +21,8 @@ def _ints(x):
 
 
 def _rna_like(rng, n, n_stalls, scale=90.0):
-    """level steps of ~43 samples (70 bases/s at 3 kHz) with stalled stretches inserted"""
-    n_lv = n // 20 + 2
-    lv = rng.normal(0.0, 1.0, n_lv)
-    dwell = np.maximum(6, rng.geometric(1.0 / 43.0, n_lv))
-    x = np.repeat(lv, dwell)[:n]
-    x = x + rng.normal(0.0, 0.25, x.shape[0])
-    raw = x * scale + 500.0
-    for _ in range(n_stalls):
-        a = int(rng.integers(0, max(1, raw.shape[0] - 3000)))
-        ln = int(rng.integers(150, 2500))   # around min_consecutive_obs + window, both sides
-        raw[a:a + ln] = raw[a] + rng.normal(0.0, rng.uniform(1.0, 12.0), raw[a:a + ln].shape[0])
-    return raw
+    from tombo_amd import synth
+    return synth.stalled_signal(rng, n, n_stalls, scale)
 
 
 def test_identify_stalls_matches_restatement_on_random_reads():

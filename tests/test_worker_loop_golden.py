@@ -1,7 +1,10 @@
 """The worker's per-read loop (`_resquiggle_worker`: run_rsqgl_iters + save-parameter retry,
 tombo/resquiggle.py:1492-1504,1578-1589) under one numpy seed, against the loop recorded from the
-live reference (tests/golden/gen_golden_loop.py -> loop_dna.npz): on CPU through the oracle, on the
-GPU through resquiggle_batch_iters(rng_order='read_major')."""
+live reference (tests/golden/gen_golden_loop.py -> loop_dna.npz, loop_rna.npz): on CPU through the
+oracle, on the GPU through resquiggle_batch_iters(rng_order='read_major').  The RNA reads arrive in
+acquisition order without stall intervals: `adjust_map_res` (the flip + ts.identify_stalls,
+resquiggle.py:1506-1530) is part of what is reproduced -- by oracle.identify_stalls on CPU, inside
+every device pass (`device_prep=True`) on the GPU."""
 import os
 import json
 import hashlib
@@ -16,19 +19,24 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
 
 
-def _load():
+SAMPS = ['DNA', 'RNA']
+
+
+def _load(name='DNA'):
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
-    g = np.load(os.path.join(GOLDEN_DIR, 'loop_dna.npz'))
+    g = np.load(os.path.join(GOLDEN_DIR, 'loop_%s.npz' % name.lower()))
     m = json.loads(str(g['meta']))
-    samp = th.seqSampleType('DNA', False)
+    samp = th.seqSampleType(name, False)
     model = ts.TomboModel(seq_samp_type=samp)
     params = ts.load_resquiggle_parameters(samp, tuple(m['aln']))
     save = ts.load_resquiggle_parameters(samp, tuple(m['aln']), use_save_bandwidth=True)
     mrs = []
     for k, (nb, seed, kw) in enumerate(m['specs']):
-        skw = dict(synth.DNA_SYNTH)
+        skw = dict(synth.RNA_SYNTH if name == 'RNA' else synth.DNA_SYNTH)
         skw.update(kw)
         mr = synth.synth_map_res(model, nb, m['seed_base'] + seed, **skw)
+        if name == 'RNA':   # acquisition order, as the FAST5 holds it
+            mr = mr._replace(raw_signal=np.ascontiguousarray(mr.raw_signal[::-1]))
         assert hashlib.sha256(mr.raw_signal.tobytes()).hexdigest() == str(g['raw%d__sha' % k])
         mrs.append(mr)
     return g, m, samp, model, params, save, mrs
@@ -44,23 +52,31 @@ def _check(g, m, k, segs, read_start, sv, score, norm, changed):
     assert bool(changed) == bool(g['changed%d' % k])
 
 
-def test_oracle_loop_reproduces_the_reference_loop():
+@pytest.mark.parametrize('name', SAMPS)
+def test_oracle_loop_reproduces_the_reference_loop(name):
     import oracle
     from tombo_amd import tombo_stats as ts
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
-    g, m, samp, model, params, save, mrs = _load()
+    g, m, samp, model, params, save, mrs = _load(name)
     K = model.kmer_width
+    if name == 'RNA':       # adjust_map_res
+        for k in range(len(mrs)):
+            raw = np.ascontiguousarray(mrs[k].raw_signal[::-1])
+            stalls = oracle.identify_stalls(raw)
+            np.testing.assert_array_equal(np.array(stalls, np.int64).reshape(-1, 2), g['stall_ints%d' % k])
+            mrs[k] = mrs[k]._replace(raw_signal=raw, stall_ints=stalls)
 
     def one(mr, p, sv=None):
         b = len(mr.genome_seq) - K + 1
         o = oracle.make_opts(K, model.central_pos, outlier_thresh=m['outlier_thresh'], scale_values=sv,
-                             sig_match_thresh=SIG_MATCH_THRESH['DNA'])
+                             sig_match_thresh=SIG_MATCH_THRESH[name])
         # the reference draws inside calc_kmer_fitted_shift_scale, i.e. only when the read got that
         # far; the restatement takes the indices up front, so the RNG is rewound on earlier failures
         state = np.random.get_state()
         si = np.random.choice(b, 1000, replace=False) if b > 1000 else None
         r = oracle.resquiggle_read(mr.raw_signal, ts.encode_seq(mr.genome_seq), model.level_means,
-                                   model.level_sds, oracle.make_params(p), o, samp_ind=si)
+                                   model.level_sds, oracle.make_params(p), o, samp_ind=si,
+                                   stall_ints=mr.stall_ints)
         if r['status'] not in (0, 19, 20):
             np.random.set_state(state)
         return r
@@ -78,12 +94,13 @@ def test_oracle_loop_reproduces_the_reference_loop():
         return r
     st = np.random.get_state()
     np.random.seed(m['seed'])
-    n_pass = []
+    n_pass, saved = [], []
     try:
         for k, mr in enumerate(mrs):
             passes = [0]
             r = iters(mr, params, passes)
             if r['status'] != 0:
+                saved.append(k)
                 r = iters(mr, save, passes)
             n_pass.append(passes[0])
             assert r['status'] == 0
@@ -92,18 +109,21 @@ def test_oracle_loop_reproduces_the_reference_loop():
     finally:
         np.random.set_state(st)
     assert n_pass == list(g['n_passes'])
+    assert saved == list(g['used_save_params'])
 
 
 @pytest.mark.gpu
-def test_engine_loop_read_major_reproduces_the_reference_loop():
+@pytest.mark.parametrize('name', SAMPS)
+def test_engine_loop_read_major_reproduces_the_reference_loop(name):
     from tombo_amd import resquiggle as rq
-    g, m, samp, model, params, save, mrs = _load()
+    g, m, samp, model, params, save, mrs = _load(name)
     st = np.random.get_state()
     np.random.seed(m['seed'])
     try:
         res, n_pass = rq.resquiggle_batch_iters(
             mrs, model, params, save, outlier_thresh=m['outlier_thresh'], seq_samp_type=samp,
-            max_scaling_iters=m['max_iters'], return_passes=True, rng_order='read_major')
+            max_scaling_iters=m['max_iters'], return_passes=True, rng_order='read_major',
+            device_prep=name == 'RNA')
     finally:
         np.random.set_state(st)
     assert n_pass == list(g['n_passes'])

@@ -45,3 +45,42 @@ def synth_map_res(std_ref, n_bases, seed, **kw):
                                 n_bases, 0),
         genome_loc=th.genomeLocation(0, '+', 'synth'), genome_seq=seq, mean_q_score=10.0,
         raw_signal=raw)
+
+
+def stalled_signal(rng, n, n_stalls, scale=90.0):
+    """RNA-like level steps of ~43 samples (70 bases/s at 3 kHz), in raw units, with `n_stalls`
+    stalled stretches (flat level + a few units of noise, 150-2500 samples: around the stall
+    detector's min_consecutive_obs + window on both sides) inserted at random places."""
+    n_lv = n // 20 + 2
+    lv = rng.normal(0.0, 1.0, n_lv)
+    dwell = np.maximum(6, rng.geometric(1.0 / 43.0, n_lv))
+    x = np.repeat(lv, dwell)[:n]
+    x = x + rng.normal(0.0, 0.25, x.shape[0])
+    raw = x * scale + 500.0
+    for _ in range(n_stalls):
+        a = int(rng.integers(0, max(1, raw.shape[0] - 3000)))
+        ln = int(rng.integers(150, 2500))
+        raw[a:a + ln] = raw[a] + rng.normal(0.0, rng.uniform(1.0, 12.0), raw[a:a + ln].shape[0])
+    return raw
+
+
+def edit_read(seq, raw, true_starts, edit):
+    """Disagreements between the mapped sequence and the signal, for test reads:
+    dict(kind='truncate', frac=f): the signal ends after the first f of the bases;
+    dict(kind='cut', n=k): the signal of k bases in the middle is missing (a deletion in the read);
+    dict(kind='insert', n=k, seed=s): k extra bases in the middle of the sequence (an insertion
+    in the reference)."""
+    if not edit:
+        return seq, raw
+    kind = edit['kind']
+    if kind == 'truncate':
+        return seq, np.ascontiguousarray(raw[:true_starts[int(len(true_starts) * edit['frac'])]])
+    if kind == 'cut':
+        a = len(true_starts) // 2
+        return seq, np.concatenate([raw[:true_starts[a]], raw[true_starts[a + edit['n']]:]])
+    if kind == 'insert':
+        rng = np.random.default_rng(edit.get('seed', 5))
+        ins = ''.join('ACGT'[c] for c in rng.integers(0, 4, edit['n']))
+        a = len(seq) // 2
+        return seq[:a] + ins + seq[a:], raw
+    raise ValueError('unknown edit %r' % (kind,))
