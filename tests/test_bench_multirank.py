@@ -47,3 +47,28 @@ def test_single_rank_bench_line_keys():
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
               'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'end_to_end'):
         assert k in r, k
+
+
+def test_four_ranks_under_torch_distributed_run():
+    """the driver's own launch line for N > 1 (python -m torch.distributed.run ... bench.py --gpus N)"""
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'TBA_STORE_PORT'):
+        env.pop(k, None)
+    import socket
+    with socket.socket() as s:      # a free port for the launcher's rendezvous
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+         '--gpus', '4', '--steps', '3', '--warmup', '1', '--reads', '12', '--bases', '400', '--cpu-sample', '2',
+         '--cpu-per-core', '0', '--stream-batch', '5', '--engine-stub',
+         os.path.join(ROOT, 'tests', 'stub_engine.py')],
+        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [x for x in out.stdout.decode().splitlines() if x.strip().startswith('{')]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 4 and r['steps'] == 3 and [x['rank'] for x in r['per_rank']] == [0, 1, 2, 3]
+    assert sum(x['steps'] for x in r['per_rank']) == 12
+    assert r['cpu_baseline']['value'] > 0 and r['roofline']['frac'] > 0
