@@ -24,11 +24,17 @@ class MemGroup(object):
 
     def create_group(self, name):
         g = self
-        for part in [p for p in name.split('/') if p]:
+        parts = [p for p in name.split('/') if p]
+        for i, part in enumerate(parts):
             if part not in g.items:
                 g.items[part] = MemGroup()
+            elif i == len(parts) - 1:
+                raise ValueError('Unable to create group (name already exists)')   # as h5py
             g = g.items[part]
         return g
+
+    def __delitem__(self, name):
+        del self.items[name]
 
     def create_dataset(self, name, data=None, **kw):
         d = MemDataset(data, **kw)

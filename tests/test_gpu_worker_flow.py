@@ -63,10 +63,24 @@ def test_fast5_to_record(samp_name):
     np.random.seed(5)
     index, failures = mapping.process_fast5_batch(fast5s, aligner, model, params, samp,
                                                   save_params=save, compute_sd=True)
-    assert sorted(m for m, _, _ in failures) == ['Alignment not produced',
-                                                 'Fastq slot not present in --basecall-group']
+    # (the read without basecalls is stopped by the prep step, under its bare file name; a read
+    # flagged by the score filter is written and indexed, and listed -- resquiggle.py:1442-1447)
+    poor = 'Poor raw to expected signal matching (revert with `tombo filter clear_filters`)'
+    n_filtered = sum(rd.filtered for _, _, rd in index)
+    assert sorted(m for m, _, _ in failures) == sorted(
+        ['Alignment not produced', 'Base calls not found in FAST5 (see `tombo preprocess`)'] + [poor] * n_filtered)
     assert all(t for _, _, t in failures)
+    assert [w for m, w, _ in failures if m.startswith('Base calls')] == ['reads/nofastq.fast5']
+    assert [w for m, w, _ in failures if m.startswith('Alignment')] == ['BaseCalled_template:::reads/nohit.fast5']
+    nohit = memh5.tree(fast5s[-2][0])
+    assert nohit['/Analyses/RawGenomeCorrected_000/BaseCalled_template@status'] == 'Alignment not produced'
+    assert nohit['/Analyses/RawGenomeCorrected_000@tombo_version'] == th.TOMBO_VERSION
+    assert nohit['/Analyses/RawGenomeCorrected_000@basecall_group'] == 'Basecall_1D_000'
     assert len(index) == len(truth)
+    # a second run over the same files: refused without --overwrite before any work is done
+    index2, failures2 = mapping.process_fast5_batch(fast5s[:2], aligner, model, params, samp)
+    assert index2 == [] and [f[0] for f in failures2] == [
+        'Tombo data exists in [--corrected-group] and [--overwrite] is not set'] * 2
     # the same reads, hand-mapped, through the iteration loop directly
     mrs = []
     for (seq, dac, ctg, r_st, strand), (f, fn) in zip(truth, fast5s):

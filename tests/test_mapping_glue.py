@@ -134,3 +134,49 @@ def test_unexpected_per_read_errors_do_not_abort_the_batch():
     assert [f[1] for f in failures] == ['BaseCalled_template:::%s.fast5' % c for c in 'abc']
     assert all(f[2] is False and 'Traceback' in f[0] for f in failures)
     assert 'aligner died' in failures[2][0]
+
+
+def test_prep_step_status_and_overwrite():
+    """th.prep_fast5 (tombo_helper.py:2259-2324) and th.write_error_status (:2326-2339) as
+    process_fast5_batch applies them: no mapping or GPU work is needed for any of these reads"""
+    import memh5
+    import gen_golden_map as gm
+    from scripted_aligner import ScriptedAligner
+    from tombo_amd import mapping, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    nohit = gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 1)
+    nobc = gm.make_fast5('ACGT', '5555', 500, 2, fastq=False)
+    other_bc = gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 3)
+    done = gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 4)
+    done['/Analyses'].create_group('RawGenomeCorrected_000/BaseCalled_template').attrs['status'] = 'success'
+    files = [(nohit, 'a.fast5'), (nobc, 'b.fast5'), (other_bc, 'c.fast5'), (done, 'd.fast5')]
+    aligner = ScriptedAligner({}, {})
+    index, failures = mapping.process_fast5_batch(files[:2] + files[3:], aligner, model, params, samp)
+    assert index == []
+    assert failures == [
+        ('Alignment not produced', 'BaseCalled_template:::a.fast5', True),
+        ('Base calls not found in FAST5 (see `tombo preprocess`)', 'b.fast5', True),
+        ('Tombo data exists in [--corrected-group] and [--overwrite] is not set', 'd.fast5', True)]
+    t = memh5.tree(nohit)
+    assert t['/Analyses/RawGenomeCorrected_000@tombo_version'] == th.TOMBO_VERSION
+    assert t['/Analyses/RawGenomeCorrected_000@basecall_group'] == 'Basecall_1D_000'
+    assert t['/Analyses/RawGenomeCorrected_000/BaseCalled_template@status'] == 'Alignment not produced'
+    assert memh5.tree(done)['/Analyses/RawGenomeCorrected_000/BaseCalled_template@status'] == 'success'
+    # --overwrite: the old group goes, the new one carries this run's outcome
+    index, failures = mapping.process_fast5_batch([(done, 'd.fast5')], aligner, model, params, samp,
+                                                  overwrite=True)
+    assert failures == [('Alignment not produced', 'BaseCalled_template:::d.fast5', True)]
+    assert memh5.tree(done)['/Analyses/RawGenomeCorrected_000/BaseCalled_template@status'] == \
+        'Alignment not produced'
+    # another --basecall-group than the file holds
+    index, failures = mapping.process_fast5_batch([(other_bc, 'c.fast5')], aligner, model, params, samp,
+                                                  bc_grp='Basecall_1D_001')
+    assert failures == [('Base calls not found in FAST5 (see `tombo preprocess`)', 'c.fast5', True)]
+    # write=False (the reference's dry run): nothing is prepared or written
+    fresh = gm.make_fast5('ACGTACGTACGT', '5' * 12, 500, 5)
+    index, failures = mapping.process_fast5_batch([(fresh, 'e.fast5')], aligner, model, params, samp,
+                                                  write=False)
+    assert failures == [('Alignment not produced', 'BaseCalled_template:::e.fast5', True)]
+    assert 'RawGenomeCorrected_000' not in fresh['/Analyses']

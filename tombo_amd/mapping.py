@@ -183,7 +183,7 @@ def process_fast5_batch(fast5s, aligner, std_ref, rsqgl_params, seq_samp_type, s
                         bc_subgrp='BaseCalled_template', corr_grp='RawGenomeCorrected_000',
                         compute_sd=False, obs_filter=None, q_score_thresh=0, sig_match_thresh=None,
                         sig_len_rng=None, seq_len_rng=None, map_thr_buf=None, write=True,
-                        engine=None):
+                        engine=None, overwrite=False):
     """One worker's share of `tombo resquiggle` for a list of reads, batch-shaped: what the
     reference does per read across `_io_and_map_read` and `_resquiggle_worker`
     (resquiggle.py:1385-1602) -- read the FAST5, map, resquiggle with the scale-iteration and
@@ -194,8 +194,14 @@ def process_fast5_batch(fast5s, aligner, std_ref, rsqgl_params, seq_samp_type, s
     the same group interface).  Returns (index_records, failures): index_records =
     [(chrom, strand, th.readData), ...] for the reads that succeeded (what the reference puts on
     its index queue, filters applied), failures = [(message, 'subgroup:::file', is_tombo_error)]
-    in the reference's failed-reads format.  The per-file error status the reference also
-    records (`th.write_error_status`) is left to the caller, who owns the files.
+    in the reference's failed-reads format -- including, as there, an entry for every read that a
+    reversible filter flagged (it is still written and indexed).
+
+    With `write`, every file is first prepared like `th.prep_fast5` does (resquiggle.py:1656:
+    basecalls present, corrected group absent or `overwrite`, group created with its version
+    attributes) -- before any mapping or GPU work is spent on it; the failures of that step carry
+    the bare file name, as the reference's do.  A read that fails with a Tombo error afterwards
+    gets the message as the `status` of its corrected subgroup (`th.write_error_status`).
     """
     from . import resquiggle as rq
     from ._default_parameters import SIG_MATCH_THRESH, OUTLIER_THRESH
@@ -204,12 +210,25 @@ def process_fast5_batch(fast5s, aligner, std_ref, rsqgl_params, seq_samp_type, s
     if sig_match_thresh is None:
         sig_match_thresh = SIG_MATCH_THRESH[seq_samp_type.name]
     failures, mapped, owners = [], [], []
+
+    def tombo_failure(f5, fn, msg):
+        if write:
+            try:
+                th.write_error_status_data(f5, corr_grp, bc_subgrp, msg)
+            except Exception:
+                pass
+        failures.append((msg, bc_subgrp + ':::' + fn, True))
     for k, (f5, fn) in enumerate(fast5s):
+        if write:
+            err = th.prep_fast5_data(f5, corr_grp, overwrite, bc_grp)
+            if err is not None:
+                failures.append((err, fn, True))
+                continue
         try:
             mr = read_fast5_for_mapping(f5, aligner, std_ref, seq_samp_type, bc_grp, bc_subgrp,
                                         map_thr_buf, q_score_thresh, sig_len_rng, seq_len_rng)
         except th.TomboError as e:
-            failures.append((str(e), bc_subgrp + ':::' + fn, True))
+            tombo_failure(f5, fn, str(e))
             continue
         except Exception:
             # any other per-read failure (truncated Fastq, missing dataset, aligner error) is
@@ -227,23 +246,32 @@ def process_fast5_batch(fast5s, aligner, std_ref, rsqgl_params, seq_samp_type, s
     for k, res in zip(owners, results):
         f5, fn = fast5s[k]
         if isinstance(res, Exception):
-            failures.append((str(res), bc_subgrp + ':::' + fn, isinstance(res, th.TomboError)))
+            if isinstance(res, th.TomboError):
+                tombo_failure(f5, fn, str(res))
+            else:
+                failures.append((str(res), bc_subgrp + ':::' + fn, False))
             continue
         if write:
             try:
-                analyses = f5['/Analyses']
-                try:
-                    analyses[corr_grp]
-                except KeyError:
-                    analyses.create_group(corr_grp)
                 th.write_new_fast5_group(f5, corr_grp, res, 'median', compute_sd,
                                          rna=seq_samp_type.rev_sig)
             except th.TomboError as e:
-                failures.append((str(e), bc_subgrp + ':::' + fn, True))
+                tombo_failure(f5, fn, str(e))
                 continue
             except Exception:
                 failures.append((traceback.format_exc(), bc_subgrp + ':::' + fn, False))
                 continue
-        index_records.append(filter_and_index_record(res, fn, corr_grp, bc_subgrp, seq_samp_type,
-                                                     sig_match_thresh, obs_filter))
+        rec = filter_and_index_record(res, fn, corr_grp, bc_subgrp, seq_samp_type, sig_match_thresh,
+                                      obs_filter)
+        # the failed-reads entries of the reversible filters (resquiggle.py:1442-1455); like the
+        # reference, the observations-per-base message goes out for every read that passed the
+        # score filter whenever an `obs_filter` is set, filtered or not
+        if res.sig_match_score > sig_match_thresh:
+            failures.append(('Poor raw to expected signal matching ' +
+                             '(revert with `tombo filter clear_filters`)', bc_subgrp + ':::' + fn, True))
+        elif obs_filter is not None:
+            failures.append(('Read filtered by observation per base ' +
+                             'thresholds (revert with `tombo filter clear_filters`)',
+                             bc_subgrp + ':::' + fn, True))
+        index_records.append(rec)
     return index_records, failures

@@ -273,6 +273,50 @@ _ALIGN_INFO_ATTRS = (   # only when the read carries an alignInfo
 )
 
 
+# the Tombo release whose FAST5 layout this writer follows (the reference stamps its own version
+# into the corrected group, tombo_helper.py:2311)
+TOMBO_VERSION = '1.5.1'
+
+
+def prep_fast5_data(fast5_data, corr_grp, overwrite, bc_grp=None):
+    """`prep_fast5` (tombo_helper.py:2259-2324) on an OPEN, writable FAST5 object: the checks the
+    reference makes before it spends any compute on a read.  The basecalls must be there; an
+    existing corrected group is an error unless `overwrite` (then it is deleted); the corrected
+    group is created with its `tombo_version` / `basecall_group` attributes.  Returns None, or
+    the reference's message for the failed-reads list (always a "Tombo error")."""
+    try:
+        try:
+            analyses = fast5_data['/Analyses']
+            if bc_grp is not None:
+                analyses[bc_grp]
+        except Exception:
+            return 'Base calls not found in FAST5 (see `tombo preprocess`)'
+        try:
+            analyses[corr_grp]
+            exists = True
+        except Exception:
+            exists = False
+        if exists:
+            if not overwrite:
+                return 'Tombo data exists in [--corrected-group] and [--overwrite] is not set'
+            del analyses[corr_grp]
+        grp = analyses.create_group(corr_grp)
+        grp.attrs['tombo_version'] = TOMBO_VERSION
+        grp.attrs['basecall_group'] = bc_grp
+    except Exception:
+        return 'Error opening or writing to fast5 file'
+    return None
+
+
+def write_error_status_data(fast5_data, corr_grp, bc_subgrp, error_text):
+    """`write_error_status` (tombo_helper.py:2326-2339) on an open FAST5 object: the message of a
+    failed read as the `status` attribute of its corrected (sub)group."""
+    grp = fast5_data['/Analyses'][corr_grp]
+    if bc_subgrp is not None:
+        grp = grp.create_group(bc_subgrp)
+    grp.attrs['status'] = error_text
+
+
 def write_new_fast5_group(fast5_data, corr_grp_slot, rsqgl_res, norm_type, compute_sd,
                           alignVals=None, old_segs=None, rna=False, event_data=None):
     """Write a resquiggled read into an open FAST5 file: the groups, attributes and `Events`
