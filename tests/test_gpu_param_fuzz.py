@@ -55,6 +55,58 @@ def test_engine_matches_oracle_over_the_parameter_box(pt):
     assert not bad, '\n'.join(bad[:20])
 
 
+@st.composite
+def disagreeing_reads(draw):
+    kind = draw(st.sampled_from(['cut', 'insert', 'truncate', 'none']))
+    edit = None
+    if kind == 'cut':
+        edit = dict(kind='cut', n=draw(st.integers(3, 90)))
+    elif kind == 'insert':
+        edit = dict(kind='insert', n=draw(st.integers(3, 90)), seed=draw(st.integers(0, 99)))
+    elif kind == 'truncate':
+        edit = dict(kind='truncate', frac=draw(st.sampled_from([0.5, 0.8, 0.9, 0.95, 0.99])))
+    return dict(rna=draw(st.booleans()), edit=edit, seed=draw(st.integers(0, 10 ** 6)),
+                n_bases=draw(st.sampled_from([260, 600, 1100, 1700])),
+                dwell=draw(st.sampled_from([None, 0.25, 0.4, 1.6, 3.0])),   # x the sample type's mean dwell
+                noise_sd=draw(st.sampled_from([0.15, 0.25, 0.5, 0.9])),
+                lead=draw(st.sampled_from([None, 20, 2500, 7000])),
+                bw=draw(st.sampled_from([100, 300, 500])), bbt=draw(st.sampled_from([10, 40])))
+
+
+@settings(max_examples=150, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(disagreeing_reads())
+def test_engine_matches_oracle_on_reads_that_disagree_with_their_sequence(pt):
+    """deletions / insertions against the mapped sequence, truncated signal, dwell and noise far
+    from the model's, long leaders: the paths that end in resolve_skipped_bases_with_raw, the
+    start retry and the failure strings (the oracle is pinned on 11 such reads recorded from the
+    live reference, tests/golden/e_*.npz)"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    from test_gpu_parity import run_batch, compare_batch
+    name = 'RNA' if pt['rna'] else 'DNA'
+    samp = th.seqSampleType(name, False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=pt['bw'], band_bound_thresh=pt['bbt'])
+    kw = dict(synth.RNA_SYNTH if pt['rna'] else synth.DNA_SYNTH, noise_sd=pt['noise_sd'])
+    if pt['dwell'] is not None:
+        kw['mean_dwell'] = max(2, int(kw['mean_dwell'] * pt['dwell']))
+        kw['min_dwell'] = max(1, min(kw['min_dwell'], kw['mean_dwell'] // 2))
+    if pt['lead'] is not None:
+        kw['lead'] = pt['lead']
+    reads = []
+    for k in range(3):
+        nb = pt['n_bases'] + 53 * k
+        seq, raw, starts = synth.synth_read(model, nb, pt['seed'] + k, **kw)
+        seq, raw = synth.edit_read(seq, raw, starts, pt['edit'])
+        b = len(seq) - model.kmer_width + 1
+        rs = np.random.RandomState(pt['seed'] + k)
+        si = rs.choice(b, 1000, replace=False).astype(np.int64) if b > 1000 else None
+        reads.append((raw, seq, None, si))
+    eng, out, oracles = run_batch(model, params, name, reads)
+    bad = compare_batch(eng, oracles, out, repr(pt))
+    assert not bad, '\n'.join(bad[:20])
+
+
 def test_rna_without_outlier_thresh_is_an_unexpected_error():
     """get_scale_values_from_events negates outlier_thresh (tombo_stats.py:228): with None the
     reference dies with a TypeError -- not a TomboError; status TBA_INTERNAL here"""
