@@ -220,7 +220,16 @@ __device__ __forceinline__ double shift_cells(double (&Q)[CPL])
 //   prev row : registers + DPP (above); cells >= W hold -inf so out-of-band candidates need no guards
 //   mu/sd    : prefetched one row ahead
 template <int CPL, bool DIRECT>
-__global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, int mode,
+// -DTBA_DP_WAVES=n: waves per SIMD the register allocation of the classes up to 8 cells per lane
+// is held to (A/B builds; 5 = 96 VGPRs for k_dp<8> instead of 112 measured SLOWER, 70.4 against
+// 65.6 ms at W = 500: the squeeze costs instructions and the LDS ring allows 19 workgroups per CU,
+// not 20 -- DESIGN.md section 4)
+#ifdef TBA_DP_WAVES
+#define TBA_DP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CPL <= 8 ? TBA_DP_WAVES : 1)))
+#else
+#define TBA_DP_WAVES_ATTR
+#endif
+__global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
     i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,
     unsigned char *moves, i64 start_moves_stride, double *last_row, DpJob *job)
@@ -375,21 +384,43 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         rc = rc < n_rows ? rc : n_rows - 1;
         mu_v = rmu[rc]; sd_v = rsd[rc];
         y_v = 1.0 / sd_v;
+        // the loads end HERE, once per 64 rows: left pending, the rows' read of these registers
+        // sits behind a conditional load and the compiler guards it with s_waitcnt vmcnt(0) in
+        // EVERY row (which on gfx9 also waits for the previous row's stores)
+        asm volatile("" : "+v"(mu_v));
     };
     if (!use_z) load_levels(row0);
+    // Per-row band geometry of the static rows, loaded one row ahead.  The three registers are
+    // touched by nothing but these loads and the static rows' read of them: an adaptive row that
+    // as much as selects on one of them gets an s_waitcnt vmcnt(0) from the compiler (the register
+    // MAY have a load in flight), which on gfx9 also waits for the previous row's stores.
     int st_n = 0, lo_n = 0, hi_n = Wi;
-    auto fetch_row = [&](int rr) { // per-row band geometry of the static rows, one row ahead
+    auto fetch_row = [&](int rr) {
         const int rc = rr < n_rows ? rr : n_rows - 1;
-        if (rc < n_static) {
-            if (identity) { st_n = rc; lo_n = 0; hi_n = Wi; }
-            else if (DIRECT) { st_n = (int)bst[rc]; lo_n = 0; hi_n = Wi; }
-            else { st_n = (int)bst[rc]; lo_n = lo_a[rc]; hi_n = hi_a[rc]; }
+        if (rc < n_static && !identity) {
+            st_n = (int)bst[rc];
+            if (!DIRECT) { lo_n = lo_a[rc]; hi_n = hi_a[rc]; }
         }
     };
     fetch_row(row0);
 
 #ifdef TBA_SWEEP_STATS
     i64 sw_total = 0;
+#endif
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 5
+    // cycles of wave 0's rows by part: 0 z-scores (ring reads + arithmetic), 1 candidates, 2 first
+    // scan + sweeps, 3 cells / flags / stores / ring upkeep, 4 arg-max, 5 band placement; 6 rows
+    // dbg[7]: where the wavefront ran: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+    // | XCC_ID << 32
+    i64 ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    i64 ph_t = (i64)__builtin_readcyclecounter();
+    u32 hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    const i64 ph_first = (i64)hw_id | ((i64)(xcc_id & 15) << 32);
+#define DP_PH(i_) do { const i64 t_ = (i64)__builtin_readcyclecounter(); ph[i_] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define DP_PH(i_) do { } while (0)
 #endif
     for (int row = row0; row < n_rows; row++) {
         double mu = 0, sd = 1, y = 1;
@@ -402,7 +433,9 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         int lo, hi;
         double fill;
         if (row < n_static) {
-            cur_start = uni(st_n); lo = uni(lo_n); hi = uni(hi_n);
+            if (identity) { cur_start = row; lo = 0; hi = Wi; }                 // start discovery
+            else if (DIRECT) { cur_start = uni(st_n); lo = 0; hi = Wi; }
+            else { cur_start = uni(st_n); lo = uni(lo_n); hi = uni(hi_n); }
             fill = fill_masked;
         } else {
             // adaptive band placement, pyx:342-358
@@ -422,6 +455,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         }
         fetch_row(row + 1); // next row's inputs travel while this row computes
         const int diff_i = row > 0 ? cur_start - prev_start : 0;
+        DP_PH(5);
 
         // shifted half z-scores of my cells (pyx:361-372 / resquiggle.py:574-582,712-720)
         double z[CPL];
@@ -454,6 +488,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        DP_PH(0);
         // diag / skip candidates from the previous row (pyx:220-231), first cell pyx:392-401:
         // pp[j] is cell j's diagonal source and cell j-1's skip source
         double cv[CPL];
@@ -484,6 +519,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         // instructions per cell instead of 3) to get the lane's exit value max(v0[CPL-1], c_{CPL-1}),
         // and the cells themselves are written once, in the pass that also derives the move flags.
         // The sequence of incoming values is the same as with full sweeps, so is the sweep count.
+        DP_PH(1);
         double in = NEG_INF;
         bool converged = false;
         double exit0;
@@ -517,6 +553,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
             if (lane == 0) { if (DIRECT) job->status = TBA_INTERNAL; else r.status = TBA_INTERNAL; }
             return;
         }
+        DP_PH(2);
         // the cells, their move codes (0 stay, 1 skip, 2 diag; pyx:216-231) packed 2 bits per cell,
         // lane-local argmax (pyx:186-197; -inf cells never win)
         u32 mvw[(CPL + 15) / 16];
@@ -573,6 +610,7 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
                 pf_at = filled; pf = ev_load(filled + lane); pf_pending = true;
             }
         }
+        DP_PH(3);
         // wave argmax, first index among equal maxima (c_argmax, pyx:186-197): first lane that
         // holds the maximum, first of its cells that equals it
         // The wave maximum is first located in float32 (conversion is monotone, so the lanes
@@ -596,7 +634,18 @@ __global__ __launch_bounds__(64) void k_dp(ReadState *rs, const DevParams *dp, i
         for (int j = CPL - 2; j >= 0; j--) wj = ((__ballot(v[j] == wm) >> wl) & 1ull) ? j : wj;
         am = wl * CPL + wj;
         prev_start = cur_start;
+        DP_PH(4);
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 5
+        ph[6]++;
+#endif
     }
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 5
+    if (!DIRECT && mode == DP_MAIN && lane == 0) {
+        for (int i = 0; i < 7; i++) r.dbg[i] = ph[i];
+        r.dbg[7] = ph_first;
+    }
+#endif
+#undef DP_PH
 #ifdef TBA_SWEEP_STATS
     if (!DIRECT && mode == DP_MAIN && lane == 0) {
         r.dbg[0] = n_rows - row0; r.dbg[1] = sw_total;

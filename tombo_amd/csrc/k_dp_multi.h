@@ -149,13 +149,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TBA_DPM_WAVE
         rc = rc < 0 ? 0 : rc;
         mu_v = rmu[ro + rc]; sd_v = rsd[ro + rc];
         y_v = 1.0 / sd_v;
+        asm volatile("" : "+v"(mu_v)); // (the loads end here, not in every row: k_dp.h)
     };
     load_levels(0);
     int st_n = 0, lo_n = 0, hi_n = Wi;
-    auto fetch_row = [&](int rr) { // band geometry of the static (masked start) rows, one row ahead
+    // band geometry of the static (masked start) rows, one row ahead.  Rows in which no group is
+    // static must not touch the three registers at all (k_dp.h: the compiler guards any use with
+    // s_waitcnt vmcnt(0), which also waits for the previous row's stores), hence the wave-uniform
+    // branches around the loads here and around the selects below.
+    auto fetch_row = [&](int rr) {
         int rc = rr < n_rows ? rr : n_rows - 1;
         rc = rc < 0 ? 0 : rc;
-        if (rc < n_static) { st_n = (int)bst[ro + rc]; lo_n = lo_a[ro + rc]; hi_n = hi_a[ro + rc]; }
+        if (__ballot(rc < n_static) != 0) {
+            if (rc < n_static) { st_n = (int)bst[ro + rc]; lo_n = lo_a[ro + rc]; hi_n = hi_a[ro + rc]; }
+        }
     };
     fetch_row(0);
     const int grp_base = lane & ~(LPR - 1);
@@ -177,9 +184,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TBA_DPM_WAVE
             }
             cs = n_ev - 1;
         }
-        int cur_start = is_static ? st_n : cs;
-        int lo = is_static ? lo_n : 0;
-        int hi = is_static ? hi_n : (cs + Wi <= n_ev ? Wi : n_ev - cs);
+        int cur_start = cs, lo = 0, hi = cs + Wi <= n_ev ? Wi : n_ev - cs;
+        if (__ballot(is_static) != 0) {
+            cur_start = is_static ? st_n : cur_start;
+            lo = is_static ? lo_n : lo;
+            hi = is_static ? hi_n : hi;
+        }
         if (!act) { cur_start = prev_start; lo = 0; hi = Wi; } // a finished group idles in place
         if (act && !is_static && first_lane) bst[ro + row] = cur_start;
         fetch_row(row + 1);

@@ -22,7 +22,8 @@ typedef uint32_t u32;
 
 // optional per-phase cycle stamps into ReadState.dbg: build with -DTBA_PHASE_DEBUG=<kernel>
 // (1 k_peaks, 2 k_normalize, 3 k_theil_sen: stamps cumulative from the kernel's start; 4: the
-// three parts of k_peaks' tiles, summed over wave 0's tiles)
+// three parts of k_peaks' tiles, summed over wave 0's tiles; 5: the parts of a k_dp row, summed
+// over the rows of the read)
 #ifdef TBA_PHASE_DEBUG
 #define TBA_PHASE_T0(k_) const i64 tba_t0_ = (k_) == TBA_PHASE_DEBUG ? (i64)__builtin_readcyclecounter() : 0; \
     const i64 tba_w0_ = (k_) == TBA_PHASE_DEBUG ? (i64)__builtin_amdgcn_s_memrealtime() : 0
