@@ -219,16 +219,17 @@ __device__ __forceinline__ double shift_cells(double (&Q)[CPL])
 //              prefetches one chunk ahead (no global-load latency on the row chain)
 //   prev row : registers + DPP (above); cells >= W hold -inf so out-of-band candidates need no guards
 //   mu/sd    : prefetched one row ahead
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
 template <int CPL, bool DIRECT>
-// -DTBA_DP_WAVES=n: waves per SIMD the register allocation of the classes up to 8 cells per lane
-// is held to (A/B builds; 5 = 96 VGPRs for k_dp<8> instead of 112 measured SLOWER, 70.4 against
-// 65.6 ms at W = 500: the squeeze costs instructions and the LDS ring allows 19 workgroups per CU,
-// not 20 -- DESIGN.md section 4)
-#ifdef TBA_DP_WAVES
-#define TBA_DP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CPL <= 8 ? TBA_DP_WAVES : 1)))
-#else
-#define TBA_DP_WAVES_ATTR
+// Waves per SIMD the register allocation of the classes up to 8 cells per lane is held to: 4 (128
+// VGPRs; k_dp<8> comes out at 133 without it since the row loop exists twice).  -DTBA_DP_WAVES=5 (96
+// VGPRs) was measured SLOWER, 70.4 against 65.6 ms at W = 500: the squeeze costs instructions and
+// the LDS ring allows 19 workgroups per CU, not 20.
+#ifndef TBA_DP_WAVES
+#define TBA_DP_WAVES 4
 #endif
+#define TBA_DP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CPL <= 8 ? TBA_DP_WAVES : 1)))
 __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
     i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,
@@ -422,7 +423,12 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
 #else
 #define DP_PH(i_) do { } while (0)
 #endif
-    for (int row = row0; row < n_rows; row++) {
+    // One row of the forward pass.  ADAPT: the row is past the static rows (compile-time: no
+    // band-geometry loads, no masked-start test -- a wavefront on its own issues ONE instruction
+    // of any kind per >= 4 cycles, so the scalar bookkeeping of the general row costs it as much
+    // as the arithmetic).  Returns true when the read has failed.
+    auto row_step = [&](const int row, auto adapt_tag) __attribute__((always_inline)) -> bool {
+        constexpr bool ADAPT = decltype(adapt_tag)::value;
         double mu = 0, sd = 1, y = 1;
         if (!use_z) {
             const int sel = (row - row0) & 63;
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
         int cur_start;
         int lo, hi;
         double fill;
-        if (row < n_static) {
+        if (!ADAPT) {
             if (identity) { cur_start = row; lo = 0; hi = Wi; }                 // start discovery
             else if (DIRECT) { cur_start = uni(st_n); lo = 0; hi = Wi; }
             else { cur_start = uni(st_n); lo = uni(lo_n); hi = uni(hi_n); }
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
             if (cur_start >= n_ev) {
                 if (row < n_rows - 2) {
                     if (lane == 0) { if (DIRECT) job->status = TBA_ADAPT_BEYOND; else r.status = TBA_ADAPT_BEYOND; }
-                    return;
+                    return true;
                 }
                 cur_start = n_ev - 1;
             }
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
             hi = cur_start + W <= n_ev ? Wi : n_ev - cur_start;
             fill = DIRECT ? fill_masked : MASK_FILL_Z_SCORE; // literal -15, pyx:385-386
         }
-        fetch_row(row + 1); // next row's inputs travel while this row computes
+        if (!ADAPT) fetch_row(row + 1); // next row's inputs travel while this row computes
         const int diff_i = row > 0 ? cur_start - prev_start : 0;
         DP_PH(5);
 
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
                 pz = __builtin_fmin(pz, zcap);
                 z[j] = zs[j] - pz; // cells past the band: -inf - pz = -inf, stays -inf for good
             }
-            if (__builtin_expect(lo != 0 || hi != Wi, 0)) { // masked start rows / band past the last event
+            if (__builtin_expect((!ADAPT && lo != 0) || hi != Wi, 0)) { // masked start rows / band past the last event
 #pragma unroll
                 for (int j = 0; j < CPL; j++) {
                     z[j] = (b0 + j >= lo && b0 + j < hi) ? z[j] : fill;
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
 #endif
         if (!converged) { // only reachable with NaNs in the signal
             if (lane == 0) { if (DIRECT) job->status = TBA_INTERNAL; else r.status = TBA_INTERNAL; }
-            return;
+            return true;
         }
         DP_PH(2);
         // the cells, their move codes (0 stay, 1 skip, 2 diag; pyx:216-231) packed 2 bits per cell,
@@ -638,6 +644,13 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
 #if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 5
         ph[6]++;
 #endif
+        return false;
+    };
+    {
+        int row = row0;
+        const int n_stat_rows = n_static < n_rows ? n_static : n_rows;
+        for (; row < n_stat_rows; row++) if (row_step(row, BoolTag<false>{})) return;
+        for (; row < n_rows; row++) if (row_step(row, BoolTag<true>{})) return;
     }
 #if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 5
     if (!DIRECT && mode == DP_MAIN && lane == 0) {
