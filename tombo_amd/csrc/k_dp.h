@@ -303,6 +303,23 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
         winsor = P.do_winsorize_z != 0;
         fill_masked = dp->fill_masked;
     }
+#ifndef TBA_NO_DP_PRIO
+    // The SIMD's arbiter serves the oldest wavefront first.  Workgroups are dispatched in index
+    // order, so the last ones of the launch -- the wavefronts its end waits for -- are the youngest
+    // on their SIMDs for all of their lives: they wait while the older ones run at lone speed and
+    // finish long after them (4 096 equal reads started together end between 16 and 30 ms).
+    // Priority by dispatch order over the last four wavefronts per SIMD (s_setprio, 4 levels; 1 024
+    // SIMDs on an MI355X): a late starter runs at lone speed, the rest of the launch is as it was.
+    // (Priority by PROGRESS -- fewer rows done, served first -- was measured too: it bunches the
+    // wavefronts of a SIMD, which then drains in steps of four or five reads: -2 % at W = 500,
+    // +4 % at W = 300.)
+    if (!DIRECT && mode == DP_MAIN) {
+        const unsigned from_end = gridDim.x - 1u - blockIdx.x;
+        if (from_end < 1024u) __builtin_amdgcn_s_setprio(3);
+        else if (from_end < 2048u) __builtin_amdgcn_s_setprio(2);
+        else if (from_end < 3072u) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     // everything above came through vector loads: make it scalar once
     W = uni(W); n_rows = uni(n_rows); n_static = uni(n_static); n_ev = uni(n_ev); row0 = uni(row0);
     identity = uni(identity); winsor = uni(winsor);
