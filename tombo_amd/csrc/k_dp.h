@@ -315,9 +315,12 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
     // +4 % at W = 300.)
     if (!DIRECT && mode == DP_MAIN) {
         const unsigned from_end = gridDim.x - 1u - blockIdx.x;
-        if (from_end < 1024u) __builtin_amdgcn_s_setprio(3);
-        else if (from_end < 2048u) __builtin_amdgcn_s_setprio(2);
-        else if (from_end < 3072u) __builtin_amdgcn_s_setprio(1);
+#ifndef TBA_DP_PRIO_LEVELS
+#define TBA_DP_PRIO_LEVELS 3
+#endif
+        if (from_end < 1024u) __builtin_amdgcn_s_setprio(TBA_DP_PRIO_LEVELS);
+        else if (TBA_DP_PRIO_LEVELS > 1 && from_end < 2048u) __builtin_amdgcn_s_setprio(TBA_DP_PRIO_LEVELS - 1);
+        else if (TBA_DP_PRIO_LEVELS > 2 && from_end < 3072u) __builtin_amdgcn_s_setprio(TBA_DP_PRIO_LEVELS - 2);
     }
 #endif
     // everything above came through vector loads: make it scalar once
