@@ -22,12 +22,15 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def golden_names():
+def golden_names(oracle_only=False):
     # read-level cases; kernels_*.npz hold stand-alone kernel vectors (test_oracle_kernels_golden),
     # dacq_*.npz the reference's runs on DAC-quantised reads (test_dac_quantised), stalls_*.npz
-    # identify_stalls off its defaults (test_stalls_golden), loop_*.npz the worker loop
+    # identify_stalls off its defaults (test_stalls_golden), loop_*.npz the worker loop.
+    # o_*.npz (gen_golden_box.py) pin the oracle over the parameter box of the GPU fuzz and are
+    # only listed with oracle_only=True: the engine meets that box through hypothesis.
+    skip = ('kernels_', 'dacq_', 'stats_', 'loop_', 'stalls_') + (() if oracle_only else ('o_',))
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))
-                  if not os.path.basename(f).startswith(('kernels_', 'dacq_', 'stats_', 'loop_', 'stalls_')))
+                  if not os.path.basename(f).startswith(skip))
 
 
 class GoldenCase(object):
