@@ -230,7 +230,7 @@ template <int CPL, bool DIRECT>
 #define TBA_DP_WAVES 4
 #endif
 #define TBA_DP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CPL <= 8 ? TBA_DP_WAVES : 1)))
-__global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, const DevParams *dp, int mode,
+__device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
     i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,
     unsigned char *moves, i64 start_moves_stride, double *last_row, DpJob *job)
@@ -694,6 +694,29 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(ReadState *rs, cons
         if (lane == 0) r.top_pos = am;
     }
 }
+
+#define TBA_DP_ARGS ReadState *rs, const DevParams *dp, int mode, \
+    const double *event_means, const double *ref_means, const double *ref_sds, \
+    i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr, \
+    unsigned char *moves, i64 start_moves_stride, double *last_row, DpJob *job
+#define TBA_DP_PASS rs, dp, mode, event_means, ref_means, ref_sds, band_starts, lo_arr, hi_arr, \
+    moves, start_moves_stride, last_row, job
+template <int CPL, bool DIRECT>
+__global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(TBA_DP_ARGS)
+{
+    dp_body<CPL, DIRECT>(TBA_DP_PASS);
+}
+#ifdef TBA_DP_NUM_VGPR
+// A/B switch: the batch form of the 8-cell class (W = 500) under an explicit register budget
+// (amdgpu_num_vgpr takes no template-dependent value, hence a specialisation), so that other
+// streams' kernels find registers beside four of its wavefronts.
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TBA_DP_WAVES), amdgpu_num_vgpr(TBA_DP_NUM_VGPR)))
+void k_dp<8, false>(TBA_DP_ARGS)
+{
+    dp_body<8, false>(TBA_DP_PASS);
+}
+#endif
 
 // Static whole-read DP (find_static_base_assignment, resquiggle.py:547-600 over
 // c_banded_forward_pass, pyx:240-279) for bands wider than the widest register class: a short
