@@ -123,6 +123,11 @@ int  tba_device_mem(tba_engine *e, int64_t *free_bytes, int64_t *total_bytes);
 
 /* device bytes held by this engine's (grow-only) batch buffers */
 int  tba_engine_held_bytes(tba_engine *e, int64_t *bytes);
+/* Scheduling hint, no effect on results: n_engines = how many engines are fed concurrently on this
+ * engine's device (the slots of a streaming pipeline; 1 = this engine has the device to itself, the
+ * default).  With n_engines > 1 a batch whose work is mostly outside the banded DP (RNA) runs the
+ * register-capped build of the DP kernel so that the other engines' kernels fit beside it. */
+int  tba_engine_set_sharing(tba_engine *e, int n_engines);
 
 /* canonical k-mer level table, lexicographic k-mer order (TomboModel, tombo_stats.py:580-919;
  * lookup replaces get_exp_levels_from_seq :834-862) */
@@ -237,6 +242,8 @@ enum {
     TBA_GET_STALL_OFF = 22,   /* int64[n] */
     TBA_GET_SAMP_IND = 23,    /* int64[n][1000]: the Theil-Sen subsamples used (as uploaded, or as
                                  drawn under tba_opts.device_subsample; reads of <= 1000 bases: unused) */
+    TBA_GET_TB_PARALLEL = 24, /* int32[n]: 1 where the chunk-parallel traceback walked the read (performance
+                               * diagnostics: 0 on an adaptive read means the lane-per-read walk had to) */
     TBA_GET_DEBUG_COUNTERS = 99 /* int64[n][8]: ReadState.dbg, only filled by -DTBA_PHASE_DEBUG /
                                    -DTBA_SWEEP_STATS profiling builds (zeros otherwise) */
 };
@@ -409,8 +416,10 @@ int tba_pack_reads(int64_t n_reads, const void *const *raw_ptrs, int raw_dtype, 
 int tba_unpack_reads(int64_t n_reads, const void *src, int64_t elem_bytes, const int64_t *src_off,
     const int64_t *count, void *const *dst_ptrs, int n_threads);
 
-/* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build: lets a
- * binding without a C compiler (ctypes) check its struct mirrors */
+/* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build, out[3]
+ * (n >= 4) = TBA_ABI_VERSION: lets a binding without a C compiler (ctypes) check its struct mirrors
+ * and refuse a stale build of the library */
+#define TBA_ABI_VERSION 4
 int tba_abi_sizes(int64_t *out, int64_t n);
 
 /* self-test: out[t] = index t of the subsample tba_opts.device_subsample draws for read

@@ -37,6 +37,9 @@ def install(_native):
         def held_bytes(self):
             return 0
 
+        def set_sharing(self, n_engines):
+            pass
+
         def host_stage(self):
             if self._stage is None:
                 self._stage = _native.PinnedStage()

@@ -285,6 +285,12 @@ def test_full_size_reads_vs_oracle_on_gpu():
     bad = compare_batch(eng, oracles, out, 'cfg2')
     assert not bad, '\n'.join(bad[:40])
     assert all(o['status'] == 0 for o in oracles)
+    # (performance guard, not parity: every one of these adaptive reads must have been walked by the
+    # chunk-parallel traceback -- a read it leaves costs the whole batch the serial walk's 5 ms)
+    from tombo_amd import _native
+    done, path = eng.get(_native.GET_TB_PARALLEL), eng.get(_native.GET_PATH)[:, 0]
+    assert np.all(done[path == 1] == 1), 'reads left to the lane-per-read traceback: %r' % (
+        np.flatnonzero((path == 1) & (done != 1)).tolist(),)
 
 
 def test_long_reads_vs_oracle_on_gpu():

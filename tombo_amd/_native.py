@@ -82,13 +82,14 @@ RAW_DTYPES = {np.dtype(np.float64): RAW_F64, np.dtype(np.float32): RAW_F32,
 GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START, \
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
     GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL, \
-    GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND = range(1, 24)
+    GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND, GET_TB_PARALLEL = range(1, 25)
 GET_DEBUG_COUNTERS = 99  # ReadState.dbg of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS profiling build
 STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, STAGE_SKIP, \
     STAGE_RESCALE = range(7)
 PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
     PUT_START_STATE = range(1, 8)
 MAX_BAND = 3072
+ABI_VERSION = 4  # TBA_ABI_VERSION of include/tombo_amd.h
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
                "rescale_score", "stalls", "total"]
@@ -103,8 +104,21 @@ def lib():
             raise RuntimeError(
                 'libtombo_amd.so is not built (run `python -c "import __graft_entry__ as g; '
                 'g.build()"`); the resquiggle engine has no CPU fallback')
-        _lib = C.CDLL(LIB_PATH)
-        _lib.tba_last_error.restype = C.c_char_p
+        L = C.CDLL(LIB_PATH)
+        L.tba_last_error.restype = C.c_char_p
+        # a stale build (the .so is not tracked by git) must not be driven through newer struct
+        # mirrors: the engine would read past tba_opts, or miss fields, without any error
+        try:
+            out = (i64 * 4)()
+            ok = L.tba_abi_sizes(out, i64(4)) == 0 and list(out) == [
+                C.sizeof(Params), C.sizeof(Opts), C.sizeof(ReadResult), ABI_VERSION]
+        except AttributeError:
+            ok = False
+        if not ok:
+            raise RuntimeError(
+                '%s does not match this binding (struct sizes / TBA_ABI_VERSION %d): rebuild it '
+                '(`python -c "import __graft_entry__ as g; g.build()"`)' % (LIB_PATH, ABI_VERSION))
+        _lib = L
     return _lib
 
 
@@ -338,6 +352,10 @@ class Engine(object):
         self._check(self._L.tba_engine_held_bytes(self._h, C.byref(a)), 'tba_engine_held_bytes')
         return a.value
 
+    def set_sharing(self, n_engines):
+        """scheduling hint: `n_engines` engines are fed concurrently on this device (tba_engine_set_sharing)"""
+        self._check(self._L.tba_engine_set_sharing(self._h, int(n_engines)), 'tba_engine_set_sharing')
+
     def host_stage(self):
         """this engine's reusable page-locked staging arrays (PinnedStage)"""
         st = getattr(self, '_stage', None)
@@ -412,6 +430,7 @@ class Engine(object):
             GET_STATUS: (np.int32, n), GET_START_FAIL: (np.int32, n),
             GET_N_STALL: (np.int64, n), GET_STALL_OFF: (np.int64, n),
             GET_SAMP_IND: (np.int64, (n, 1000)),
+            GET_TB_PARALLEL: (np.int32, n),
         }
         if what in (GET_VALID_CPTS, GET_EVENT_MEANS):
             out = np.zeros(max(int(self.ev_off[-1]), 1),

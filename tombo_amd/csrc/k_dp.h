@@ -706,17 +706,19 @@ __global__ __launch_bounds__(64) TBA_DP_WAVES_ATTR void k_dp(TBA_DP_ARGS)
 {
     dp_body<CPL, DIRECT>(TBA_DP_PASS);
 }
-#ifdef TBA_DP_NUM_VGPR
-// A/B switch: the batch form of the 8-cell class (W = 500) under an explicit register budget
-// (amdgpu_num_vgpr takes no template-dependent value, hence a specialisation), so that other
-// streams' kernels find registers beside four of its wavefronts.
-template <>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TBA_DP_WAVES), amdgpu_num_vgpr(TBA_DP_NUM_VGPR)))
-void k_dp<8, false>(TBA_DP_ARGS)
+// The batch form of the 8-cell class (W = 500) under a register budget of 112 instead of 128
+// (amdgpu_num_vgpr counts in units of two on gfx90a+: 56; it takes no template-dependent value,
+// hence a kernel of its own).  Four wavefronts of the 128-register kernel fill a SIMD's register
+// file; at 112 a wavefront of another stream's kernel (event detection, normalisation: <= 64
+// registers) still fits beside them.  Costs 4 spilled registers (main_dp 59.9 -> 64.1 ms at cfg2)
+// and wins when several engines stream on one device AND the DP is the smaller part of the work:
+// RNA 3 kb reads in -> results out 95.6 k -> 107.6 k reads/s, DNA 10 kb 95.5 k -> 88.4 k
+// (profiles/r04_k_dp_vgpr_budget_ab.txt) -- the engine picks per batch (tba_engine_set_sharing).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TBA_DP_WAVES), amdgpu_num_vgpr(56)))
+void k_dp8_lowreg(TBA_DP_ARGS)
 {
     dp_body<8, false>(TBA_DP_PASS);
 }
-#endif
 
 // Static whole-read DP (find_static_base_assignment, resquiggle.py:547-600 over
 // c_banded_forward_pass, pyx:240-279) for bands wider than the widest register class: a short
@@ -925,6 +927,7 @@ __global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const D
     if (ri >= n_reads) return;
     ReadState &r = rs[ri];
     r.moves_off = 0;
+    r.tb_done = 0;
     if (r.status != TBA_OK) return;
     const tba_params &P = dp->p;
     i64 *bst = band_starts + r.ref_off;
@@ -1059,6 +1062,7 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, cons
     ReadState &r = rs[ri];
     if (r.status != TBA_OK) return;
     if (r.path == PATH_NONE) { r.status = TBA_INTERNAL; return; }
+    if (r.tb_done) return;                              // walked chunk-parallel (k_tb_par.h)
     if (r.is_long && r.path == PATH_ADAPTIVE && r.W <= 1024) return; // k_main_tb_long (k_long.h)
     const i64 B = r.B;
     const int Wi = (int)r.W;

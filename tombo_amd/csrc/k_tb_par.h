@@ -1,0 +1,254 @@
+// k_tb_par.h -- the main traceback (c_banded_traceback, pyx:281-310), rows of one read walked by
+// several lanes at once.
+//
+// The walk is a pointer chase: the state entering row rr is the event position cur_ev, and what it
+// is on leaving depends on the move codes of that row only.  k_main_tb walks the B rows of a read
+// on one lane (10 000 dependent steps: 4.8 ms for a batch of 10 kb reads however few reads there
+// are; 49 ms for a 200 kb read).  Here a read is cut into chunks of rows with a lane each:
+//   phase A: the lane of chunk c walks the rows of its chunk, top to bottom, writing read_tb.
+//     Chunk 0 starts from the end of the forward pass (the true walk); a chunk c >= 1 starts at
+//     the MIDDLE of its top row's band (cell W / 2): the adaptive band is placed so that the best
+//     cell of the previous row sits there, and traceback paths that start near each other merge
+//     within a few rows (measured on synthetic 10 kb reads: median 1 row, maximum 12 from W / 2;
+//     from an end of the band 200-300 rows) -- so all but the first few rows of what the lane
+//     writes are the true path already, only nobody knows yet.
+//   phase B: the lane of chunk c walks on into chunk c + 1, compares its state after every row
+//     with what the lane below recorded for that row, overwrites where they differ and stops where
+//     they agree.  A walk is a deterministic function of its state, so from an agreement on the
+//     recorded path IS the continuation of this lane's path.
+//   chain (one lane per read): chunk 0 is the true walk; if its lane merged into chunk 1's
+//     record, that record is true from the merge row down, in particular where chunk 1's lane
+//     started ITS phase B, and so on down the read.  The result is the serial walk row for row,
+//     by induction, whatever the start cells were worth; a read whose chain breaks (a lane that
+//     finds no agreement inside the next chunk) is left to k_main_tb, untouched (never seen on
+//     synthetic reads: tests/test_gpu_parity.py asserts it through TBA_GET_TB_PARALLEL).
+// Errors of the serial walk are errors on the TRUE path only: those of chunk 0's phase A, of any
+// phase B, and of a chunk's phase A at or below the row where the lane above merged into it; phase
+// A therefore walks on through band-edge violations and records the lowest row that had one.  The
+// first error in walk order gives the status (a violation comes before the walk's death).
+// Integer work: bit-exact by construction.  tools/tb_par_model.py restates the scheme over the
+// oracle's move matrices (tests/test_tb_par_model.py, CPU); on the GPU every parity test compares
+// read_tb with the oracle's.
+#pragma once
+#include "k_dp.h"
+
+#define TBP_NONE ((i64)0x3fffffffffffffffll)
+#define TBP_WAVE_BELOW 1024 // batches up to this many reads: a wavefront per read (latency form)
+#define TBP_MIN_CHUNK 64    // rows; the overlap (phase B) is a block of 16 or two
+
+// One block of TBR rows of one walker: rows r0, r0 - 1, ... > stop, with the reference's rules
+// (negative band positions wrap like Python indices).  The fetch / bit-mask / clz scheme is
+// k_main_tb's (k_dp.h).
+//   EXT == false (phase A): every row writes tb; a band-edge violation is recorded (viol_lo = its
+//     row; rows descend, so the last one recorded is the lowest) and the walk goes on; leaving the
+//     band ends it (rc).
+//   EXT == true (phase B): before a row's value is written it is compared with what tb holds
+//     (rows >= cmp_lo only: below that the lane underneath wrote nothing); equal -> merged_row = that
+//     row, the walk ends; a violation ends it as well (rc), as in the serial walk.
+template <bool EXT>
+__device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int roww, const i64 *st,
+    int Wi, int thresh, i64 r0, i64 stop, i64 &cur_ev, int &bp_guess, int &rc, i64 *tb,
+    i64 &viol_lo, i64 cmp_lo, i64 &merged_row)
+{
+    i64 stv[TBR];
+    uint4 win[TBR];
+    i64 oldv[TBR];
+    int wb = (bp_guess >> 4) - 2;                   // first dword of the window
+    wb = wb < 0 ? 0 : (wb > roww - 4 ? roww - 4 : wb);
+#pragma unroll
+    for (int k = 0; k < TBR; k++) {
+        const i64 rr = r0 - k;
+        const i64 rc_ = rr >= 1 ? rr : 1;
+        stv[k] = st[rc_ - 1];
+        win[k] = *(const uint4 *)(mv + rc_ * rowb + 4 * wb);
+        if (EXT) oldv[k] = tb[rc_ - 1];
+    }
+    u64 nzl[TBR], nzh[TBR], d2l[TBR], d2h[TBR];
+    int fl_full[TBR], m2_full[TBR];
+#pragma unroll
+    for (int k = 0; k < TBR; k++) {
+        const u64 lo = ((u64)win[k].y << 32) | win[k].x, hi = ((u64)win[k].w << 32) | win[k].z;
+        const u64 E = 0x5555555555555555ull;
+        nzl[k] = (lo | (lo >> 1)) & E; nzh[k] = (hi | (hi >> 1)) & E;
+        d2l[k] = (lo >> 1) & ~lo & E;  d2h[k] = (hi >> 1) & ~hi & E;
+        const int cf = __clzll((long long)(nzl[k] | 1ull));
+        fl_full[k] = nzl[k] ? 31 - (cf >> 1) : -1;
+        m2_full[k] = (int)((d2l[k] >> (2 * (fl_full[k] & 31))) & 1ull);
+    }
+#pragma unroll
+    for (int k = 0; k < TBR; k++) {
+        const i64 rr = r0 - k;
+        const bool act = rr > stop && rr >= 1 && rc == TBA_OK && (!EXT || merged_row == TBP_NONE);
+        const i64 bp64 = cur_ev - stv[k];
+        int bp = (int)bp64;
+        const int lc = bp - 16 * wb;                // position inside the window
+        const bool in_win = bp64 < Wi && bp64 >= 0 && (unsigned)lc < 64u;
+        const bool up = (lc & 32) != 0;
+        const int amt = 62 - 2 * (lc & 31);
+        const u64 sn = (up ? nzh[k] : nzl[k]) << amt, s2 = (up ? d2h[k] : d2l[k]) << amt;
+        const bool hit = sn != 0;
+        const int c = __clzll((long long)(sn | 1ull)); // 1 + 2 (lc - f); 63 without a hit
+        const bool low = !hit && up && fl_full[k] >= 0;
+        const int m2_hit = (int)((s2 >> (63 - c)) & 1ull);
+        const int f = hit ? lc - (c >> 1) : fl_full[k];
+        const int m2 = hit ? m2_hit : m2_full[k];
+        const bool fast = in_win && (hit || low);
+        int m = m2 ? 2 : 1;
+        if (fast) bp = 16 * wb + f;
+        if (__builtin_expect(act && !fast, 0)) {
+            // outside the window, or nothing but stays down to its start
+            if (bp64 >= Wi || bp64 < -Wi) { rc = TBA_INTERNAL; continue; }
+            if (in_win) bp = wb > 0 ? 16 * wb - 1 : -1; // everything in the window was a stay
+            const unsigned char *row = mv + rr * rowb;
+            // the highest non-stay cell at or below bp, 32 cells (one aligned 8-byte load) at a time
+            m = 0;
+            while (bp >= 0) {
+                const u64 wd = *(const u64 *)(row + 8 * (bp >> 5));
+                const int top = bp & 31;
+                const u64 ms = top == 31 ? wd : (wd & ((1ull << (2 * top + 2)) - 1ull));
+                const u64 nz = (ms | (ms >> 1)) & 0x5555555555555555ull;
+                if (nz) {
+                    const int ff = (63 - __clzll((long long)nz)) >> 1;
+                    bp = 32 * (bp >> 5) + ff;
+                    m = (int)((wd >> (2 * ff)) & 3ull);
+                    break;
+                }
+                bp = 32 * (bp >> 5) - 1;
+            }
+            if (bp < 0) {
+                // the reference keeps walking through Python's wrap-around of a negative index
+#define MVG(b_) ({ int bb_ = (b_) < 0 ? (b_) + Wi : (b_); (int)((row[bb_ >> 2] >> (2 * (bb_ & 3))) & 3); })
+                m = MVG(bp);
+                while (m == 0) {
+                    bp--;
+                    if (bp < -Wi) { rc = TBA_INTERNAL; break; }
+                    m = MVG(bp);
+                }
+#undef MVG
+                if (rc != TBA_OK) continue;
+            }
+        }
+        if (m == 2) bp--;
+        const int edge = bp < Wi - bp - 1 ? bp : Wi - bp - 1;
+        const bool beyond = thresh >= 0 && edge < thresh;
+        if (act) {
+            if (EXT && beyond) rc = TBA_BEYOND_BANDWIDTH;
+            else {
+                if (!EXT && beyond) viol_lo = rr;
+                cur_ev = stv[k] + bp;
+                bp_guess = bp;
+                if (EXT && rr - 1 >= cmp_lo && oldv[k] == cur_ev + 1) merged_row = rr - 1;
+                else tb[rr - 1] = cur_ev + 1;
+            }
+        }
+    }
+}
+
+// LPR lanes per read (a power of two <= 64), 64 / LPR reads per wavefront.  idx != nullptr: the
+// reads are idx[0 .. n_reads) (the long reads: one wavefront each).  Reads this kernel finishes
+// are marked (ReadState.tb_done) and skipped by k_main_tb / k_main_tb_long.
+template <int LPR>
+__global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, const i32 *idx,
+    const DevParams *dp, const unsigned char *moves, const i64 *band_starts, i64 *read_tb)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x, g = lane / LPR, c = lane % LPR, gbase = g * LPR;
+    const i64 slot = (i64)blockIdx.x * RPW + g;
+    const bool have = slot < n_reads;
+    const i64 ri = have ? (idx ? (i64)idx[slot] : slot) : 0;
+    ReadState &r = rs[ri];
+    // every lane of the group takes the same decision here (same read)
+    const bool on = have && r.status == TBA_OK && r.path == PATH_ADAPTIVE && r.tb_done == 0 &&
+                    (idx != nullptr || !r.is_long) && r.B >= 2 && cpl_class(r.W) != 0;
+    const i64 B = on ? r.B : 2;
+    const int Wi = on ? (int)r.W : 64;
+    const int rowb = (int)mv_row_bytes(Wi), roww = rowb / 4;
+    const unsigned char *mv = moves + (on ? r.moves_off : 0);
+    const i64 *st = band_starts + (on ? r.ref_off : 0);
+    i64 *tb = read_tb + (on ? r.seg_off : 0);
+    const int thresh = (int)dp->p.band_bound_thresh;
+
+    // chunk c: rows (lo, hi], hi = B - c L; fewer chunks than lanes for short reads.  The rows of
+    // the static bands at the start of the read (masked start, resquiggle.py:607-683: the path is
+    // anywhere in those bands, not near their middle) all belong to the lowest chunk.
+    i64 top_rows = B - ((on ? r.n_static : 0) + 16);
+    top_rows = top_rows < 1 ? 1 : top_rows;
+    i64 L = (top_rows + LPR - 1) / LPR;
+    L = L < TBP_MIN_CHUNK ? TBP_MIN_CHUNK : L;
+    const int n_chunks = (int)((top_rows + L - 1) / L);
+    const i64 hi = B - (i64)c * L, lo = c >= n_chunks - 1 || hi - L < 0 ? 0 : hi - L;
+    const bool mine = on && c < n_chunks;
+    // ---- phase A
+    i64 cur = 0, viol_lo = TBP_NONE, none = TBP_NONE;
+    int guess = Wi / 2, rcA = TBA_OK;
+    if (mine) {
+        if (c == 0) { guess = (int)r.top_pos; cur = r.top_pos + st[B - 1]; tb[B] = cur + 1; }
+        else cur = st[hi - 1] + Wi / 2;
+    }
+    const i64 start_ev = cur;                       // my state entering row hi
+    {
+        i64 r0 = hi;
+        bool walking = mine;
+        while (__any(walking)) {
+            if (walking) {
+                tbp_block<false>(mv, rowb, roww, st, Wi, thresh, r0, lo, cur, guess, rcA, tb, viol_lo, 0, none);
+                r0 -= TBR;
+                if (rcA != TBA_OK || r0 <= lo) walking = false;
+            }
+        }
+    }
+    // the lowest tb index this lane wrote a value into: rows are written top-down and a walk that
+    // dies (rcA) stops writing, so without a death it is lo; after one, nothing below is known --
+    // the lane above then compares nothing in this chunk (cmp_lo above every row of it)
+    const i64 wrote_lo = rcA == TBA_OK ? lo : hi;
+    __threadfence_block(); // phase B reads what the lane below wrote
+    // ---- phase B: into chunk c + 1
+    const bool ext = mine && c + 1 < n_chunks && rcA == TBA_OK;
+    const i64 nxt_start = shfl_i64(start_ev, (lane + 1) & 63), nxt_wrote_lo = shfl_i64(wrote_lo, (lane + 1) & 63);
+    const i64 lo2 = c + 1 >= n_chunks - 1 || lo - L < 0 ? 0 : lo - L; // lo of chunk c + 1
+    i64 merged_row = TBP_NONE;
+    int rcB = TBA_OK;
+    {
+        bool walking = ext;
+        if (ext && cur == nxt_start) { merged_row = lo; walking = false; } // (entering row lo = its hi)
+        i64 r0 = lo;
+        while (__any(walking)) {
+            if (walking) {
+                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rcB, tb, viol_lo, nxt_wrote_lo, merged_row);
+                r0 -= TBR;
+                if (rcB != TBA_OK || merged_row != TBP_NONE || r0 <= lo2) walking = false;
+            }
+        }
+    }
+    // ---- the chain, top down (uniform over the group: every lane runs the same loop)
+    int status = TBA_OK;
+    bool broken = false;
+    i64 true_from = B + 1;                          // chunk 0: all of phase A is the true walk
+    for (int j = 0; j < LPR; j++) {
+        const i64 vj = shfl_i64(viol_lo, gbase + j), mj = shfl_i64(merged_row, gbase + j);
+        const int aj = __shfl(rcA, gbase + j, 64), bj = __shfl(rcB, gbase + j, 64);
+        if (j >= n_chunks || status != TBA_OK || broken) continue;
+        if (vj != TBP_NONE && vj <= true_from) { status = TBA_BEYOND_BANDWIDTH; continue; }
+        if (aj != TBA_OK) { status = aj; continue; }
+        if (j == n_chunks - 1) continue;            // walked down to row 1: done
+        if (bj != TBA_OK) { status = bj; continue; }
+        if (mj == TBP_NONE) { broken = true; continue; }
+        true_from = mj;
+    }
+    __threadfence_block(); // the lanes' read_tb entries, before lane 0 of the group reads them back
+    if (!on || c != 0 || broken) return;            // (broken: k_main_tb walks this read)
+    r.tb_done = 1;
+    if (status != TBA_OK) { r.status = status; return; }
+    // _trim_traceback (resquiggle.py:754-764) and the first base's change point, as k_main_tb
+    const i64 n_ev = r.n_ev - r.clip;
+    volatile i64 *vtb = tb;
+    {
+        i64 i = 0;
+        while (vtb[i] < 0) { vtb[i] = 0; i++; if (i > B) { r.status = TBA_INTERNAL; return; } }
+        i64 j = 1;
+        while (vtb[B + 1 - j] > n_ev) { vtb[B + 1 - j] = n_ev; j++; if (j > B + 1) { r.status = TBA_INTERNAL; return; } }
+    }
+    i64 t0 = vtb[0];
+    if (t0 < 0) t0 += n_ev + 1;
+    r.top_pos = t0;
+}

@@ -51,7 +51,8 @@ struct ReadState {
     i32 n_start_calls, changed, pad0;
     i32 is_long;              // more than TBA_LONG_RAW samples or TBA_LONG_BASES bases (k_long.h)
     double shift, scale, lower, upper; // scale values in force after segment_signal
-    i32 has_lims, pad2;
+    i32 has_lims;
+    i32 tb_done;              // the main traceback of this read is finished (k_tb_par.h)
     i64 n_cpts, n_ev;
     double start_res[4];      // (loc, events_per_base) of start-discovery call 0 / 1
     i64 mapped_start; double epb;

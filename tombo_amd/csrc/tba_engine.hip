@@ -6,6 +6,7 @@
 #include "k_segment.h"
 #include "k_prep_raw.h"
 #include "k_dp.h"
+#include "k_tb_par.h"
 #include "k_dp_multi.h"
 #include "k_long.h"
 #include "k_dp_wg.h"
@@ -95,6 +96,7 @@ struct tba_engine {
     bool any_stall = false, have_samp = false, have_sv = false;
     std::vector<i64> ne_override; // per-read num_events for the next upload (stepwise API)
     double algo_bytes = 0, dp_cells = 0;
+    int n_sharing = 1;            // engines fed concurrently on this device (tba_engine_set_sharing)
     int raw_dtype = TBA_RAW_F64;
     PinBuf h_rs, h_dp;            // ReadState[n] / DevParams as uploaded (pinned)
     DevBuf d_res, d_segs32;       // packed results of tba_batch_download_async
@@ -499,15 +501,26 @@ extern "C" int tba_set_num_events(tba_engine *e, const int64_t *num_events, int6
     return 0;
 }
 
+// k_dp<8> or its 112-register build (k_dp.h): the latter when other engines run their kernels beside
+// this one (streaming slots) and the batch has more than 0.04 samples per DP cell, i.e. event
+// detection and normalisation, not the DP, are most of the work (RNA 3 kb: 0.087, DNA 10 kb: 0.018)
+static bool dp_lowreg(const tba_engine *e)
+{
+    return e->n_sharing > 1 && e->dp_cells > 0 && (double)e->S_tot > 0.04 * e->dp_cells;
+}
 template <int CPL>
 static void launch_dp_t(tba_engine *e, int mode)
 {
-    k_dp<CPL, false><<<dim3((unsigned)e->n_reads), dim3(64), 0, e->stream>>>(
-        e->d_rs.as<ReadState>(), e->d_dp.as<DevParams>(), mode, e->d_evm.as<double>(),
-        e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), e->d_lo.as<i32>(),
-        e->d_hi.as<i32>(),
-        mode == DP_MAIN ? e->d_moves.as<unsigned char>() : e->d_smoves.as<unsigned char>(),
-        e->start_moves_stride, e->d_lastrow.as<double>(), nullptr);
+#define DP_LAUNCH_ARGS e->d_rs.as<ReadState>(), e->d_dp.as<DevParams>(), mode, e->d_evm.as<double>(), \
+        e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), e->d_lo.as<i32>(), \
+        e->d_hi.as<i32>(), \
+        mode == DP_MAIN ? e->d_moves.as<unsigned char>() : e->d_smoves.as<unsigned char>(), \
+        e->start_moves_stride, e->d_lastrow.as<double>(), nullptr
+    if (CPL == 8 && mode == DP_MAIN && dp_lowreg(e))
+        k_dp8_lowreg<<<dim3((unsigned)e->n_reads), dim3(64), 0, e->stream>>>(DP_LAUNCH_ARGS);
+    else
+        k_dp<CPL, false><<<dim3((unsigned)e->n_reads), dim3(64), 0, e->stream>>>(DP_LAUNCH_ARGS);
+#undef DP_LAUNCH_ARGS
 }
 template <int CPL, int RPW>
 static void launch_dp_multi_t(tba_engine *e)
@@ -658,6 +671,14 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 10 main tb
     if (ON(TBA_STAGE_ASSIGN)) {
+#ifndef TBA_NO_TB_PAR
+        // rows of a read over several lanes (k_tb_par.h): 16 lanes per read when the reads fill the
+        // machine, a wavefront per read for small batches and for the long reads; what it leaves
+        // (static bands, failed verification) is walked by the lane-per-read kernels below
+        if (n > TBP_WAVE_BELOW) k_main_tb_par<16><<<(unsigned)((n + 3) / 4), 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        else k_main_tb_par<64><<<nb, 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        if (e->n_long > 0 && n > TBP_WAVE_BELOW) k_main_tb_par<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+#endif
         k_main_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         if (e->n_long > 0) k_main_tb_long<<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         k_tb_gather<<<dim3(gB, nb), 256, 0, s>>>(rs, e->d_cpts.as<i64>(), e->d_readtb.as<i64>(), e->d_dpsegs.as<i64>());
@@ -946,6 +967,11 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
     if (what == TBA_GET_STATUS) {
         if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
         for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].status;
+        return 0;
+    }
+    if (what == TBA_GET_TB_PARALLEL) {
+        if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].tb_done;
         return 0;
     }
     if (what == TBA_GET_N_CPTS || what == TBA_GET_DP_READ_START || what == TBA_GET_N_STALL ||
@@ -1713,13 +1739,15 @@ extern "C" int tba_pack_reads(int64_t n_reads, const void *const *raw_ptrs, int 
         return set_err(TBA_E_ARG, "bad arguments");
     if (raw_dtype < TBA_RAW_F64 || raw_dtype > TBA_RAW_I16) return set_err(TBA_E_ARG, "unknown raw dtype");
     const size_t eb = raw_elem_bytes(raw_dtype);
-    static unsigned char code[256];
-    static bool have_code = false;
-    if (!have_code) { // ACGT -> 0..3, anything else 255 (the engine reports TBA_INVALID_SEQ)
-        for (int i = 0; i < 256; i++) code[i] = 255;
-        code[(int)'A'] = 0; code[(int)'C'] = 1; code[(int)'G'] = 2; code[(int)'T'] = 3;
-        have_code = true;
-    }
+    // ACGT -> 0..3, anything else 255 (the engine reports TBA_INVALID_SEQ).  A function-local static
+    // with an initialiser is built once under the C++11 guard: callers pack from several threads
+    // (ctypes releases the GIL; ReadFeeder.prefetch runs on a helper thread).
+    struct CodeTable {
+        unsigned char c[256];
+        CodeTable() { for (int i = 0; i < 256; i++) c[i] = 255; c[(int)'A'] = 0; c[(int)'C'] = 1; c[(int)'G'] = 2; c[(int)'T'] = 3; }
+    };
+    static const CodeTable table;
+    const unsigned char *code = table.c;
     auto work = [&](i64 a, i64 b) {
         for (i64 i = a; i < b; i++) {
             const i64 n = raw_off[i + 1] - raw_off[i], m = seq_off[i + 1] - seq_off[i];
@@ -1758,6 +1786,7 @@ extern "C" int tba_abi_sizes(int64_t *out, int64_t n)
     if (!out || n < 3) return set_err(TBA_E_ARG, "bad arguments");
     out[0] = (int64_t)sizeof(tba_params); out[1] = (int64_t)sizeof(tba_opts);
     out[2] = (int64_t)sizeof(tba_read_result);
+    if (n >= 4) out[3] = TBA_ABI_VERSION;
     return 0;
 }
 
@@ -1787,6 +1816,13 @@ extern "C" int tba_unpack_reads(int64_t n_reads, const void *src, int64_t elem_b
         a = b;
     }
     for (auto &x : th) x.join();
+    return 0;
+}
+
+extern "C" int tba_engine_set_sharing(tba_engine *e, int n_engines)
+{
+    if (!e || n_engines < 1) return set_err(TBA_E_ARG, "bad arguments");
+    e->n_sharing = n_engines;
     return 0;
 }
 

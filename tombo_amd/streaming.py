@@ -67,21 +67,18 @@ class ReadBatch(object):
             raw[raw_off[i]:raw_off[i + 1]] = raws[i]
             seq[seq_off[i]:seq_off[i + 1]] = seqs[i]
         si = None
-        if samp_inds is not None and any(s is None and len(q) > MAX_POINTS_FOR_THEIL_SEN + 16
-                                         for s, q in zip(samp_inds, seqs)):
-            # (zero-filled rows would fit a line through base 0 a thousand times: a silently
-            # wrong scale; the engine cannot tell a missing subsample from a given one)
-            raise ValueError('samp_inds has no entry for a read longer than %d bases; pass one per '
-                             'long read, or None for all and subsample_seed to the pipeline' %
-                             MAX_POINTS_FOR_THEIL_SEN)
         if samp_inds is not None and any(s is not None for s in samp_inds):
+            # A read of more than 1000 bases (len(seq) - kmer_width + 1: the engine knows K, this
+            # function does not) needs its row.  Rows without one are poisoned with -1: the kernel
+            # rejects a negative index (TBA_INTERNAL for that read) instead of fitting a line
+            # through whatever the row held -- it cannot tell a missing subsample from a given one.
             if pinned:
                 psi = _native.PinnedArray((n, 1000), np.int64)
                 keep.append(psi)
                 si = psi.a
-                si[:] = 0
+                si[:] = -1
             else:
-                si = np.zeros((n, 1000), np.int64)
+                si = np.full((n, 1000), -1, np.int64)
             for i, s in enumerate(samp_inds):
                 if s is not None:
                     si[i] = s
@@ -162,6 +159,7 @@ class StreamPipeline(object):
         self.slots = [_Slot(device) for _ in range(max(1, int(n_slots)))]
         for s in self.slots:
             s.eng.ensure_model(std_ref)
+            s.eng.set_sharing(len(self.slots))
         self.params = _native.make_params(rsqgl_params)
         self.opts = _native.make_opts(
             outlier_thresh=outlier_thresh, const_scale=const_scale,
@@ -230,6 +228,14 @@ class StreamPipeline(object):
             # (on the device this is the generic TBA_INTERNAL status of every long read; say it here)
             raise ValueError('batch %r has reads longer than %d bases but no Theil-Sen subsamples: pass '
                              'samp_inds, or subsample_seed to the pipeline' % (batch.tag, MAX_POINTS_FOR_THEIL_SEN))
+        if batch.samp_ind is not None and self.subsample_seed is None and not self.opts.skip_seq_scaling:
+            # per read, with the model's k-mer width: a read of more than 1000 bases whose row was
+            # left without a subsample (poisoned with -1 by from_lists / ReadFeeder.pack)
+            n_bases = np.diff(batch.seq_off) - (slot.eng.kmer_width or 1) + 1
+            si0 = np.asarray(batch.samp_ind).reshape(batch.n, -1)[:, 0]
+            if np.any((n_bases > MAX_POINTS_FOR_THEIL_SEN) & (si0 < 0)):
+                raise ValueError('batch %r: no Theil-Sen subsample for a read longer than %d bases' %
+                                 (batch.tag, MAX_POINTS_FOR_THEIL_SEN))
         done = self._finish(slot) if slot.pending is not None else None
         self._seq += 1
         slot.seq = self._seq
@@ -326,21 +332,26 @@ class ReadFeeder(object):
     def pack(self, raws, seqs, samp_inds=None, stalls=None, tag=None):
         """one batch, packed now; seqs: str / bytes of ACGT"""
         k = self._take_stage()
-        stage = self.stages[k]
-        raw, raw_off, seq, seq_off, _ = _native.pack_reads(
-            raws, seqs, reverse=self.reverse, stage=stage, n_threads=self.n_threads)
-        si = None
-        if samp_inds is not None:
-            n = len(raws)
-            si = stage.get('si', n * MAX_POINTS_FOR_THEIL_SEN, np.int64).reshape(n, MAX_POINTS_FOR_THEIL_SEN)
-            for i, s in enumerate(samp_inds):
-                if s is not None:
-                    si[i] = s
-                elif len(seqs[i]) > MAX_POINTS_FOR_THEIL_SEN + 16:
-                    raise ValueError('no Theil-Sen subsample for a read longer than %d bases' %
-                                     MAX_POINTS_FOR_THEIL_SEN)
-        st, sto = _native.pack_stalls(stalls) if stalls is not None and \
-            any(s is not None and len(s) for s in stalls) else (None, None)
+        try:
+            stage = self.stages[k]
+            raw, raw_off, seq, seq_off, _ = _native.pack_reads(
+                raws, seqs, reverse=self.reverse, stage=stage, n_threads=self.n_threads)
+            si = None
+            if samp_inds is not None:
+                n = len(raws)
+                si = stage.get('si', n * MAX_POINTS_FOR_THEIL_SEN, np.int64).reshape(n, MAX_POINTS_FOR_THEIL_SEN)
+                for i, s in enumerate(samp_inds):
+                    if s is not None:
+                        si[i] = s
+                    else:
+                        # the staging buffer is reused: a row without a subsample must not keep an
+                        # earlier batch's indices (the kernel rejects -1, see ReadBatch.from_lists)
+                        si[i] = -1
+            st, sto = _native.pack_stalls(stalls) if stalls is not None and \
+                any(s is not None and len(s) for s in stalls) else (None, None)
+        except BaseException:
+            self._release_stage(k)  # (a failed pack must not leave the staging set busy for good)
+            raise
         b = ReadBatch(raw, raw_off, seq, seq_off, si, st, sto, tag)
         b.release = lambda: self._release_stage(k)
         return b
