@@ -244,6 +244,11 @@ enum {
                                  drawn under tba_opts.device_subsample; reads of <= 1000 bases: unused) */
     TBA_GET_TB_PARALLEL = 24, /* int32[n]: 1 where the chunk-parallel traceback walked the read (performance
                                * diagnostics: 0 on an adaptive read means the lane-per-read walk had to) */
+    TBA_GET_ED_FUSED = 25,    /* int32[n]: 1 where the score-free event detection (k_detect / k_pick) finished the
+                               * read, 0 where the kernels that keep the score array had to (diagnostics) */
+    TBA_GET_ED_TAKEN_POS = 26, /* int32, two slots per sample (CSR by 2 * raw_off): positions of the taken list k_detect
+                                * left, valid right after stage TBA_STAGE_SEGMENT only (later stages reuse the buffer) */
+    TBA_GET_ED_N_TAKEN = 27,  /* int64[n]: its length per read */
     TBA_GET_DEBUG_COUNTERS = 99 /* int64[n][8]: ReadState.dbg, only filled by -DTBA_PHASE_DEBUG /
                                    -DTBA_SWEEP_STATS profiling builds (zeros otherwise) */
 };

@@ -291,6 +291,8 @@ def test_full_size_reads_vs_oracle_on_gpu():
     done, path = eng.get(_native.GET_TB_PARALLEL), eng.get(_native.GET_PATH)[:, 0]
     assert np.all(done[path == 1] == 1), 'reads left to the lane-per-read traceback: %r' % (
         np.flatnonzero((path == 1) & (done != 1)).tolist(),)
+    # ... and the score-free event detection (k_detect.h) must have finished all of them
+    assert np.all(eng.get(_native.GET_ED_FUSED) == 1)
 
 
 def test_long_reads_vs_oracle_on_gpu():

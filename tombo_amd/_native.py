@@ -82,7 +82,7 @@ RAW_DTYPES = {np.dtype(np.float64): RAW_F64, np.dtype(np.float32): RAW_F32,
 GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START, \
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
     GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL, \
-    GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND, GET_TB_PARALLEL = range(1, 25)
+    GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND, GET_TB_PARALLEL, GET_ED_FUSED, GET_ED_TAKEN_POS, GET_ED_N_TAKEN = range(1, 28)
 GET_DEBUG_COUNTERS = 99  # ReadState.dbg of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS profiling build
 STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, STAGE_SKIP, \
     STAGE_RESCALE = range(7)
@@ -430,7 +430,8 @@ class Engine(object):
             GET_STATUS: (np.int32, n), GET_START_FAIL: (np.int32, n),
             GET_N_STALL: (np.int64, n), GET_STALL_OFF: (np.int64, n),
             GET_SAMP_IND: (np.int64, (n, 1000)),
-            GET_TB_PARALLEL: (np.int32, n),
+            GET_TB_PARALLEL: (np.int32, n), GET_ED_FUSED: (np.int32, n),
+            GET_ED_TAKEN_POS: (np.int32, 2 * self.n_raw_total), GET_ED_N_TAKEN: (np.int64, n),
         }
         if what in (GET_VALID_CPTS, GET_EVENT_MEANS):
             out = np.zeros(max(int(self.ev_off[-1]), 1),

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_normalize(ReadState *rs, const De
                 double ds[WS_PER];
 #pragma unroll
                 for (int q = 0; q < WS_PER; q++) ds[q] = of(samp[q]);
-                done = block_median_window(val, n, ds, y, n, &sm, &a_lo, &a_hi);
+                done = block_median_window<2>(x, of, n, ds, y, n, &sm, &a_lo, &a_hi);
                 if (done) res = (n & 1) ? a_lo : (a_lo + a_hi) / 2.0;
                 __syncthreads();
             }
@@ -158,13 +158,12 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_normalize(ReadState *rs, const De
     if (write_norm) {
         if (have_lims) {
             // c_apply_outlier_thresh, _c_helper.pyx:73-87
-            block_stream<4>(n, [&](i64 i) { return x[i]; }, [&](i64 i, double xv) {
+            block_map2<2>(n, x, y, [&](double xv) {
                 const double v = (xv - shift) / scale;
-                y[i] = v > hi ? hi : (v < lo ? lo : v);
+                return v > hi ? hi : (v < lo ? lo : v);
             });
         } else {
-            block_stream<4>(n, [&](i64 i) { return x[i]; },
-                            [&](i64 i, double xv) { y[i] = (xv - shift) / scale; });
+            block_map2<2>(n, x, y, [&](double xv) { return (xv - shift) / scale; });
         }
     }
     TBA_PHASE(2, 4);
@@ -252,9 +251,10 @@ __host__ inline int cs_reads_for(i64 n_reads)
 // MODE 1 (identify_stalls, tombo_stats.py:277: np.cumsum(all_raw_signal)): the same pipeline over
 // the RAW samples (any boundary type, widened exactly), and what the store step writes is the
 // cumulative sum itself: score[raw_off + read + k] = sum of the first k samples, k = 0..n_raw.
+// only_flagged: the reads k_detect / k_pick (k_detect.h) left to this kernel (ReadState.ed_flag).
 template <int CS_READS, class RT = double, int MODE = 0>
 __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 n_reads,
-    const DevParams *dp, const RT *__restrict__ norm, double *__restrict__ score)
+    const DevParams *dp, const RT *__restrict__ norm, double *__restrict__ score, int only_flagged = 0)
 {
     // half rows per loader wave: 3 x CS_UNITS >= 2 x CS_READS, even so halves pair up
     constexpr int CS_UNITS = (((2 * CS_READS + 2) / 3) + 1) & ~1;
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void k_cumsum_scores(const ReadState *rs, i64 
     if (tid < CS_READS) {
         const i64 ri = r0 + tid;
         // (long reads have a workgroup of their own: k_cumsum_scores_long, k_long.h)
-        const bool live = ri < n_reads && rs[ri].status == TBA_OK && !rs[ri].is_long;
+        const bool live = ri < n_reads && rs[ri].status == TBA_OK && !rs[ri].is_long &&
+                          (!only_flagged || rs[ri].ed_flag);
         s_off[tid] = live ? rs[ri].raw_off : 0;
         s_n[tid] = live ? rs[ri].n_raw : 0;
         if (MODE == 1 && live) score[rs[ri].raw_off + ri] = 0.0; // c[0]
@@ -683,7 +684,8 @@ __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *de
 // registers); 0: any radius, everything through the global rounds.
 template <int RT>
 __global__ __launch_bounds__(SEL_NT, 4) void k_peaks(ReadState *rs, const DevParams *dp,
-    const double *score, unsigned char *state, double *dense, i64 *valid_cpts, int ttest)
+    const double *score, unsigned char *state, double *dense, i64 *valid_cpts, int ttest,
+    int only_flagged = 0)
 {
     __shared__ BucketSmem sm;
     __shared__ i64 s_w[SEL_NT / 64];
@@ -691,6 +693,7 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_peaks(ReadState *rs, const DevPar
     __shared__ u32 s_ndense;
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK) return;
+    if (only_flagged && !r.ed_flag) return; // k_detect / k_pick (k_detect.h) finished this read
     const int tid = threadIdx.x;
     const i64 w = dp->p.running_stat_width, m = dp->p.min_obs_per_base;
     const i64 ns = ttest ? r.n_raw - 2 * w : r.n_raw + 1 - 2 * w;

@@ -27,27 +27,83 @@ __device__ __forceinline__ void block_stream(i64 n, Load load, Body body)
     for (i64 i = base + tid; i < n; i += nt) body(i, load(i));
 }
 
-// wave_stage: a wavefront copies x[lo .. lo + span), span <= 64 * NLD, into its LDS slice as
-// f(index, value); all loads of a lane go out before the first value is used (uniform branches:
-// span is made an SGPR).
-template <int NLD, class Sig, class F>
-__device__ __forceinline__ void wave_stage(Sig x, i64 lo, i64 span, double *lds, F f)
+// block_stream2: the same pass with two consecutive elements per access (sig_pair: 16 bytes per
+// lane for float64); body(i, value) for every i, the odd last element by thread 0.
+template <int U, class Sig, class Body>
+__device__ __forceinline__ void block_stream2(i64 n, Sig x, Body body)
+{
+    const i64 tid = threadIdx.x, nt = blockDim.x, np = n >> 1;
+    i64 base = 0;
+    for (; base + (i64)U * nt <= np; base += (i64)U * nt) {
+        double a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) sig_pair(x, 2 * (base + (i64)u * nt + tid), a[u], b[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const i64 i = 2 * (base + (i64)u * nt + tid);
+            body(i, a[u]); body(i + 1, b[u]);
+        }
+    }
+    for (i64 j = base + tid; j < np; j += nt) {
+        double a, b;
+        sig_pair(x, 2 * j, a, b);
+        body(2 * j, a); body(2 * j + 1, b);
+    }
+    if ((n & 1) && tid == 0) body(n - 1, x[n - 1]);
+}
+// ... and with the results written back pairwise: out[i] = f(x[i]) (16-byte stores)
+template <int U, class Sig, class F>
+__device__ __forceinline__ void block_map2(i64 n, Sig x, double *out, F f)
+{
+    const i64 tid = threadIdx.x, nt = blockDim.x, np = n >> 1;
+    i64 base = 0;
+    for (; base + (i64)U * nt <= np; base += (i64)U * nt) {
+        double a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) sig_pair(x, 2 * (base + (i64)u * nt + tid), a[u], b[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) st2(out + 2 * (base + (i64)u * nt + tid), f(a[u]), f(b[u]));
+    }
+    for (i64 j = base + tid; j < np; j += nt) {
+        double a, b;
+        sig_pair(x, 2 * j, a, b);
+        st2(out + 2 * j, f(a), f(b));
+    }
+    if ((n & 1) && tid == 0) out[n - 1] = f(x[n - 1]);
+}
+
+// wave_stage: a wavefront copies x[lo .. lo + span), span <= 128 * NP, into its LDS slice as
+// f(value) -- and, with out != nullptr, to out[lo ..] as well -- two consecutive elements per lane
+// and access (16-byte loads and stores); all loads of a lane go out before the first value is used
+// (uniform branches: span is made an SGPR).  The pair that straddles the end of an odd span reads
+// one element past it: every signal buffer of the engine carries a few bytes of slack for that.
+template <int NP, class Sig, class F>
+__device__ __forceinline__ void wave_stage(Sig x, i64 lo, i64 span, double *lds, double *out, F f)
 {
     const int lane = threadIdx.x & 63;
     const int spn = __builtin_amdgcn_readfirstlane((int)span);
-    double v[NLD];
+    double a[NP], b[NP];
 #pragma unroll
-    for (int u = 0; u < NLD; u++) {
-        if (64 * u < spn) {
-            const int k = lane + 64 * u;
-            v[u] = x[lo + (k < spn ? k : spn - 1)];
+    for (int u = 0; u < NP; u++) {
+        if (128 * u < spn) {
+            int k = 2 * lane + 128 * u;
+            k = k < spn ? k : (spn - 1) & ~1;       // (lanes past the end re-read the last pair)
+            sig_pair(x, lo + k, a[u], b[u]);
         }
     }
 #pragma unroll
-    for (int u = 0; u < NLD; u++) {
-        if (64 * u < spn) {
-            const int k = lane + 64 * u;
-            if (k < spn) lds[k] = f(lo + k, v[u]);
+    for (int u = 0; u < NP; u++) {
+        if (128 * u < spn) {
+            const int k = 2 * lane + 128 * u;
+            if (k + 1 < spn) {
+                const double va = f(a[u]), vb = f(b[u]);
+                lds[k] = va; lds[k + 1] = vb;
+                if (out) st2(out + lo + k, va, vb);
+            } else if (k < spn) {
+                const double va = f(a[u]);
+                lds[k] = va;
+                if (out) out[lo + k] = va;
+            }
         }
     }
 }
@@ -479,8 +535,10 @@ __device__ double block_median_fast(F val, i64 n, double lo, double hi, BucketSm
                   // read; 16 per thread touch every line -- most of a pass -- for a window half
                   // as wide: 8.5 vs 6.5 ms on the 10k x 10 kb batch)
 #endif
-template <int WU = 4, class F> // WU: element loads in flight per thread during the pass
-__device__ __forceinline__ bool block_median_window(F val, i64 n, const double (&samp)[WS_PER], double *list,
+// The elements are of(x[i]), 0 <= i < n: x a signal (sig_pair: two consecutive samples per access),
+// of the value looked at (x itself, |x - shift|, ...).
+template <int WU = 4, class X, class OF> // WU: PAIR loads in flight per thread during the pass
+__device__ __forceinline__ bool block_median_window(X x, OF of, i64 n, const double (&samp)[WS_PER], double *list,
                                     i64 cap, BucketSmem *sm, double *lo_mid, double *hi_mid)
 {
     const int tid = threadIdx.x;
@@ -539,21 +597,27 @@ __device__ __forceinline__ bool block_median_window(F val, i64 n, const double (
     // the pass: count below the window, list the window (wave-aggregated append)
     i64 c_lo = 0;
     const int lane = tid & 63;
-    // (WU loads in flight per thread, one list-counter bump per WU * 64 elements)
-    for (i64 base = 0; base < n; base += (i64)WU * SEL_NT) {
-        double v[WU];
+    // (WU pair loads in flight per thread, one list-counter bump per 2 WU * 64 elements; the odd
+    // last element rides in the last pair slot of the pass)
+    const i64 np = (n + 1) >> 1;
+    for (i64 base = 0; base < np; base += (i64)WU * SEL_NT) {
+        double v[2 * WU];
+        bool okv[2 * WU];
 #pragma unroll
         for (int u = 0; u < WU; u++) {
-            const i64 i = base + (i64)u * SEL_NT + tid;
-            v[u] = val(i < n ? i : n - 1);
+            const i64 j = base + (i64)u * SEL_NT + tid;
+            const i64 i = 2 * j;
+            okv[2 * u] = i < n; okv[2 * u + 1] = i + 1 < n;
+            if (i + 1 < n) sig_pair(x, i, v[2 * u], v[2 * u + 1]);
+            else { v[2 * u] = x[i < n ? i : n - 1]; v[2 * u + 1] = v[2 * u]; }
         }
-        u64 m[WU];
+        u64 m[2 * WU];
         u32 tot = 0;
 #pragma unroll
-        for (int u = 0; u < WU; u++) {
-            const bool ok = base + (i64)u * SEL_NT + tid < n;
-            c_lo += ok && v[u] < t1;
-            m[u] = __ballot(ok && v[u] >= t1 && v[u] < t2);
+        for (int u = 0; u < 2 * WU; u++) {
+            v[u] = of(v[u]);
+            c_lo += okv[u] && v[u] < t1;
+            m[u] = __ballot(okv[u] && v[u] >= t1 && v[u] < t2);
             tot += (u32)__popcll(m[u]);
         }
         if (tot) {
@@ -561,7 +625,7 @@ __device__ __forceinline__ bool block_median_window(F val, i64 n, const double (
             if (lane == 0) b0 = atomicAdd(&s_nl, tot);
             b0 = __shfl(b0, 0, 64);
 #pragma unroll
-            for (int u = 0; u < WU; u++) {
+            for (int u = 0; u < 2 * WU; u++) {
                 const u32 pos = b0 + (u32)__popcll(m[u] & ((1ull << lane) - 1ull));
                 if (((m[u] >> lane) & 1ull) && pos < cap) list[pos] = v[u];
                 b0 += (u32)__popcll(m[u]);
@@ -752,7 +816,7 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
         double s = 0;
         if (span <= SEGW_CAP) {
             __builtin_amdgcn_wave_barrier(); // the previous group's lanes are done with the slice
-            wave_stage<(SEGW_CAP + 63) / 64>(x, lo, span, lds, [](i64, double v) { return v; });
+            wave_stage<(SEGW_CAP + 127) / 128>(x, lo, span, lds, nullptr, [](double v) { return v; });
             __builtin_amdgcn_wave_barrier();
             s = seq_sum_lds(lds, a - lo, b - lo);
         } else {

@@ -912,6 +912,11 @@ struct FinalSignal {
     double ca, cb;
     __device__ __forceinline__ double operator[](i64 i) const { return rescale ? (p[i] - ca) / cb : p[i]; }
 };
+__device__ __forceinline__ void sig_pair(FinalSignal x, i64 i, double &a, double &b)
+{
+    ld2(x.p + i, a, b);
+    if (x.rescale) { a = (a - x.ca) / x.cb; b = (b - x.ca) / x.cb; }
+}
 __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const DevParams *dp,
     const double *norm_out, const double *norm, const i64 *segs, double *means, double *stds)
 {
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const D
         const bool staged = span <= CAP;
         if (staged) {
             __builtin_amdgcn_wave_barrier();
-            wave_stage<CAP / 64>(x, lo, span, lds, [](i64, double xv) { return xv; });
+            wave_stage<CAP / 128>(x, lo, span, lds, nullptr, [](double xv) { return xv; });
             __builtin_amdgcn_wave_barrier();
         }
         const double len = (double)(b - a);
@@ -998,10 +1003,8 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
         double s = 0;
         if (span <= CAP) {
             __builtin_amdgcn_wave_barrier();
-            wave_stage<CAP / 64>(x, lo, span, lds, [&](i64 j, double xv) {
-                const double v = skip ? xv : (xv - ca) / cb; // resquiggle.py:1190
-                if (WRITE) y[j] = v;
-                return v;
+            wave_stage<CAP / 128>(x, lo, span, lds, WRITE ? y : nullptr, [&](double xv) {
+                return skip ? xv : (xv - ca) / cb; // resquiggle.py:1190
             });
             __builtin_amdgcn_wave_barrier();
             s = seq_sum_lds(lds, a - lo, b - lo);

@@ -53,6 +53,8 @@ struct ReadState {
     double shift, scale, lower, upper; // scale values in force after segment_signal
     i32 has_lims;
     i32 tb_done;              // the main traceback of this read is finished (k_tb_par.h)
+    i32 ed_flag, pad3;        // event detection: 1 = this read needs the kernels that keep the scores (k_detect.h)
+    i64 n_taken;              // entries of the taken (score, position) list k_detect left
     i64 n_cpts, n_ev;
     double start_res[4];      // (loc, events_per_base) of start-discovery call 0 / 1
     i64 mapped_start; double epb;
@@ -71,6 +73,27 @@ struct DevParams {
                         // resquiggle.py:665-668,678
 };
 
+// Two consecutive float64 as ONE 16-byte memory access at 8-byte alignment (global_load /
+// global_store_dwordx4 only need dword alignment on gfx9).  An 8-byte access per lane runs at
+// 0.54-0.70 x the rate of a 16-byte one (MI355X_MICROARCH.md), which is what held the streaming
+// kernels of this pipeline at 2.7-3.6 TB/s through round 3: every pass over a float64 signal
+// goes through these now.  Reads of a read's slice are ragged (8-byte aligned starts, odd
+// lengths): the callers handle the odd last element.
+typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef short i16x2_u __attribute__((ext_vector_type(2), aligned(2)));
+__device__ __forceinline__ void ld2(const double *p, double &a, double &b)
+{
+    const f64x2_u v = *(const f64x2_u *)p;
+    a = v.x; b = v.y;
+}
+__device__ __forceinline__ void st2(double *p, double a, double b)
+{
+    f64x2_u v;
+    v.x = a; v.y = b;
+    *(f64x2_u *)p = v;
+}
+
 // raw samples of one read as float64 (exact widening of float / int16 input)
 template <class RT>
 struct RawSamples {
@@ -78,6 +101,21 @@ struct RawSamples {
     __device__ __forceinline__ double operator[](i64 i) const { return (double)p[i]; }
     __device__ __forceinline__ RawSamples operator+(i64 k) const { return RawSamples{p + k}; }
 };
+// samples i and i + 1 of a signal in one access
+__device__ __forceinline__ void sig_pair(const double *x, i64 i, double &a, double &b) { ld2(x + i, a, b); }
+__device__ __forceinline__ void sig_pair(RawSamples<double> x, i64 i, double &a, double &b) { ld2(x.p + i, a, b); }
+__device__ __forceinline__ void sig_pair(RawSamples<float> x, i64 i, double &a, double &b)
+{
+    const f32x2_u v = *(const f32x2_u *)(x.p + i);
+    a = (double)v.x; b = (double)v.y;
+}
+__device__ __forceinline__ void sig_pair(RawSamples<int16_t> x, i64 i, double &a, double &b)
+{
+    const i16x2_u v = *(const i16x2_u *)(x.p + i);
+    a = (double)v.x; b = (double)v.y;
+}
+template <class Sig> // anything else that can be indexed (FinalSignal: rescaled on the fly)
+__device__ __forceinline__ void sig_pair(Sig x, i64 i, double &a, double &b) { a = x[i]; b = x[i + 1]; }
 
 // a / b for a row-constant divisor, bit-identical to IEEE division: y = RN(1/b) comes from one
 // true division per row, q0 = RN(a*y) is within 2 ulp, one residual correction makes it

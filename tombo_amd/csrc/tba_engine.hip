@@ -4,6 +4,7 @@
 #include "tba_common.h"
 #include "k_select.h"
 #include "k_segment.h"
+#include "k_detect.h"
 #include "k_prep_raw.h"
 #include "k_dp.h"
 #include "k_tb_par.h"
@@ -77,11 +78,11 @@ static const char *STAGE_NAMES[N_STAGE] = {
 // the DNA / RNA parameter sets, anything else takes the generic kernel
 static void launch_peaks(i64 min_obs_per_base, unsigned n_blocks, hipStream_t s, ReadState *rs,
                          const DevParams *dp, const double *score, unsigned char *state,
-                         double *dense, i64 *valid_cpts, int ttest)
+                         double *dense, i64 *valid_cpts, int ttest, int only_flagged = 0)
 {
-    if (min_obs_per_base - 1 == 2) k_peaks<2><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest);
-    else if (min_obs_per_base - 1 == 5) k_peaks<5><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest);
-    else k_peaks<0><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest);
+    if (min_obs_per_base - 1 == 2) k_peaks<2><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged);
+    else if (min_obs_per_base - 1 == 5) k_peaks<5><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged);
+    else k_peaks<0><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged);
 }
 struct tba_engine {
     int device = 0;
@@ -314,11 +315,12 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
 #define BUF(name_, bytes_) f(q ? &q->name_ : (DevBuf *)nullptr, (size_t)(bytes_))
     BUF(d_rs, N * sizeof(ReadState));
     BUF(d_dp, sizeof(DevParams));
-    BUF(d_raw, S * raw_elem_bytes(raw_dtype));
-    BUF(d_norm, S * 8);
-    if (!o->skip_norm_out) BUF(d_norm_out, S * 8);
-    BUF(d_csum, (S + N) * 8);
-    BUF(d_score, S * 8);
+    // (+ 64 bytes: the 16-byte accesses of a pass over a signal may touch the element past an odd end)
+    BUF(d_raw, S * raw_elem_bytes(raw_dtype) + 64);
+    BUF(d_norm, S * 8 + 64);
+    if (!o->skip_norm_out) BUF(d_norm_out, S * 8 + 64);
+    BUF(d_csum, (S + N) * 8 + 64);
+    BUF(d_score, S * 8 + 64);
     BUF(d_state, std::max(S, S / 8 + 8 * N + 64)); // (also the stall detector's bit words)
     BUF(d_cpts, Et * 8);
     BUF(d_evm, Et * 8);
@@ -608,11 +610,23 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     const bool fused_scores = 2 * P.running_stat_width <= 64; // cumsum + scores in one kernel
     if (ON(TBA_STAGE_SEGMENT) && !rna)
         RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0, 1)));
+    // DNA defaults: the scores never reach memory (k_detect.h); what that form leaves (flagged reads)
+    // goes through the kernels below as before
+#ifdef TBA_NO_FUSED_DETECT
+    const bool fused_detect = false;
+#else
+    const bool fused_detect = !rna && 2 * P.running_stat_width <= DT_W2MAX && P.min_obs_per_base == 3;
+#endif
+    const int only_flagged = fused_detect ? 1 : 0;
     MARK(); // 1 cumsum
     if (ON(TBA_STAGE_SEGMENT) && !rna) {
+        if (fused_detect) {
+            k_detect<2><<<(unsigned)((n + DT_READS - 1) / DT_READS), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_csum.as<double>(), e->d_score.as<double>());
+            k_pick<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>(), e->d_cpts.as<i64>());
+        }
         if (fused_scores) {
-            if (cs_reads_for(n) == 20) k_cumsum_scores<20><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
-            else k_cumsum_scores<32><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>());
+            if (cs_reads_for(n) == 20) k_cumsum_scores<20><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>(), only_flagged);
+            else k_cumsum_scores<32><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>(), only_flagged);
             if (e->n_long > 0) k_cumsum_scores_long<double, 0><<<(unsigned)e->n_long, 256, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_norm.as<double>(), e->d_score.as<double>());
         }
         else k_cumsum<<<tpr, 64, 0, s>>>(rs, n, e->d_norm.as<double>(), e->d_csum.as<double>());
@@ -624,7 +638,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 3 peaks
     if (ON(TBA_STAGE_SEGMENT)) {
-        launch_peaks(P.min_obs_per_base, nb, s, rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0);
+        launch_peaks(P.min_obs_per_base, nb, s, rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0, only_flagged);
         if (e->any_stall) k_remove_stalls<<<nb, SEL_NT, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>(), e->d_csum.as<double>());
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
             RAW_DISPATCH(rdt, (k_event_means<RT><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 1)));
@@ -940,6 +954,7 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
     case TBA_GET_VALID_CPTS: return copy(e->d_cpts, (size_t)e->E_tot * 8);
     case TBA_GET_EVENT_MEANS: return copy(e->d_evm, (size_t)e->E_tot * 8);
     case TBA_GET_SEG_NORM: return copy(e->d_norm, (size_t)e->S_tot * 8);
+    case TBA_GET_ED_TAKEN_POS: return copy(e->d_score, (size_t)e->S_tot * 8);
     case TBA_GET_BAND_STARTS: return copy(e->d_bst, (size_t)e->B_tot * 8);
     case TBA_GET_READ_TB: return copy(e->d_readtb, (size_t)(e->B_tot + e->n_reads) * 8);
     case TBA_GET_DP_SEGS: return copy(e->d_dpsegs, (size_t)(e->B_tot + e->n_reads) * 8);
@@ -969,9 +984,19 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
         for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].status;
         return 0;
     }
+    if (what == TBA_GET_ED_FUSED) {
+        if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].ed_flag ? 0 : 1;
+        return 0;
+    }
     if (what == TBA_GET_TB_PARALLEL) {
         if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
         for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].tb_done;
+        return 0;
+    }
+    if (what == TBA_GET_ED_N_TAKEN) {
+        if ((size_t)out_bytes < N * 8) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++) ((i64 *)out)[i] = rs[i].n_taken;
         return 0;
     }
     if (what == TBA_GET_N_CPTS || what == TBA_GET_DP_READ_START || what == TBA_GET_N_STALL ||

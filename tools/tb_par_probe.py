@@ -29,4 +29,5 @@ done, path, status = eng.get(_native.GET_TB_PARALLEL), eng.get(_native.GET_PATH)
 ms = eng.get(_native.GET_KERNEL_MS)
 print('reads', n, 'ok', int((status == 0).sum()), 'adaptive', int((path == 1).sum()),
       'walked chunk-parallel', int(done.sum()), 'left to the serial walk', np.flatnonzero((path == 1) & (done != 1))[:20].tolist())
+print('event detection without the score array finished', int(eng.get(_native.GET_ED_FUSED).sum()), 'of', n)
 print('stage ms', dict(zip(_native.STAGE_NAMES, [round(float(x), 3) for x in ms[:len(_native.STAGE_NAMES)]])))
