@@ -31,6 +31,13 @@
 #define DT_HSTRIDE (DT_W2MAX + 1)
 #define DT_CSTRIDE 33
 #define DT_MAX_ROUNDS 64
+// tile rows: column c of a 128-sample chunk sits at c + c / 32 (one pad per 32-slot word, + one
+// per row): the four words of a read that the greedy lanes walk in step start 66 dwords apart instead
+// of 64 -- on the same LDS bank every one of their reads was a 4-way conflict, and the LDS pipe,
+// shared by the whole CU, is what bounds a step (measured: 9.8 k of its 17 k cycles) -- and the
+// rows 266 dwords apart keep the scan's lane-per-read column walk conflict free
+#define DT_STRIDE 133
+#define DT_PC(c_) ((c_) + ((c_) >> 5))
 
 // bit i <- bit i + d of (next:cur);  bit i <- bit i - d of (cur:prev);  0 < d < 32
 __device__ __forceinline__ u32 dt_down(u32 cur, u32 next, int d) { return __builtin_amdgcn_alignbit(next, cur, d); }
@@ -44,18 +51,49 @@ __device__ __forceinline__ u32 dt_lane_above(u32 x) // lane l <- lane l + 1 (lan
     return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
 }
 
+// -DTBA_PHASE_DEBUG=7: cycles per role and part, summed over the steps, into dbg[] of the
+// workgroup's first read: 0 scan, 1 loader, 2 greedy (wave 2) = 3 masks + 4 rounds + 5 emission + 6 tail
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 7
+#define DT_T0() i64 dt_t_ = (i64)__builtin_readcyclecounter()
+#define DT_T(i_) do { const i64 n_ = (i64)__builtin_readcyclecounter(); if (lane == 0) dt_acc[i_] += n_ - dt_t_; dt_t_ = n_; } while (0)
+#else
+#define DT_T0() do { } while (0)
+#define DT_T(i_) do { } while (0)
+#endif
+// g <- 2 g + (|a| >= |b|): one compare into VCC, one add-with-carry (the C++ form is a compare, a
+// select and a shift-or)
+__device__ __forceinline__ u32 dt_shift_in_ge(u32 g, double a, double b)
+{
+    asm("v_cmp_ge_f64 vcc, |%1|, |%2|\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(g) : "v"(a), "v"(b) : "vcc");
+    return g;
+}
 template <int R>
 __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, const DevParams *dp,
     const double *__restrict__ norm, double *__restrict__ dense, double *__restrict__ posbuf)
 {
     static_assert(R >= 1 && R <= 8, "exclusion radius");
-    __shared__ double tile[3][DT_READS * CS_STRIDE];
-    __shared__ double halo[DT_READS * DT_HSTRIDE];   // row q: the 2w sums before the tile being scored
-    __shared__ double carry[2][DT_READS * DT_CSTRIDE]; // scores of the last word of the previous step
+    // one LDS array, so that every access of the greedy is smem[integer index]: a select between
+    // two __shared__ objects is compiled as a branch around two loads
+    constexpr int DT_TILE = DT_READS * DT_STRIDE;                 // doubles per tile buffer
+    constexpr int DT_HALO = 3 * DT_TILE;                          // row q: the 2w sums before the tile being scored
+    constexpr int DT_CARRY = DT_HALO + DT_READS * DT_HSTRIDE;     // [2][reads][33]: scores of the last word of the previous step
+    constexpr int DT_ZROW = DT_CARRY + 2 * DT_READS * DT_CSTRIDE; // 32 zeros (see the greedy's addressing)
+    __shared__ double smem[DT_ZROW + 32];
+    double *const halo = smem + DT_HALO;
+    double *const zrow = smem + DT_ZROW;
+#define DT_TILEP(b_) (smem + (b_) * DT_TILE)
     __shared__ i64 s_off[DT_READS], s_n[DT_READS];
     __shared__ u32 s_cnt[DT_READS];
     __shared__ int s_bad[DT_READS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // roles: 0 scan, 1 loader, 2 / 3 greedy.  Two workgroups share a CU, one wavefront of each per
+    // SIMD: with the roles rotated by two in every other workgroup a SIMD holds one of the two heavy
+    // (greedy) wavefronts and one light one instead of two heavy ones (TBA_DT_NO_ROTATE: A/B switch)
+#ifdef TBA_DT_NO_ROTATE
+    const int wave = tid >> 6;
+#else
+    const int wave = ((tid >> 6) + 2 * (int)(blockIdx.x & 1)) & 3;
+#endif
     const i64 r0 = (i64)blockIdx.x * DT_READS;
     const int w = (int)dp->p.running_stat_width, w2 = 2 * w;
     if (tid < DT_READS) {
@@ -69,6 +107,8 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
         if (ok && !live) { rs[ri].ed_flag = 1; rs[ri].n_taken = 0; } // long read: k_long.h + k_peaks
     }
     for (int k = tid; k < DT_READS * DT_HSTRIDE; k += 256) halo[k] = 0.0; // c[0] = 0, nothing before it
+    if (tid < 32) zrow[tid] = 0.0;
+    for (int k = tid; k < 2 * DT_READS * DT_CSTRIDE; k += 256) smem[DT_CARRY + k] = 0.0;
     __syncthreads();
     i64 n_max = 0;
     for (int q = 0; q < DT_READS; q++) n_max = s_n[q] > n_max ? s_n[q] : n_max;
@@ -86,15 +126,16 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
         }
     };
     auto drop = [&](double *t) {
+        const int pc = DT_PC(2 * lane);                // (2 lane and 2 lane + 1: same word)
 #pragma unroll
         for (int u = 0; u < DT_READS; u++) {
-            t[u * CS_STRIDE + 2 * lane] = pa[u];
-            t[u * CS_STRIDE + 2 * lane + 1] = pb[u];
+            t[u * DT_STRIDE + pc] = pa[u];
+            t[u * DT_STRIDE + pc + 1] = pb[u];
         }
     };
     // (fetch and drop of a tile sit inside ONE step, in the loader's branch: registers carried across
     // the steps would be held through the greedy branch as well, and the kernel has none to spare)
-    if (wave == 1) { fetch(0); drop(tile[0]); }
+    if (wave == 1) { fetch(0); drop(DT_TILEP(0)); }
     __syncthreads();
 
     // ---- wave 0: the scan (lane = read)
@@ -112,73 +153,112 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
 #pragma unroll
     for (int d = 0; d <= R; d++) prevX[d] = 0;
     int cb = 0;
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 7
+    i64 dt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     for (i64 i = 0; i <= n_steps + 1; i++) {
+        DT_T0();
         if (wave == 0) {
             if (i < n_steps && lane < DT_READS) {
-                double *row = tile[i % 3] + lane * CS_STRIDE;
+                double *row = DT_TILEP(i % 3) + lane * DT_STRIDE;
                 const i64 left = my_n - i * CS_CHUNK;
                 if (left >= CS_CHUNK) {
 #pragma unroll 16
-                    for (int k = 0; k < CS_CHUNK; k++) { acc = acc + row[k]; row[k] = acc; }
+                    for (int k = 0; k < CS_CHUNK; k++) { acc = acc + row[DT_PC(k)]; row[DT_PC(k)] = acc; }
                 } else {
                     for (int k = 0; k < CS_CHUNK; k++)
-                        if (k < left) { acc = acc + row[k]; row[k] = acc; }
+                        if (k < left) { acc = acc + row[DT_PC(k)]; row[DT_PC(k)] = acc; }
                 }
             }
+            DT_T(0);
         } else if (wave == 1) {
-            if (i + 1 < n_steps) { fetch(i + 1); drop(tile[(i + 1) % 3]); }
+            if (i + 1 < n_steps) { fetch(i + 1); drop(DT_TILEP((i + 1) % 3)); }
+            DT_T(1);
         } else if (i >= 1) {
             // tile j = i - 1: column t holds c[jC + 1 + t]; slot s = jC + t is the score whose window
             // ends there: position k = s + 1 - 2w, |2 c[k+w] - c[k] - c[k+2w]| (pyx:94-98) with
             // c[k+2w] = column t, c[k+w] = column t - w, c[k] = column t - 2w (negative: the halo)
             const i64 j = i - 1;
-            const double *trow = tile[j % 3] + (glane ? q : 0) * CS_STRIDE;
-            const double *hrow = halo + (glane ? q : 0) * DT_HSTRIDE;
-            const double *crow = carry[cb] + (glane ? q : 0) * DT_CSTRIDE;
-            double *cnext = carry[cb ^ 1] + (glane ? q : 0) * DT_CSTRIDE;
-            const i64 S0 = j * CS_CHUNK;
-            const i64 slot0 = S0 - 32 + 32 * h;       // first slot of my word
+            const int qz = glane ? q : 0;
+            const int it_row = (int)(j % 3) * DT_TILE + qz * DT_STRIDE;   // my read's row of the tile
+            const int ih_row = DT_HALO + qz * DT_HSTRIDE;                 // ... of the halo
+            const int ic_row = DT_CARRY + cb * DT_READS * DT_CSTRIDE + qz * DT_CSTRIDE;
+            const int ic_next = DT_CARRY + (cb ^ 1) * DT_READS * DT_CSTRIDE + qz * DT_CSTRIDE;
+            const double *trow = smem + it_row;
+            const int S0 = (int)j * CS_CHUNK;         // (slots fit 32 bits: TBA_LONG_RAW reads are not here)
+            const int slot0 = S0 - 32 + 32 * h;       // first slot of my word
             const int col0 = 32 * (h - 1);            // its column in the tile (h >= 1)
-            auto valid = [&](i64 s) { return glane && s >= w2 - 1 && s <= gn - 1; };
-            auto c_at = [&](int col) { return col >= 0 ? trow[col] : hrow[w2 + col]; };
-            auto score_at = [&](int t) { // slot of column t of the tile
-                const double cc = c_at(t), cbv = c_at(t - w), ca = c_at(t - w2);
-                return fabs(((2 * cbv) - ca) - cc);
+            const int gni = (int)gn;
+            auto valid = [&](int s) { return glane && s >= w2 - 1 && s <= gni - 1; };
+            // Addressing: the three sums of slot t sit at smem[ic + t], smem[ib + t'], smem[ia + t'']
+            // with per-lane bases.  Word 0 has its scores in the carry: it reads them as "c[k+2w]"
+            // against zeros for the other two sums, |(2*0 - 0) - s| = s.  Physical columns (DT_PC):
+            // my word's own columns carry h - 1 pads; a sum w / 2w columns back sits in the word
+            // below while t < w / 2w: one pad less (t' = t - 1), and for the first word of the tile
+            // that is the halo.  All selects are integer selects on the index (no branches).
+            const int pbase = col0 + (h - 1);
+            const int ic = h == 0 ? ic_row : it_row + pbase;
+            const int ib = h == 0 ? DT_ZROW : it_row + pbase - w;
+            const int ia = h == 0 ? DT_ZROW : it_row + pbase - w2;
+            const int ibl = h == 0 ? DT_ZROW : (h == 1 ? ih_row + w : ib - 1);  // base while t < w
+            const int ial = h == 0 ? DT_ZROW : (h == 1 ? ih_row : ia - 1);      // base while t < 2w
+            auto score_raw = [&](int t) {              // (2 c[k+w] - c[k]) - c[k+2w] of my slot t: the score up to its sign
+                const double cc = smem[ic + t], cbv = smem[(t < w ? ibl : ib) + t], ca = smem[(t < w2 ? ial : ia) + t];
+                return ((2 * cbv) - ca) - cc;
             };
-            u32 V = 0, G[R + 1];
-#pragma unroll
-            for (int d = 0; d <= R; d++) G[d] = 0;
-            double hist[R];                           // the last R scores
-            double first[R], last[R];
-#pragma unroll
-            for (int d = 0; d < R; d++) { hist[d] = 0.0; first[d] = 0.0; last[d] = 0.0; }
-#pragma unroll 1
-            for (int t8 = 0; t8 < 32; t8 += 8) {      // (eight positions' LDS reads in flight, not 32)
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int t = t8 + u;
-                    const double s = h == 0 ? crow[t] : score_at(col0 + t);
-                    const bool vt = valid(slot0 + t);
-                    V |= (vt ? 1u : 0u) << t;
-                    if (h == 4) cnext[t] = s;
-#pragma unroll
-                    for (int d = 1; d <= R; d++) {
-                        // pair (t - d, t): "the neighbour at +d outranks me" for position t - d
-                        // (ties fall to the higher index: >=)
-                        const bool b = t - d >= 0 && vt && ((V >> ((t - d) & 31)) & 1u) && s >= hist[d - 1];
-                        G[d] |= (b ? 1u : 0u) << ((t - d) & 31);
-                    }
-#pragma unroll
-                    for (int d = R - 1; d >= 1; d--) hist[d] = hist[d - 1];
-                    hist[0] = s;
-#pragma unroll
-                    for (int d = 0; d < R; d++) {
-                        if (t == d) first[d] = s;
-                        if (t == 32 - R + d) last[d] = s;
-                    }
+            // validity of my 32 slots: w2 - 1 <= slot <= gn - 1
+            u32 V = 0;
+            {
+                const int lo_t = w2 - 1 - slot0 > 0 ? w2 - 1 - slot0 : 0, hi_t = gni - 1 - slot0;
+                if (glane && hi_t >= lo_t && lo_t < 32) {
+                    const u32 up_to = hi_t >= 31 ? ~0u : ((2u << hi_t) - 1u);
+                    V = up_to & (~0u << lo_t);
                 }
             }
+            // G[d] bit p: the neighbour at p + d outranks p (ties fall to the higher index: >=).
+            // The compare of pair (t - d, t) is shifted in from the right as t walks up, so after 32
+            // slots it sits at bit 31 - t: reversed and moved down by d it is bit t - d.  Pairs that
+            // do not exist (t < d) fall off the top, invalid ends are masked.
+            u32 G[R + 1], acc_g[R + 1];
+#pragma unroll
+            for (int d = 0; d <= R; d++) { G[d] = 0; acc_g[d] = 0; }
+            double first[R], last[R], before[R];      // before: the R scores ahead of the current chunk
+#pragma unroll
+            for (int d = 0; d < R; d++) { first[d] = 0.0; last[d] = 0.0; before[d] = 0.0; }
+#pragma unroll
+            for (int t8 = 0; t8 < 32; t8 += 8) {      // eight slots' LDS reads in flight
+                double sc[8 + R];                      // sc[R + u] = score of slot t8 + u
+#pragma unroll
+                for (int d = 0; d < R; d++) sc[d] = before[d];
+                if (t8 >= w2) {                        // (no slot of the chunk reaches below its word: no selects)
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        sc[R + u] = ((2 * smem[ib + t8 + u]) - smem[ia + t8 + u]) - smem[ic + t8 + u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sc[R + u] = score_raw(t8 + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int d = 1; d <= R; d++) acc_g[d] = dt_shift_in_ge(acc_g[d], sc[R + u], sc[R + u - d]);
+                }
+                if (h == 4) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) smem[ic_next + t8 + u] = fabs(sc[R + u]);
+                }
+#pragma unroll
+                for (int d = 0; d < R; d++) before[d] = sc[8 + d];
+                if (t8 == 0) {
+#pragma unroll
+                    for (int d = 0; d < R; d++) first[d] = sc[R + d];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < R; d++) last[d] = before[d];
+#pragma unroll
+            for (int d = 1; d <= R; d++) G[d] = (__builtin_bitreverse32(acc_g[d]) >> d) & V & (V >> d);
             // pairs into the next word: its first R scores come from the lane above; the future
             // (beyond the last word) counts as outranking wherever it exists
 #pragma unroll
@@ -188,15 +268,15 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
 #pragma unroll
                 for (int d = k + 1; d <= R; d++) {
                     const int tp = 32 + k - d;        // my position of the pair, 32 - d .. 31
-                    const bool b = bv && ((V >> tp) & 1u) && (h == 4 || bs >= last[tp - (32 - R)]);
+                    const bool b = bv && ((V >> tp) & 1u) && (h == 4 || fabs(bs) >= fabs(last[tp - (32 - R)]));
                     G[d] |= (b ? 1u : 0u) << tp;
                 }
             }
             // neighbour words: inside the read by DPP, at its ends the carried context / the future
             u32 vfut = 0;                             // validity of the 32 slots after the last word
             {
-                const i64 f0 = S0 + 128;
-                const i64 lo_s = w2 - 1 > f0 ? w2 - 1 - f0 : 0, hi_s = gn - 1 - f0; // valid: lo_s <= t <= hi_s
+                const int f0 = S0 + 128;
+                const int lo_s = w2 - 1 > f0 ? w2 - 1 - f0 : 0, hi_s = gni - 1 - f0; // valid: lo_s <= t <= hi_s
                 if (glane && hi_s >= lo_s && lo_s < 32) {
                     const u32 up_to = hi_s >= 31 ? ~0u : ((2u << hi_s) - 1u);
                     vfut = up_to & (~0u << lo_s);
@@ -212,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
                 const u32 xb = dt_lane_below(X[d]);
                 Hm[d] = V & dt_up(X[d], h == 0 ? prevX[d] : xb, d); // the neighbour at -d outranks me
             }
+            DT_T(3);
             u32 T = 0, S = 0, U = V;
             for (int round = 0; round < DT_MAX_ROUNDS; round++) {
                 const u32 ta = dt_lane_above(T), tb = dt_lane_below(T);
@@ -228,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
                 T |= nT; S |= nS; U &= ~(nT | nS);
                 if (__ballot((nS | nT) != 0) == 0) break;
             }
+            DT_T(4);
             // words 0..3 are final now; an open position there means a chain longer than a word
             if (glane && h < 4 && U != 0) s_bad[q] = 1;
             // emission, in position order: what word 0 decided late, words 1..3, and what word 4
@@ -247,23 +329,33 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
             u32 o = base + (u32)(inc - ce);
             for (u32 m = glane ? E : 0u; m != 0; m &= m - 1u) {
                 const int t = __ffs((int)m) - 1;
-                const double s = h == 0 ? crow[t] : score_at(col0 + t);
+                const double s = fabs(score_raw(t));
                 dn[o] = s;
                 pn[o] = (i32)(slot0 + t - (w2 - 1));
                 o++;
             }
+            DT_T(5);
             // context of the next step: its word 0 is this step's word 4, below it word 3
             prevT = (u32)__shfl((int)T, (lane + 3) & 63, 64);
 #pragma unroll
             for (int d = 1; d <= R; d++) prevX[d] = (u32)__shfl((int)X[d], (lane + 3) & 63, 64);
             prev_emitted = (u32)__shfl((int)T, (lane + 4) & 63, 64);
             // the next tile's halo: the last 2w sums of this one
-            if (glane && h == 4 && j < n_steps)
-                for (int k = 0; k < w2; k++) halo[q * DT_HSTRIDE + k] = trow[CS_CHUNK - w2 + k];
+            if (glane && j < n_steps)                  // (the read's five lanes share the copy)
+                for (int k = h; k < w2; k += 5) smem[ih_row + k] = trow[CS_CHUNK - w2 + k + 3]; // (last word: 3 pads)
             cb ^= 1;
+            DT_T(6);
         }
         __syncthreads();
     }
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 7
+    if (lane == 0 && r0 < n_reads) {
+        i64 *dbg = rs[r0].dbg;
+        if (wave == 0) dbg[0] = dt_acc[0];
+        if (wave == 1) dbg[1] = dt_acc[1];
+        if (wave == 2) { dbg[2] = dt_acc[3] + dt_acc[4] + dt_acc[5] + dt_acc[6]; dbg[3] = dt_acc[3]; dbg[4] = dt_acc[4]; dbg[5] = dt_acc[5]; dbg[6] = dt_acc[6]; dbg[7] = n_steps; }
+    }
+#endif
     if (wave >= 2 && glane && h == 0 && gn > 0) {
         ReadState &r = rs[gri];
         r.n_taken = (i64)s_cnt[q];
