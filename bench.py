@@ -710,7 +710,9 @@ def main():
         # what _io_and_map_read hands the worker: the file's int16 samples (RNA: acquisition order)
         mrs = [mk(i, dacs[i]) for i in range(n_api)]
         eng = rq.get_engine(dev)
-        kw = dict(outlier_thresh=5.0, seq_samp_type=samp, engine=eng, reverse_raw=rna, stall_params=stall_params)
+        kw = dict(outlier_thresh=5.0, seq_samp_type=samp, reverse_raw=rna, stall_params=stall_params)
+        if dev != rq.default_device():
+            kw['engine'] = eng   # (an explicit engine: one batch at a time, no streaming inside the call)
         api = {'reads': n_api, 'raw_dtype': 'int16', 'returns': 'list of resquiggleResults (float64 '
                'normalised signal + int64 boundaries per read), same as the reference'}
         for mode, extra in (('numpy_subsample', {}), ('device_subsample', dict(subsample_seed=1)),

@@ -143,6 +143,37 @@ def test_auto_sub_batching_gives_the_one_batch_result():
             assert x.sig_match_score == y.sig_match_score
 
 
+def test_streamed_resquiggle_batch_gives_the_one_batch_result(monkeypatch):
+    """a long list goes through three engines in rotation (pack / compute / download + unpack
+    overlapped, resquiggle._stream_batches): same results, same order, failures included; with the
+    host draw the Theil-Sen subsamples come off numpy's RNG in read order either way"""
+    from tombo_amd import resquiggle as rq
+    samp, model, params, reads = _setup(n_reads=41, seed0=170)
+    mrs = _map_results(reads)
+    mrs[5] = mrs[5]._replace(raw_signal=mrs[5].raw_signal[:400])     # a read that fails
+    monkeypatch.setenv('TBA_API_STREAM', '0')
+    np.random.seed(11)
+    one = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp)
+    monkeypatch.setenv('TBA_API_STREAM', '1')
+    monkeypatch.setenv('TBA_API_STREAM_MIN', '12')
+    np.random.seed(11)
+    cut = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp)
+    nosig = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp,
+                                subsample_seed=3, return_signal=False)
+    assert len(one) == len(cut) == len(nosig) == len(mrs)
+    assert any(isinstance(x, Exception) for x in one)
+    for x, y, z in zip(one, cut, nosig):
+        assert isinstance(x, Exception) == isinstance(y, Exception) == isinstance(z, Exception)
+        if isinstance(x, Exception):
+            assert str(x) == str(y)
+            continue
+        np.testing.assert_array_equal(x.segs, y.segs)
+        np.testing.assert_array_equal(x.raw_signal, y.raw_signal)
+        assert x.sig_match_score == y.sig_match_score and x.scale_values == y.scale_values
+        assert x.genome_seq == y.genome_seq and x.read_start_rel_to_raw == y.read_start_rel_to_raw
+        assert z.raw_signal is None and z.segs.shape == x.segs.shape
+
+
 def test_put_rejects_indices_outside_the_signal():
     from tombo_amd import _native, resquiggle as rq, tombo_stats as ts
     samp, model, params, reads = _setup(n_reads=1, seed0=11)

@@ -219,6 +219,7 @@ class Engine(object):
         if rc != 0:
             raise EngineError('tba_engine_create failed (%d): %s' % (
                 rc, self._L.tba_last_error().decode()))
+        self.device = int(device)
         self.kmer_width = None
         self._keep = None
         self._model_key = None

@@ -100,21 +100,44 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
             pre_err[i] = th.TomboError(errors.MESSAGES[21])
             raw = np.zeros(1)
         raws.append(raw if isinstance(raw, np.ndarray) else np.asarray(raw))
+    args = dict(std_ref=std_ref, rsqgl_params=rsqgl_params, outlier_thresh=outlier_thresh,
+                max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
+                const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
+                seq_samp_type=seq_samp_type, reverse_raw=reverse_raw, stall_params=stall_params,
+                return_signal=return_signal, return_debug=return_debug)
+    cuts = [(0, n)]
     if n > 1 and not return_debug:
         from . import planner
         if mem_budget is None:
-            mem_budget = max(0.6 * (eng.device_mem()[0] + eng.held_bytes()), float(2 << 30))
+            # (what is free now plus what this engine already holds; no floor: on a device that
+            # other engines share a floor would stop the planner from cutting, and the upload
+            # would fail with TBA_E_NOMEM instead)
+            mem_budget = 0.6 * (eng.device_mem()[0] + eng.held_bytes())
         p_ = _native.make_params(rsqgl_params)
-        o_ = _native.make_opts(min_event_to_seq_ratio=min_event_to_seq_ratio)
+        o_ = _native.make_opts(min_event_to_seq_ratio=min_event_to_seq_ratio, reverse_raw=reverse_raw,
+                               stall_params=stall_params, subsample_seed=subsample_seed,
+                               skip_norm_out=not return_signal)
         n_raw = [r.shape[0] for r in raws]
         seq_len = [len(mr.genome_seq) for mr in map_results]
-        # (page-locked staging holds the batch once on the way in and once on the way out)
-        host_cap = 1 << 30   # samples per sub-batch
-        if n > planner.MAX_READS or sum(n_raw) > host_cap or \
-                planner.exact_bytes(n_raw, seq_len, p_, o_, K) > mem_budget:
+        # Sub-batches.  By memory (the engine's own footprint function) and by host staging, and --
+        # for a list worth it -- by the stream: with several sub-batches in flight on as many
+        # engines the packing of one, the kernels of another and the download + unpacking of a
+        # third overlap (_stream_batches); one sub-batch should still fill the machine's DP
+        # wavefront slots together with its neighbours (~1 600 reads each: 6 cuts of a 5 000-read list
+        # took 110 ms of GPU time for what one batch does in 50).
+        stream_cuts = 1
+        stream_min = int(os.environ.get('TBA_API_STREAM_MIN', '2400'))   # (tests lower it)
+        if engine is None and n >= stream_min and os.environ.get('TBA_API_STREAM', '1') != '0':
+            stream_cuts = max(3, min(12, n // max(2 * stream_min // 3, 1)))
+        slot_budget = mem_budget if stream_cuts == 1 else mem_budget / _STREAM_SLOTS
+        host_cap = 1 << 28   # samples per sub-batch: 2 GiB of float64 each way in page-locked staging
+        target = -(-n // stream_cuts)
+        if n > planner.MAX_READS or sum(n_raw) > host_cap or stream_cuts > 1 or \
+                planner.exact_bytes(n_raw, seq_len, p_, o_, K) > slot_budget:
             # consecutive cuts (sort=False): the Theil-Sen subsamples are drawn from the global
             # RNG in read order, exactly as for one big batch
-            parts = planner.plan_batches(n_raw, seq_len, p_, o_, K, mem_budget, sort=False)
+            parts = planner.plan_batches(n_raw, seq_len, p_, o_, K, slot_budget, sort=False,
+                                         max_reads=min(planner.MAX_READS, max(target, 1)))
             cuts = []
             for idx in parts:   # ... and by host staging
                 a0, acc = int(idx[0]), 0
@@ -124,28 +147,121 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                         a0, acc = int(i), 0
                     acc += n_raw[i]
                 cuts.append((a0, int(idx[-1]) + 1))
-            if len(cuts) > 1:
-                out = []
-                for k, (a, b) in enumerate(cuts):
-                    out.extend(resquiggle_batch(
-                        map_results[a:b], std_ref, rsqgl_params, outlier_thresh=outlier_thresh,
-                        all_raw_signals=None if all_raw_signals is None else all_raw_signals[a:b],
-                        max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
-                        const_scale=const_scale, skip_seq_scaling=skip_seq_scaling,
-                        seq_samp_type=seq_samp_type,
-                        samp_inds=None if samp_inds is None else samp_inds[a:b], engine=eng,
-                        mem_budget=float('inf'), reverse_raw=reverse_raw, stall_params=stall_params,
-                        subsample_seed=None if subsample_seed is None else subsample_seed + 7919 * k,
-                        return_signal=return_signal))
-                return out
+    if len(cuts) > 1:
+        engines = _stream_engines(eng, std_ref) if engine is None and stream_cuts > 1 else [eng]
+        return _stream_batches(engines, cuts, map_results, raws, pre_err, samp_inds, subsample_seed, args)
+    ctx = _submit_batch(eng, 0, n, map_results, raws, pre_err, samp_inds, subsample_seed, args)
+    _sync_batch(ctx)
+    _unpack_batch(ctx)
+    results = _build_results(ctx)
+    if return_debug:
+        return results, ctx['out']
+    return results
+
+
+_STREAM_SLOTS = 3
+_STREAM_ENGINES = {}
+
+
+def _stream_engines(eng, std_ref):
+    """the engines a streamed `resquiggle_batch` rotates over: the process-wide one of the device
+    and two more, created on first use (each has its own stream, device buffers and staging)"""
+    extra = _STREAM_ENGINES.get(eng.device)
+    if extra is None:
+        extra = _STREAM_ENGINES[eng.device] = [_native.Engine(eng.device) for _ in range(_STREAM_SLOTS - 1)]
+    engines = [eng] + extra
+    for e in engines:
+        e.ensure_model(std_ref)
+        e.set_sharing(len(engines))
+    return engines
+
+
+def _stream_batches(engines, cuts, map_results, raws, pre_err, samp_inds, subsample_seed, args):
+    """Sub-batches through `engines` in rotation: while one computes, the next is packed and
+    uploaded and the one before is downloaded, cut into per-read arrays (a helper thread: native
+    copies, GIL released) and turned into results (this thread).  Results in input order."""
+    from concurrent.futures import ThreadPoolExecutor
+    import time
+    trace = [] if os.environ.get('TBA_API_TRACE') else None   # (what, sub-batch, seconds since the call)
+    t_call = time.perf_counter()
+
+    def mark(what, k):
+        if trace is not None:
+            trace.append((what, k, round(time.perf_counter() - t_call, 4)))
+    out, pending = [], []          # pending: contexts in submission order
+    S = len(engines)
+    last_ctx = [None] * S          # the context that used engine k last (its staging is reused)
+    # With the signal coming back the call is bound by the download (0.74 MB per 10 kb read): the
+    # sub-batches then compute one after the other (tba_batch_wait_for), so that the download of one
+    # runs under the kernels of the next; without it they share the device (small batches do not
+    # fill it alone) -- measured on 5 000 reads of 10 kb, three cuts: all three finished computing
+    # together after 65 ms and only then 74 ms of downloads began.
+    chain = bool(args['return_signal'])
+    with ThreadPoolExecutor(1) as ex:
+        def unpack(ctx):
+            _unpack_batch(ctx)
+            mark('unpacked', ctx['k'])
+
+        def pump():
+            """retire what the device has finished (sync is immediate then; the unpacking goes to
+            the helper), build the results of what the helper is done with, in order"""
+            moved = False
+            for c in pending:
+                if 'unpack' not in c and not c['eng'].query():
+                    _sync_batch(c)
+                    mark('synced', c['k'])
+                    c['unpack'] = ex.submit(unpack, c)
+                    moved = True
+            while pending and 'unpack' in pending[0] and pending[0]['unpack'].done():
+                c = pending.pop(0)
+                c['unpack'].result()
+                out.extend(_build_results(c))
+                mark('built', c['k'])
+                moved = True
+            return moved
+
+        for k, (a, b) in enumerate(cuts):
+            e = k % S
+            old = last_ctx[e]
+            while old is not None and not ('unpack' in old and old['unpack'].done()):
+                if not pump():           # its page-locked outputs must be free again
+                    time.sleep(0.0002)
+            seed = None if subsample_seed is None else subsample_seed + 7919 * k
+            mark('submit', k)
+            ctx = _submit_batch(engines[e], a, b, map_results, raws, pre_err, samp_inds, seed, args,
+                                after=engines[(k - 1) % S] if chain and k > 0 else None)
+            ctx['k'] = k
+            mark('submitted', k)
+            last_ctx[e] = ctx
+            pending.append(ctx)
+            pump()
+        while pending:
+            if not pump():
+                time.sleep(0.0002)
+    if trace is not None:
+        import sys
+        print('resquiggle_batch stream trace:', trace, file=sys.stderr)
+    for e in engines:
+        e.set_sharing(1)
+    return out
+
+
+def _submit_batch(eng, a, b, map_results, raws, pre_err, samp_inds, subsample_seed, args, after=None):
+    """pack reads [a, b), upload, enqueue the kernel sequence and the downloads; returns the
+    context `_sync_batch` / `_unpack_batch` / `_build_results` finish"""
+    std_ref, rsqgl_params = args['std_ref'], args['rsqgl_params']
+    return_signal, return_debug = args['return_signal'], args['return_debug']
+    mrs, rws = map_results[a:b], raws[a:b]
+    n = b - a
+    K = std_ref.kmer_width
     stage = eng.host_stage()
     raw, raw_off, seq, seq_off, _ = _native.pack_reads(
-        raws, [mr.genome_seq for mr in map_results], stage=stage)
+        rws, [mr.genome_seq for mr in mrs], stage=stage)
     sv_in = sv_flags = None
-    if any(mr.scale_values is not None for mr in map_results):
+    if any(mr.scale_values is not None for mr in mrs):
         sv_in = np.zeros((n, 4))
         sv_flags = np.zeros(n, np.int32)
-        for i, mr in enumerate(map_results):
+        for i, mr in enumerate(mrs):
             sv = mr.scale_values
             if sv is None:
                 continue
@@ -155,63 +271,88 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
                 sv_in[i, 2], sv_in[i, 3] = sv.lower_lim, sv.upper_lim
                 sv_flags[i] |= 2
     st = sto = None
-    if stall_params is None:
-        stalls = [mr.stall_ints for mr in map_results]
+    if args['stall_params'] is None:
+        stalls = [mr.stall_ints for mr in mrs]
         if any(s is not None and len(s) for s in stalls):
             st, sto = _native.pack_stalls(stalls)
     nb = np.diff(seq_off) - K + 1
     si = None
-    rng_state = np.random.get_state() if n == 1 else None
-    if not skip_seq_scaling and subsample_seed is None and (nb > MAX_POINTS_FOR_THEIL_SEN).any():
+    rng_state = np.random.get_state() if len(map_results) == 1 else None
+    if not args['skip_seq_scaling'] and subsample_seed is None and (nb > MAX_POINTS_FOR_THEIL_SEN).any():
         si = stage.get('si', n * MAX_POINTS_FOR_THEIL_SEN, np.int64).reshape(n, MAX_POINTS_FOR_THEIL_SEN)
+        si[:] = -1   # (rows of reads that need none; the kernel rejects a negative index)
         for i in np.flatnonzero(nb > MAX_POINTS_FOR_THEIL_SEN):
-            si[i] = _draw_samp_ind(int(nb[i])) if samp_inds is None or samp_inds[i] is None \
-                else samp_inds[i]
+            si[i] = _draw_samp_ind(int(nb[i])) if samp_inds is None or samp_inds[a + i] is None \
+                else samp_inds[a + i]
     p = _native.make_params(rsqgl_params)
+    seq_samp_type = args['seq_samp_type']
     o = _native.make_opts(
-        outlier_thresh=outlier_thresh, const_scale=const_scale,
-        skip_seq_scaling=skip_seq_scaling,
+        outlier_thresh=args['outlier_thresh'], const_scale=args['const_scale'],
+        skip_seq_scaling=args['skip_seq_scaling'],
         sig_match_thresh=None if seq_samp_type is None else SIG_MATCH_THRESH[seq_samp_type.name],
-        max_raw_cpts=max_raw_cpts, min_event_to_seq_ratio=min_event_to_seq_ratio,
-        reverse_raw=reverse_raw, stall_params=stall_params, subsample_seed=subsample_seed,
+        max_raw_cpts=args['max_raw_cpts'], min_event_to_seq_ratio=args['min_event_to_seq_ratio'],
+        reverse_raw=args['reverse_raw'], stall_params=args['stall_params'], subsample_seed=subsample_seed,
         skip_norm_out=not return_signal and not return_debug)
     eng.upload_packed(p, o, raw, raw_off, seq, seq_off, sv_in=sv_in, sv_flags=sv_flags,
                       samp_ind=si, stall_ints=st, stall_off=sto)
+    if after is not None:
+        eng.wait_for(after)   # this batch's kernels start when that engine's sequence has finished
     eng.enqueue()
-    if return_debug:
-        eng.sync()
+    ctx = dict(eng=eng, a=a, b=b, n=n, nb=nb, raw_off=raw_off, seg_off=eng.seg_off.copy(),
+               map_results=mrs, pre_err=pre_err[a:b], rng_state=rng_state, args=args)
+    if not return_debug:
+        ctx['o_res'] = stage.get('res', n, _native.RESULT_DTYPE)
+        ctx['o_segs'] = stage.get('segs', int(eng.seg_off[-1]), np.int64)
+        ctx['o_norm'] = stage.get('norm', eng.n_raw_total, np.float64) if return_signal else None
+        eng.download_async(results=ctx['o_res'], segs64=ctx['o_segs'], norm=ctx['o_norm'])
+    return ctx
+
+
+def _sync_batch(ctx):
+    """wait for the batch; the small per-read outputs (copies: the staging is reused)"""
+    eng, args = ctx['eng'], ctx['args']
+    eng.sync()
+    if args['return_debug']:
         out = eng.download()
-        o_res = None
     else:
-        o_res = stage.get('res', n, _native.RESULT_DTYPE)
-        o_segs = stage.get('segs', int(eng.seg_off[-1]), np.int64)
-        o_norm = stage.get('norm', eng.n_raw_total, np.float64) if return_signal else None
-        eng.download_async(results=o_res, segs64=o_segs, norm=o_norm)
-        eng.sync()
-        out = dict(status=o_res['status'], read_start=o_res['read_start_rel_to_raw'],
-                   norm_len=o_res['norm_len'], score=o_res['sig_match_score'],
-                   changed=o_res['norm_params_changed'],
+        o_res = ctx['o_res']
+        out = dict(status=o_res['status'].copy(), read_start=o_res['read_start_rel_to_raw'].copy(),
+                   norm_len=o_res['norm_len'].copy(), score=o_res['sig_match_score'].copy(),
+                   changed=o_res['norm_params_changed'].copy(),
                    sv=np.stack([o_res['shift'], o_res['scale'], o_res['lower_lim'],
                                 o_res['upper_lim']], axis=1))
+    ctx['out'] = out
     status = np.asarray(out['status'])
-    if rng_state is not None and int(status[0]) not in (0, 19, 20):
+    if ctx['rng_state'] is not None and int(status[0]) not in (0, 19, 20):
         # a batch of one is the reference's call: it only touches the RNG once the read reaches
         # sequence rescaling (calc_kmer_fitted_shift_scale), so a read that failed earlier leaves
         # the seeded stream where it was
-        np.random.set_state(rng_state)
-    ok = np.flatnonzero((status == 0) & np.array([e is None for e in pre_err]))
-    if o_res is not None:
-        segs_l = _native.unpack_reads(o_segs, eng.seg_off[:-1][ok], nb[ok] + 1)
-        norm_l = _native.unpack_reads(o_norm, raw_off[:-1][ok], out['norm_len'][ok]) if return_signal \
-            else [None] * len(ok)
+        np.random.set_state(ctx['rng_state'])
+    ctx['ok'] = np.flatnonzero((status == 0) & np.array([e is None for e in ctx['pre_err']]))
+    ctx['dev_stalls'] = eng.stall_ints() if args['stall_params'] is not None else None
+
+
+def _unpack_batch(ctx):
+    """the per-read boundary / signal arrays out of the flat downloads (native threads)"""
+    out, ok, nb, args = ctx['out'], ctx['ok'], ctx['nb'], ctx['args']
+    if not args['return_debug']:
+        ctx['segs_l'] = _native.unpack_reads(ctx['o_segs'], ctx['seg_off'][:-1][ok], nb[ok] + 1)
+        ctx['norm_l'] = _native.unpack_reads(ctx['o_norm'], ctx['raw_off'][:-1][ok], out['norm_len'][ok]) \
+            if args['return_signal'] else [None] * len(ok)
     else:
-        segs_l = [out['segs'][eng.seg_off[i]:eng.seg_off[i + 1]].copy() for i in ok]
-        norm_l = [out['norm'][eng.raw_off[i]:eng.raw_off[i] + int(out['norm_len'][i])].copy() for i in ok]
-    dev_stalls = eng.stall_ints() if stall_params is not None else None
-    results = [None] * n
-    cp = std_ref.central_pos
+        so, ro = ctx['seg_off'], ctx['raw_off']
+        ctx['segs_l'] = [out['segs'][so[i]:so[i + 1]].copy() for i in ok]
+        ctx['norm_l'] = [out['norm'][ro[i]:ro[i] + int(out['norm_len'][i])].copy() for i in ok]
+
+
+def _build_results(ctx):
+    """resquiggleResults / TomboError per read of the batch"""
+    out, ok, args, n = ctx['out'], ctx['ok'], ctx['args'], ctx['n']
+    std_ref = args['std_ref']
+    K, cp = std_ref.kmer_width, std_ref.central_pos
     dn = K - cp - 1
-    svs, rstart, score, changed = out['sv'], out['read_start'], out['score'], out['changed']
+    results = [None] * n
+    status = np.asarray(out['status'])
     # (thousands of small tuples are born here and none of them is garbage: with the cyclic
     # collector running, its generation passes over the caller's live objects were a quarter of the
     # host time of a 5 000-read call)
@@ -219,11 +360,14 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
     gc_was = gc.isenabled()
     gc.disable()
     try:
-        _fill_results(results, ok, map_results, svs, rstart, score, changed, segs_l, norm_l, dev_stalls,
-                      skip_seq_scaling, outlier_thresh, rsqgl_params, const_scale, cp, dn)
+        _fill_results(results, ok, ctx['map_results'], out['sv'], out['read_start'], out['score'],
+                      out['changed'], ctx['segs_l'], ctx['norm_l'], ctx['dev_stalls'],
+                      args['skip_seq_scaling'], args['outlier_thresh'], args['rsqgl_params'],
+                      args['const_scale'], cp, dn)
     finally:
         if gc_was:
             gc.enable()
+    pre_err = ctx['pre_err']
     for i in range(n):
         if results[i] is not None:
             continue
@@ -235,8 +379,6 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
             results[i] = th.TomboError(errors.MESSAGES[st_i])
         else:
             results[i] = RuntimeError('Unexpected error in resquiggle engine (status %d)' % st_i)
-    if return_debug:
-        return results, out
     return results
 
 
