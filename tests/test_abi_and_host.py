@@ -260,6 +260,9 @@ def test_stream_pipeline_slot_logic_with_stub_engines(monkeypatch):
         def ensure_model(self, m):
             pass
 
+        def set_sharing(self, n_engines):
+            pass
+
         def upload_packed(self, p, o, raw, raw_off, seq, seq_off, **kw):
             self.n = len(raw_off) - 1
             self.raw_off = np.asarray(raw_off)
@@ -354,6 +357,9 @@ def test_stream_pipeline_any_slot_and_feeder_staging(monkeypatch):
             self.busy_until = 0.0
 
         def ensure_model(self, m):
+            pass
+
+        def set_sharing(self, n_engines):
             pass
 
         def upload_packed(self, p, o, raw, raw_off, seq, seq_off, **kw):
