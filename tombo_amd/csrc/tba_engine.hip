@@ -73,6 +73,7 @@ static const char *STAGE_NAMES[N_STAGE] = {
 
 #define WIDE_BLOCKS 64 // workgroups of k_dp_wide (each owns two scratch rows)
 #define TB_LANES 16    // reads per wavefront of the latency-bound lane-per-read kernels
+#define TBA_SMALL_BATCH 256 // up to this many reads the scan of event detection runs a workgroup per read
 
 // k_peaks is compiled per exclusion radius (min_obs_per_base - 1): 2 and 5 are the defaults of
 // the DNA / RNA parameter sets, anything else takes the generic kernel
@@ -617,9 +618,16 @@ static int enqueue_stages(tba_engine *e, int first, int last)
 #else
     const bool fused_detect = !rna && 2 * P.running_stat_width <= DT_W2MAX && P.min_obs_per_base == 3;
 #endif
-    const int only_flagged = fused_detect ? 1 : 0;
+    // A handful of reads cannot hide the scan's serial chain behind each other: k_detect /
+    // k_cumsum_scores pay a pipeline step (barrier, memory round trip, greedy: ~7 us) per 128 samples
+    // whatever the batch, 5 ms for a 10 kb read; a workgroup per read (k_long.h: the step is 1 856
+    // dependent adds long) does the same in 0.5 ms.  (resquiggle_read, a batch of one: 20.4 -> 16 ms.)
+    const bool wg_scan = !rna && fused_scores && n <= TBA_SMALL_BATCH && (size_t)n * 4 <= e->d_order.cap;
+    const int only_flagged = fused_detect && !wg_scan ? 1 : 0;
     MARK(); // 1 cumsum
-    if (ON(TBA_STAGE_SEGMENT) && !rna) {
+    if (ON(TBA_STAGE_SEGMENT) && !rna && wg_scan) {
+        k_cumsum_scores_long<double, 0><<<nb, 256, 0, s>>>(rs, e->d_order.as<i32>(), dp, e->d_norm.as<double>(), e->d_score.as<double>());
+    } else if (ON(TBA_STAGE_SEGMENT) && !rna) {
         if (fused_detect) {
             k_detect<2><<<(unsigned)((n + DT_READS - 1) / DT_READS), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_csum.as<double>(), e->d_score.as<double>());
             k_pick<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>(), e->d_cpts.as<i64>());
