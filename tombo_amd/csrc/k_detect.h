@@ -365,8 +365,10 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
 
 // The cap: keep the num_cpts best taken positions.  dense / posbuf: the taken (score, position)
 // list k_detect left, ascending in position.  One workgroup per read.
+// ttest: the candidates of c_valid_cpts_w_cap_t_test (_c_helper.pyx:185-202: n - 2w scores, all of them
+// candidates) instead of c_valid_cpts_w_cap's (n + 1 - 2w scores, the last 2w no candidates).
 __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevParams *dp,
-    const double *dense, const double *posbuf, i64 *valid_cpts)
+    const double *dense, const double *posbuf, i64 *valid_cpts, int ttest)
 {
     __shared__ BucketSmem sm;
     __shared__ i64 s_w[SEL_NT / 64];
@@ -376,7 +378,8 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevPara
     if (r.status != TBA_OK || r.ed_flag) return;
     const int tid = threadIdx.x;
     const i64 w = dp->p.running_stat_width;
-    const i64 ns = r.n_raw + 1 - 2 * w, num_cands = ns - 2 * w, num_cpts = r.num_events;
+    const i64 ns = ttest ? r.n_raw - 2 * w : r.n_raw + 1 - 2 * w, num_cands = ttest ? ns : ns - 2 * w;
+    const i64 num_cpts = r.num_events;
     const double *dn = dense + r.raw_off + blockIdx.x;
     const i32 *pn = (const i32 *)(posbuf + r.raw_off);
     i64 *cpts = valid_cpts + r.ev_off;
@@ -414,10 +417,10 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevPara
     // The reference raises when the rank of the last pick in the argsort order, + 1, reaches
     // num_cands (_c_helper.pyx:116-118).  That rank is below ns minus the positions that score
     // under the threshold, and every taken position under the threshold is one: no error while
-    // those alone outnumber 2 * width.  Too close to call (or more ties than the list holds): the
-    // kernels that keep the scores decide.
+    // those alone outnumber ns - num_cands (2 * width; 0 for the t-test scores).  Too close to call
+    // (or more ties than the list holds): the kernels that keep the scores decide.
     const i64 c_lt = n_taken - c_gt - c_eq;
-    if ((num_cpts > 1 && c_lt <= 2 * w) || c_eq > 2048 || need_eq < 1 || need_eq > c_eq) {
+    if ((num_cpts > 1 && c_lt <= ns - num_cands) || c_eq > 2048 || need_eq < 1 || need_eq > c_eq) {
         if (tid == 0) r.ed_flag = 1;
         return;
     }
@@ -428,5 +431,215 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevPara
         [&](i64 i, double v) { return v > tval || (v == tval && (i64)pn[i] >= idx_thr); },
         [&](i64 i, i64 o) { if (o < num_cpts) cpts[o] = (i64)pn[i] + w; }, s_w);
     if (tid == 0) { r.n_cpts = num_cpts; r.n_ev = num_cpts - 1; }
-    (void)num_cands;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same for the t-test scores of RNA (c_valid_cpts_w_cap_t_test, _c_helper.pyx:144-202): a score
+// needs the 2w samples around its position and nothing before them, so there is no scan to wait
+// for -- one workgroup per read walks its signal in tiles of TT_NEW positions: all wavefronts
+// compute the tile's scores into LDS (ttest_score, k_segment.h), then wavefront 0 resolves the
+// uncapped greedy on them -- a lane per 32-position word, word 0 = the last word of the previous tile
+// (carried: positions near a tile's end wait for the next one), early emission as in k_detect --
+// and appends the taken (score, position) pairs to the read's list while the other wavefronts
+// stage the next tile's samples.  k_pick caps the list.  Replaces k_scores_ttest (8 S bytes
+// written) + k_peaks<5> (read ~2.3 times, + a state byte per sample: 20.7 of cfg4's 103 ms).
+#define TT_WORDS 64
+#define TT_NEW (32 * (TT_WORDS - 1))          // new positions per tile (word 0 is carried)
+#define TT_SPAD(i_) ((i_) + ((i_) >> 5))      // score slot of tile position i: one pad per word
+template <int R, int WS, class RT>
+__global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const DevParams *dp,
+    const RT *__restrict__ raw, double *__restrict__ dense, double *__restrict__ posbuf)
+{
+    static_assert(R >= 1 && R <= 8, "exclusion radius");
+    __shared__ double rawt[2][TT_NEW + 2 * TT_MAXW];     // the samples of a tile (+ 2w beyond); double buffered
+    __shared__ double sbuf[2][TT_SPAD(32 * TT_WORDS) + 2]; // its scores, word h at 33 h; double buffered
+    __shared__ u32 s_cnt;
+    __shared__ int s_bad;
+    ReadState &r = rs[blockIdx.x];
+    if (r.status != TBA_OK) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = (int)dp->p.running_stat_width, w2 = 2 * w;
+    const int n = (int)r.n_raw, ns = n - w2;             // positions 0 .. ns - 1
+    if (w2 > 2 * TT_MAXW || r.n_raw > 0x7fffffffll / 2 || ns <= 0) {
+        if (tid == 0) { r.ed_flag = 1; r.n_taken = 0; } // the kernels that keep the scores take it
+        return;
+    }
+    const RawSamples<RT> x{raw + r.raw_off};
+    double *dn = dense + r.raw_off + blockIdx.x;
+    i32 *pn = (i32 *)(posbuf + r.raw_off);
+    if (tid == 0) { s_cnt = 0; s_bad = 0; }
+    const int n_tiles = (ns + TT_NEW - 1) / TT_NEW;
+    // Wavefront 0 runs the greedy of tile i while wavefronts 1..7 (the "scorers": SC_NT threads)
+    // compute the scores of tile i + 1 and fetch the samples of tile i + 2; one barrier per tile.
+    constexpr int SC_NT = SEL_NT - 64;
+    constexpr int PER = (TT_NEW + 2 * TT_MAXW + SC_NT - 1) / SC_NT; // samples per scorer thread and tile
+    const int st = tid - 64;                             // scorer thread index (wave >= 1)
+    double pre[PER];
+    auto fetch = [&](int tile) {
+        const int p0 = tile * TT_NEW, span = TT_NEW + w2;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int c = st + u * SC_NT;
+            pre[u] = (c < span && p0 + c < n) ? x[p0 + c] : 0.0;
+        }
+    };
+    auto drop = [&](double *rt) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int c = st + u * SC_NT;
+            if (c < TT_NEW + 2 * TT_MAXW) rt[c] = pre[u];
+        }
+    };
+    auto scores = [&](int tile) {                        // tile's scores -> sbuf[tile & 1], word 0 = carried word
+        double *sb = sbuf[tile & 1];
+        const double *sp = sbuf[(tile & 1) ^ 1], *rt = rawt[tile & 1];
+        const int P0 = tile * TT_NEW;
+        if (tile < n_tiles)
+            for (int c = st; c < TT_NEW; c += SC_NT) {
+                const double v = P0 + c < ns ? (WS > 0 ? ttest_score<WS>(rt + c, WS) : ttest_score<0>(rt + c, w)) : 0.0;
+                sb[TT_SPAD(32 + c)] = v;
+            }
+        if (st < 32) sb[st] = tile > 0 ? sp[TT_SPAD(32 * (TT_WORDS - 1) + st)] : 0.0; // word 0 <- last word
+    };
+    if (wave >= 1) {
+        fetch(0);
+        drop(rawt[0]);
+    }
+    __syncthreads();
+    if (wave >= 1) {
+        if (n_tiles > 1) fetch(1);
+        scores(0);
+        if (n_tiles > 1) drop(rawt[1]);
+    }
+    __syncthreads();
+    u32 prevT = 0, prev_emitted = 0, prevX[R + 1];
+#pragma unroll
+    for (int d = 0; d <= R; d++) prevX[d] = 0;
+    for (int i = 0; i <= n_tiles; i++) {                 // (one more step finishes the carried word)
+        const double *sb = sbuf[i & 1];
+        const int P0 = i * TT_NEW;                       // first new position of the tile
+        if (wave != 0) {
+            // tile i + 1: its samples sit in rawt[(i + 1) & 1]; tile i + 2's are fetched meanwhile and
+            // dropped into rawt[i & 1], which nobody reads any more (tile i was scored a step ago)
+            if (i + 1 <= n_tiles) {
+                if (i + 2 < n_tiles) fetch(i + 2);
+                scores(i + 1);
+                if (i + 2 < n_tiles) drop(rawt[i & 1]);
+            }
+        } else {
+            // ---- greedy: lane h = positions P0 - 32 + 32 h .. + 31, scores at sb[33 h ..]
+            const int h = lane;
+            const int pos0 = P0 - 32 + 32 * h;
+            const double *row = sb + 33 * h;
+            u32 V = 0;
+            {
+                const int lo_t = pos0 < 0 ? -pos0 : 0, hi_t = ns - 1 - pos0;
+                if (hi_t >= lo_t && lo_t < 32) {
+                    const u32 up_to = hi_t >= 31 ? ~0u : ((2u << hi_t) - 1u);
+                    V = up_to & (~0u << lo_t);
+                }
+            }
+            u32 G[R + 1], acc_g[R + 1];
+#pragma unroll
+            for (int d = 0; d <= R; d++) { G[d] = 0; acc_g[d] = 0; }
+            double first[R], last[R], before[R];
+#pragma unroll
+            for (int d = 0; d < R; d++) { first[d] = 0.0; last[d] = 0.0; before[d] = 0.0; }
+#pragma unroll
+            for (int t8 = 0; t8 < 32; t8 += 8) {
+                double sc[8 + R];
+#pragma unroll
+                for (int d = 0; d < R; d++) sc[d] = before[d];
+#pragma unroll
+                for (int u = 0; u < 8; u++) sc[R + u] = row[t8 + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int d = 1; d <= R; d++) acc_g[d] = dt_shift_in_ge(acc_g[d], sc[R + u], sc[R + u - d]);
+                }
+#pragma unroll
+                for (int d = 0; d < R; d++) before[d] = sc[8 + d];
+                if (t8 == 0) {
+#pragma unroll
+                    for (int d = 0; d < R; d++) first[d] = sc[R + d];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < R; d++) last[d] = before[d];
+#pragma unroll
+            for (int d = 1; d <= R; d++) G[d] = (__builtin_bitreverse32(acc_g[d]) >> d) & V & (V >> d);
+            // pairs into the next word (the lane above); the future counts as outranking
+            const bool top = h == TT_WORDS - 1;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const double bs = shfl_f64(first[k], (lane + 1) & 63);
+                const int pb = pos0 + 32 + k;
+                const bool bv = pb >= 0 && pb < ns;
+#pragma unroll
+                for (int d = k + 1; d <= R; d++) {
+                    const int tp = 32 + k - d;
+                    const bool b = bv && ((V >> tp) & 1u) && (top || bs >= last[tp - (32 - R)]);
+                    G[d] |= (b ? 1u : 0u) << tp;
+                }
+            }
+            u32 vfut = 0;                                 // validity of the 32 positions after the tile
+            {
+                const int hi_s = ns - 1 - (P0 + TT_NEW);
+                if (hi_s >= 0) vfut = hi_s >= 31 ? ~0u : ((2u << hi_s) - 1u);
+            }
+            const u32 va = dt_lane_above(V);
+            const u32 Vn = top ? vfut : va;
+            u32 X[R + 1], Hm[R + 1];
+#pragma unroll
+            for (int d = 1; d <= R; d++) {
+                const u32 pv = V & dt_down(V, Vn, d);
+                X[d] = pv & ~G[d];
+                const u32 xb = dt_lane_below(X[d]);
+                Hm[d] = V & dt_up(X[d], h == 0 ? prevX[d] : xb, d);
+            }
+            u32 T = 0, S = 0, U = V;
+            for (int round = 0; round < DT_MAX_ROUNDS; round++) {
+                const u32 ta = dt_lane_above(T), tb = dt_lane_below(T);
+                const u32 ua = dt_lane_above(U), ub = dt_lane_below(U);
+                const u32 Tn = top ? 0u : ta, Tp = h == 0 ? prevT : tb;
+                const u32 Un = top ? vfut : ua, Up = h == 0 ? 0u : ub;
+                u32 at = 0, au = 0;
+#pragma unroll
+                for (int d = 1; d <= R; d++) {
+                    at |= (G[d] & dt_down(T, Tn, d)) | (Hm[d] & dt_up(T, Tp, d));
+                    au |= (G[d] & dt_down(U, Un, d)) | (Hm[d] & dt_up(U, Up, d));
+                }
+                const u32 nS = U & at, nT = U & ~at & ~au;
+                T |= nT; S |= nS; U &= ~(nT | nS);
+                if (__ballot((nS | nT) != 0) == 0) break;
+            }
+            if (!top && U != 0) s_bad = 1;                // a chain longer than a word: not for this kernel
+            // emission in position order; the last word's decisions are final too and emitted now
+            const u32 E = h == 0 ? T & ~prev_emitted : T;
+            const int ce = __popc(E);
+            int inc = ce;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const int t = __shfl_up(inc, dd, 64);
+                if (lane >= dd) inc += t;
+            }
+            const int tot = __shfl(inc, 63, 64);
+            const u32 base = s_cnt;
+            if (lane == 0) s_cnt = base + (u32)tot;
+            u32 o = base + (u32)(inc - ce);
+            for (u32 m = E; m != 0; m &= m - 1u) {
+                const int t = __ffs((int)m) - 1;
+                dn[o] = row[t];
+                pn[o] = pos0 + t;
+                o++;
+            }
+            // context of the next tile: its word 0 is this tile's last word, below it word 62
+            prevT = (u32)__shfl((int)T, TT_WORDS - 2, 64);
+#pragma unroll
+            for (int d = 1; d <= R; d++) prevX[d] = (u32)__shfl((int)X[d], TT_WORDS - 2, 64);
+            prev_emitted = (u32)__shfl((int)T, TT_WORDS - 1, 64);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { r.n_taken = (i64)s_cnt; r.ed_flag = s_bad; }
 }

@@ -416,11 +416,12 @@ __device__ __forceinline__ double ttest_score(Acc t, int w)
 #define TT_MAXW 64
 template <class RT>
 __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const DevParams *dp,
-    const RT *raw, double *score)
+    const RT *raw, double *score, int only_flagged = 0)
 {
     __shared__ double tile[256 + 2 * TT_MAXW];
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
+    if (only_flagged && !r.ed_flag) return; // k_detect_tt / k_pick (k_detect.h) finished this read
     const i64 w = dp->p.running_stat_width;
     const i64 ns = r.n_raw - 2 * w;
     const RawSamples<RT> x{raw + r.raw_off};

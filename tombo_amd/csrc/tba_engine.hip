@@ -623,14 +623,19 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     // whatever the batch, 5 ms for a 10 kb read; a workgroup per read (k_long.h: the step is 1 856
     // dependent adds long) does the same in 0.5 ms.  (resquiggle_read, a batch of one: 20.4 -> 16 ms.)
     const bool wg_scan = !rna && fused_scores && n <= TBA_SMALL_BATCH && (size_t)n * 4 <= e->d_order.cap;
-    const int only_flagged = fused_detect && !wg_scan ? 1 : 0;
+#ifdef TBA_NO_FUSED_DETECT
+    const bool fused_tt = false;
+#else
+    const bool fused_tt = rna && P.min_obs_per_base == 6 && P.running_stat_width <= TT_MAXW; // RNA defaults: radius 5
+#endif
+    const int only_flagged = (fused_detect && !wg_scan) || fused_tt ? 1 : 0;
     MARK(); // 1 cumsum
     if (ON(TBA_STAGE_SEGMENT) && !rna && wg_scan) {
         k_cumsum_scores_long<double, 0><<<nb, 256, 0, s>>>(rs, e->d_order.as<i32>(), dp, e->d_norm.as<double>(), e->d_score.as<double>());
     } else if (ON(TBA_STAGE_SEGMENT) && !rna) {
         if (fused_detect) {
             k_detect<2><<<(unsigned)((n + DT_READS - 1) / DT_READS), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_csum.as<double>(), e->d_score.as<double>());
-            k_pick<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>(), e->d_cpts.as<i64>());
+            k_pick<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>(), e->d_cpts.as<i64>(), 0);
         }
         if (fused_scores) {
             if (cs_reads_for(n) == 20) k_cumsum_scores<20><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_score.as<double>(), only_flagged);
@@ -642,7 +647,14 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     MARK(); // 2 scores
     if (ON(TBA_STAGE_SEGMENT)) {
         if (!rna) { if (!fused_scores) k_scores_dna<<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>()); }
-        else RAW_DISPATCH(rdt, (k_scores_ttest<RT><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_score.as<double>())));
+        else {
+            if (fused_tt) {
+                if (P.running_stat_width == 12) RAW_DISPATCH(rdt, (k_detect_tt<5, 12, RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_csum.as<double>(), e->d_score.as<double>())));
+                else RAW_DISPATCH(rdt, (k_detect_tt<5, 0, RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_csum.as<double>(), e->d_score.as<double>())));
+                k_pick<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>(), e->d_cpts.as<i64>(), 1);
+            }
+            RAW_DISPATCH(rdt, (k_scores_ttest<RT><<<dim3(gS, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_score.as<double>(), only_flagged)));
+        }
     }
     MARK(); // 3 peaks
     if (ON(TBA_STAGE_SEGMENT)) {
