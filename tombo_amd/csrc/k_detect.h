@@ -67,9 +67,17 @@ __device__ __forceinline__ u32 dt_shift_in_ge(u32 g, double a, double b)
     asm("v_cmp_ge_f64 vcc, |%1|, |%2|\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(g) : "v"(a), "v"(b) : "vcc");
     return g;
 }
-template <int R>
+// The loader also IS the last pass of ts.normalize_raw_signal (tombo_stats.py:560-573, k_normalize
+// launched with write_norm = 2 leaves it to this kernel): it reads the raw samples (RT: float64,
+// float32 or the file's int16), normalises and clips them with the scale values k_normalize left in
+// ReadState -- (x - shift) / scale as a multiplication by 1 / scale with two residual corrections,
+// bit-identical to the division (div_by_recip) -- writes the normalised signal (the later stages
+// read it) and drops it into the tile: one pass over the signal less, 8 S bytes read and 8 S
+// written less per read than normalising first and reading the result back here.
+template <int R, class RT>
 __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, const DevParams *dp,
-    const double *__restrict__ norm, double *__restrict__ dense, double *__restrict__ posbuf)
+    const RT *__restrict__ raw, double *__restrict__ norm, double *__restrict__ dense, double *__restrict__ posbuf,
+    i64 dump_off)
 {
     static_assert(R >= 1 && R <= 8, "exclusion radius");
     // one LDS array, so that every access of the greedy is smem[integer index]: a select between
@@ -82,9 +90,10 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
     double *const halo = smem + DT_HALO;
     double *const zrow = smem + DT_ZROW;
 #define DT_TILEP(b_) (smem + (b_) * DT_TILE)
-    __shared__ i64 s_off[DT_READS], s_n[DT_READS];
+    __shared__ i64 s_off[DT_READS], s_n[DT_READS], s_st[DT_READS];
     __shared__ u32 s_cnt[DT_READS];
     __shared__ int s_bad[DT_READS];
+    __shared__ double s_shift[DT_READS], s_scale[DT_READS], s_rcp[DT_READS], s_lo[DT_READS], s_hi[DT_READS];
     const int tid = threadIdx.x, lane = tid & 63;
     // roles: 0 scan, 1 loader, 2 / 3 greedy.  Two workgroups share a CU, one wavefront of each per
     // SIMD: with the roles rotated by two in every other workgroup a SIMD holds one of the two heavy
@@ -102,8 +111,16 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
         const bool live = ok && !rs[ri].is_long;
         s_off[tid] = live ? rs[ri].raw_off : 0;
         s_n[tid] = live ? rs[ri].n_raw : 0;
+        s_st[tid] = live ? rs[ri].raw_off : dump_off;  // where the row's normalised samples go
         s_cnt[tid] = 0;
         s_bad[tid] = 0;
+        const double sc = live ? rs[ri].scale : 1.0;
+        s_shift[tid] = live ? rs[ri].shift : 0.0;
+        s_scale[tid] = sc;
+        s_rcp[tid] = 1.0 / sc;
+        const bool lim = live && rs[ri].has_lims != 0;
+        s_lo[tid] = lim ? rs[ri].lower : -INFINITY;
+        s_hi[tid] = lim ? rs[ri].upper : INFINITY;
         if (ok && !live) { rs[ri].ed_flag = 1; rs[ri].n_taken = 0; } // long read: k_long.h + k_peaks
     }
     for (int k = tid; k < DT_READS * DT_HSTRIDE; k += 256) halo[k] = 0.0; // c[0] = 0, nothing before it
@@ -116,26 +133,67 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
 
     // ---- wave 1: loader, a row (read) per unit, two samples per lane and access
     double pa[DT_READS], pb[DT_READS];
-    auto fetch = [&](i64 chunk) {
-#pragma unroll
-        for (int u = 0; u < DT_READS; u++) {
-            const i64 k = chunk * CS_CHUNK + 2 * lane, n = s_n[u];
-            const double *p = norm + s_off[u] + k;
-            if (k + 1 < n) ld2(p, pa[u], pb[u]);
-            else { pa[u] = k < n ? p[0] : 0.0; pb[u] = 0.0; }
-        }
+    // (no divergent branches: a pair is always loaded from inside the read -- clamped -- and what lies
+    // past the end is selected away on the way into the tile)
+    auto norm_one = [&](double xv, int u) {
+        // (reads without limits carry -inf / +inf: the clip is unconditional -- a test of the flag, a
+        // value the compiler cannot prove uniform, became a branch around two instructions per value,
+        // 80 of them per step with an LDS wait each)
+        const double sh = s_shift[u], sc = s_scale[u], y = s_rcp[u], lo = s_lo[u], hi = s_hi[u];
+        const double v = div_by_recip(xv - sh, sc, y);
+        return v > hi ? hi : (v < lo ? lo : v);
     };
-    auto drop = [&](double *t) {
+    // One loader step, four rows at a time: normalise the samples of chunk `chunk` (in registers since
+    // the previous step), write them out, drop them into tile `t`, and ask for the same rows of chunk
+    // `next` into the registers just freed -- every load then has a whole step to come back (issued
+    // after the step's work they had a tenth of one, and the wait for them WAS the step: 18 k cycles).
+    auto loader_step = [&](i64 chunk, double *t, i64 next) {
         const int pc = DT_PC(2 * lane);                // (2 lane and 2 lane + 1: same word)
 #pragma unroll
-        for (int u = 0; u < DT_READS; u++) {
-            t[u * DT_STRIDE + pc] = pa[u];
-            t[u * DT_STRIDE + pc + 1] = pb[u];
+        for (int u0 = 0; u0 < DT_READS; u0 += 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk >= 0) {
+#pragma unroll
+                for (int u = u0; u < u0 + 4; u++) {
+                    // c_apply_outlier_thresh over (x - shift) / scale (_c_helper.pyx:73-87, tombo_stats.py:560-573)
+                    // Every lane normalises the pair it loaded and stores it where it came from: past the
+                    // end of the read that is the (clamped) last pair again -- the same values to the same
+                    // place, also the last sample of a read of odd length -- and no branch splits the rows
+                    // (a store under `if` sat in a block of its own behind an LDS read: 1 000 cycles a row).
+                    // Dead rows store into the slack behind the signal buffer (s_st).
+                    const i64 k = chunk * CS_CHUNK + 2 * lane, n = s_n[u];
+                    const bool full = k + 1 < n, one = k < n;
+                    i64 kc = k < n - 2 ? k : n - 2;
+                    kc = kc < 0 ? 0 : kc;
+#if defined(TBA_DT_EXP) && (TBA_DT_EXP & 2)
+                    const double va = pa[u], vb = pb[u];   // (timing experiment: no normalisation)
+#else
+                    const double va = norm_one(pa[u], u), vb = norm_one(pb[u], u);
+#endif
+#if !(defined(TBA_DT_EXP) && (TBA_DT_EXP & 1))
+                    st2(norm + s_st[u] + kc, va, vb);
+#endif
+                    t[u * DT_STRIDE + pc] = one ? (full ? va : vb) : 0.0;
+                    t[u * DT_STRIDE + pc + 1] = full ? vb : 0.0;
+                }
+            }
+            if (next >= 0) {
+#pragma unroll
+                for (int u = u0; u < u0 + 4; u++) {
+                    const i64 k = next * CS_CHUNK + 2 * lane, n = s_n[u];
+                    const RawSamples<RT> x{raw + s_off[u]};
+                    i64 kc = k < n - 2 ? k : n - 2;    // (live reads have hundreds of samples; dead rows: n = 0)
+                    kc = kc < 0 ? 0 : kc;
+                    sig_pair(x, kc, pa[u], pb[u]);
+                }
+            }
         }
     };
-    // (fetch and drop of a tile sit inside ONE step, in the loader's branch: registers carried across
-    // the steps would be held through the greedy branch as well, and the kernel has none to spare)
-    if (wave == 1) { fetch(0); drop(DT_TILEP(0)); }
+#ifdef TBA_DT_INSTEP
+    if (wave == 1) { loader_step(-1, nullptr, 0); loader_step(0, DT_TILEP(0), -1); }
+#else
+    if (wave == 1) { loader_step(-1, nullptr, 0); loader_step(0, DT_TILEP(0), n_steps > 1 ? 1 : -1); }
+#endif
     __syncthreads();
 
     // ---- wave 0: the scan (lane = read)
@@ -173,7 +231,11 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
             }
             DT_T(0);
         } else if (wave == 1) {
-            if (i + 1 < n_steps) { fetch(i + 1); drop(DT_TILEP((i + 1) % 3)); }
+#ifdef TBA_DT_INSTEP
+            if (i + 1 < n_steps) { loader_step(-1, nullptr, i + 1); loader_step(i + 1, DT_TILEP((i + 1) % 3), -1); }
+#else
+            if (i + 1 < n_steps) loader_step(i + 1, DT_TILEP((i + 1) % 3), i + 2 < n_steps ? i + 2 : -1);
+#endif
             DT_T(1);
         } else if (i >= 1) {
             // tile j = i - 1: column t holds c[jC + 1 + t]; slot s = jC + t is the score whose window

@@ -11,7 +11,7 @@
 // file, resquiggle.py:1397); widening to float64 is exact, so every pass sees the values the
 // reference sees after its own int16 -> float64 promotion.
 // The read's `norm` slice serves as scratch (window lists) until the final pass writes the signal;
-// write_norm == 0: only the scale values are produced.
+// write_norm == 0: only the scale values are produced; 2: see below.
 // Medians: int16 input -> one counting pass (block_int_medians); float input -> one pass per
 // median through a sampled window (block_median_window); short reads and every failure of the
 // fast forms -> the generic bucket select (two passes per median).
@@ -155,7 +155,9 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_normalize(ReadState *rs, const De
     // The normalised signal is written once, at the end: the passes in between recompute
     // (x - shift) / scale on the fly (same operation, same bits).
     TBA_PHASE(2, 3);
-    if (write_norm) {
+    // write_norm == 2: only the reads whose normalised signal k_detect's loader (k_detect.h) will not
+    // write on its way: the long ones (k_long.h takes their scan)
+    if (write_norm == 1 || (write_norm == 2 && r.is_long)) {
         if (have_lims) {
             // c_apply_outlier_thresh, _c_helper.pyx:73-87
             block_map2<2>(n, x, y, [&](double xv) {

@@ -609,8 +609,6 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     HIP_TRY(hipEventRecord(e->ev[16], s));
     MARK(); // 0 normalize
     const bool fused_scores = 2 * P.running_stat_width <= 64; // cumsum + scores in one kernel
-    if (ON(TBA_STAGE_SEGMENT) && !rna)
-        RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0, 1)));
     // DNA defaults: the scores never reach memory (k_detect.h); what that form leaves (flagged reads)
     // goes through the kernels below as before
 #ifdef TBA_NO_FUSED_DETECT
@@ -629,12 +627,16 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     const bool fused_tt = rna && P.min_obs_per_base == 6 && P.running_stat_width <= TT_MAXW; // RNA defaults: radius 5
 #endif
     const int only_flagged = (fused_detect && !wg_scan) || fused_tt ? 1 : 0;
+    // (with k_detect on the way its loader writes the normalised signal: k_normalize only finds the
+    // scale values then, and normalises the long reads, which k_detect leaves to k_long.h)
+    if (ON(TBA_STAGE_SEGMENT) && !rna)
+        RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 0, fused_detect && !wg_scan ? 2 : 1)));
     MARK(); // 1 cumsum
     if (ON(TBA_STAGE_SEGMENT) && !rna && wg_scan) {
         k_cumsum_scores_long<double, 0><<<nb, 256, 0, s>>>(rs, e->d_order.as<i32>(), dp, e->d_norm.as<double>(), e->d_score.as<double>());
     } else if (ON(TBA_STAGE_SEGMENT) && !rna) {
         if (fused_detect) {
-            k_detect<2><<<(unsigned)((n + DT_READS - 1) / DT_READS), 256, 0, s>>>(rs, n, dp, e->d_norm.as<double>(), e->d_csum.as<double>(), e->d_score.as<double>());
+            RAW_DISPATCH(rdt, (k_detect<2, RT><<<(unsigned)((n + DT_READS - 1) / DT_READS), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_csum.as<double>(), e->d_score.as<double>(), e->S_tot)));
             k_pick<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_csum.as<double>(), e->d_score.as<double>(), e->d_cpts.as<i64>(), 0);
         }
         if (fused_scores) {
