@@ -349,7 +349,9 @@ def main():
                          'or by np.random.choice on the feeder thread (the seeded-parity mode)')
     ap.add_argument('--stream-batch', type=int, default=None,
                     help='reads per streamed batch (default: 10000 compact, 5000 full: its float64 outputs are page-locked per slot)')
-    ap.add_argument('--slots', type=int, default=3, help='engine slots per GPU of the streaming pipeline')
+    ap.add_argument('--slots', type=int, default=2,
+                    help='engine slots per GPU of the streaming pipeline (round 4: 2 slots 98.9 k reads/s end to end at '
+                         'cfg2, 3 slots 92.3 k -- the event-detection kernel fills a CU alone now; RNA 125 k vs 112 k)')
     ap.add_argument('--serial-compute', action='store_true',
                     help='streaming: kernel sequences of the slots back to back (tba_batch_wait_for) instead of interleaved')
     ap.add_argument('--resident-split', type=int, default=1,
@@ -382,8 +384,8 @@ def main():
     longtail = a.preset == 'longtail'
     if longtail and a.reads == 10000:
         a.reads = 16000   # enough work per pass to hide the serial time of a 200 kb read
-    if longtail and a.slots == 3:
-        a.slots = 4       # (measured: 3 -> 39.2 k, 4 -> 40.9 k, 6 -> 27 k reads/s end to end)
+    if longtail and a.slots == 2:
+        a.slots = 4       # (measured in round 3: 3 -> 39.2 k, 4 -> 40.9 k, 6 -> 27 k reads/s end to end)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

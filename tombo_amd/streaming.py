@@ -9,7 +9,7 @@ because different slots use different streams the copy engines move batch N+1 in
 out while the compute units work on batch N.  With page-locked host arrays (`PinnedArray`) the
 transfers are DMA and nothing blocks the host but `sync`.
 
-    pipe = StreamPipeline(std_ref, rsqgl_params, n_slots=3, outlier_thresh=5.0)
+    pipe = StreamPipeline(std_ref, rsqgl_params, n_slots=2, outlier_thresh=5.0)
     for res in pipe.run(batches):          # batches: iterable of ReadBatch
         ...res.results['status'], res.segs_of(i)...
 
@@ -146,7 +146,7 @@ class _Slot(object):
 class StreamPipeline(object):
     """`n_slots` engines on one GPU, used round-robin; see the module docstring."""
 
-    def __init__(self, std_ref, rsqgl_params, n_slots=3, device=None, outlier_thresh=None,
+    def __init__(self, std_ref, rsqgl_params, n_slots=2, device=None, outlier_thresh=None,
                  seq_samp_type=th.seqSampleType(DNA_SAMP_TYPE, False), const_scale=None,
                  skip_seq_scaling=False, max_raw_cpts=MAX_RAW_CPTS,
                  min_event_to_seq_ratio=MIN_EVENT_TO_SEQ_RATIO, want_norm=False,
