@@ -667,7 +667,11 @@ def resquiggle_batch_iters(map_results, std_ref, rsqgl_params, save_params=None,
 
     `device_prep`: `map_results` are the mapped reads as `_io_and_map_read` left them (RNA signal
     in acquisition order, no `stall_ints`) and `adjust_map_res` -- the flip and
-    `ts.identify_stalls` -- happens on the device inside every pass.
+    `ts.identify_stalls` -- happens on the device inside every pass.  (The device computes the stall
+    metric in float64 whatever the sample type; the reference's worker hands `identify_stalls` the
+    file's int16 samples and gets an int16-truncated metric: intervals within one unit of the
+    threshold or at the signal's edges can differ -- INTEGRATION.md section 6.  Pass `stall_ints`
+    on the reads, without `device_prep`, for the reference's own intervals.)
     """
     from ._default_parameters import MAX_SCALING_ITERS
     if max_scaling_iters is None:

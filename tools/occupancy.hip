@@ -6,8 +6,10 @@
 #include "../tombo_amd/csrc/tba_common.h"
 #include "../tombo_amd/csrc/k_select.h"
 #include "../tombo_amd/csrc/k_segment.h"
+#include "../tombo_amd/csrc/k_detect.h"
 #include "../tombo_amd/csrc/k_prep_raw.h"
 #include "../tombo_amd/csrc/k_dp.h"
+#include "../tombo_amd/csrc/k_tb_par.h"
 #include "../tombo_amd/csrc/k_dp_multi.h"
 #include "../tombo_amd/csrc/k_long.h"
 #include "../tombo_amd/csrc/k_tail.h"
@@ -33,8 +35,13 @@ int main()
     report("k_scores_ttest<double>", k_scores_ttest<double>, 256);
     report("k_peaks<2>", k_peaks<2>, SEL_NT);
     report("k_peaks<5>", k_peaks<5>, SEL_NT);
+    report("k_detect<2,double>", k_detect<2, double>, 256);
+    report("k_detect<2,int16_t>", k_detect<2, int16_t>, 256);
+    report("k_pick", k_pick, SEL_NT);
+    report("k_detect_tt<5,12,double>", k_detect_tt<5, 12, double>, SEL_NT);
     report("k_event_means<double>", k_event_means<double>, 256);
     report("k_dp<8,false>", k_dp<8, false>, 64);
+    report("k_dp8_lowreg", k_dp8_lowreg, 64);
     report("k_dp<5,false>", k_dp<5, false>, 64);
     report("k_dp<12,false>", k_dp<12, false>, 64);
     report("k_dp_multi<4,2>", k_dp_multi<4, 2>, 64);
@@ -46,6 +53,8 @@ int main()
     report("k_cumsum_scores_long<f64,0>", k_cumsum_scores_long<double, 0>, 256);
     report("k_main_tb_long", k_main_tb_long, 64);
     report("k_main_tb", k_main_tb, 64);
+    report("k_main_tb_par<16>", k_main_tb_par<16>, 64);
+    report("k_main_tb_par<64>", k_main_tb_par<64>, 64);
     report("k_skip_dp", k_skip_dp, 64);
     report("k_theil_sen", k_theil_sen, SEL_NT);
     report("k_rescale_absz<true>", k_rescale_absz<true>, 256);
