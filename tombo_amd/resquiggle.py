@@ -129,6 +129,8 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
         stream_min = int(os.environ.get('TBA_API_STREAM_MIN', '2400'))   # (tests lower it)
         if engine is None and n >= stream_min and os.environ.get('TBA_API_STREAM', '1') != '0':
             stream_cuts = max(3, min(12, n // max(2 * stream_min // 3, 1)))
+            if os.environ.get('TBA_API_CUTS'):     # (measurement aid)
+                stream_cuts = max(2, int(os.environ['TBA_API_CUTS']))
         slot_budget = mem_budget if stream_cuts == 1 else mem_budget / _STREAM_SLOTS
         host_cap = 1 << 28   # samples per sub-batch: 2 GiB of float64 each way in page-locked staging
         target = -(-n // stream_cuts)
@@ -197,6 +199,8 @@ def _stream_batches(engines, cuts, map_results, raws, pre_err, samp_inds, subsam
     # fill it alone) -- measured on 5 000 reads of 10 kb, three cuts: all three finished computing
     # together after 65 ms and only then 74 ms of downloads began.
     chain = bool(args['return_signal'])
+    if os.environ.get('TBA_API_CHAIN'):            # (measurement aid)
+        chain = os.environ['TBA_API_CHAIN'] == '1'
     with ThreadPoolExecutor(1) as ex:
         def unpack(ctx):
             _unpack_batch(ctx)
