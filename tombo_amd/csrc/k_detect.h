@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
 #pragma unroll
     for (int d = 0; d <= R; d++) prevX[d] = 0;
     int cb = 0;
+    double smin = INFINITY, smax = -INFINITY;        // range of the scores this lane emitted (k_pick's select)
 #if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 7
     i64 dt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
             for (u32 m = glane ? E : 0u; m != 0; m &= m - 1u) {
                 const int t = __ffs((int)m) - 1;
                 const double s = fabs(score_raw(t));
+                smin = s < smin ? s : smin; smax = s > smax ? s : smax;
                 dn[o] = s;
                 pn[o] = (i32)(slot0 + t - (w2 - 1));
                 o++;
@@ -418,10 +420,18 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
         if (wave == 2) { dbg[2] = dt_acc[3] + dt_acc[4] + dt_acc[5] + dt_acc[6]; dbg[3] = dt_acc[3]; dbg[4] = dt_acc[4]; dbg[5] = dt_acc[5]; dbg[6] = dt_acc[6]; dbg[7] = n_steps; }
     }
 #endif
+    if (wave >= 2) {                                  // the read's range: over its five lanes
+#pragma unroll
+        for (int dd = 1; dd < 5; dd++) {
+            const double a = shfl_f64(smin, (lane + dd) & 63), b = shfl_f64(smax, (lane + dd) & 63);
+            if (h == 0) { smin = a < smin ? a : smin; smax = b > smax ? b : smax; }
+        }
+    }
     if (wave >= 2 && glane && h == 0 && gn > 0) {
         ReadState &r = rs[gri];
         r.n_taken = (i64)s_cnt[q];
         r.ed_flag = s_bad[q];
+        r.ed_min = smin; r.ed_max = smax;
     }
 }
 
@@ -435,7 +445,6 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevPara
     __shared__ BucketSmem sm;
     __shared__ i64 s_w[SEL_NT / 64];
     __shared__ i32 s_tie[2048];
-    __shared__ u32 s_ntie;
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK || r.ed_flag) return;
     const int tid = threadIdx.x;
@@ -448,33 +457,129 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevPara
     const i64 n_taken = r.n_taken;
     if (ns <= 0 || num_cpts <= 0) { if (tid == 0) r.status = TBA_INTERNAL; return; }
     if (n_taken < num_cpts) { if (tid == 0) r.status = TBA_FEWER_CPTS; return; }
-    // range of the taken scores
-    double mn = INFINITY, mx = -INFINITY;
-    block_stream2<4>(n_taken, dn, [&](i64, double v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; });
-    for (int mm = 32; mm >= 1; mm >>= 1) {
-        double a = shfl_xor_f64(mn, mm), b2 = shfl_xor_f64(mx, mm);
-        mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
+    TBA_PHASE_T0(8);
+    // range of the taken scores: k_detect / k_detect_tt kept it
+    const double mn = r.ed_min, mx = r.ed_max;
+
+    __syncthreads();
+    // Score of the num_cpts-th best taken position (ascending rank n_taken - num_cpts) and, per
+    // wavefront chunk of the list (compact_chunk), the positions above / at it: the compaction
+    // starts from these counts.  The kernel is bound by its passes over the list (0.3 MB per 10 kb
+    // read, five passes = 6.6 TB/s when select, counts and a two-pass compaction each made their
+    // own), so the common case takes three: a histogram of the scores; one pass that counts the
+    // scores in the buckets above the threshold's and collects the members of that bucket with
+    // their wavefront (they decide the threshold and the rest of the counts); the emit.
+    __shared__ i32 s_gt[SEL_NT / 64], s_eq[SEL_NT / 64];
+    const int lane = tid & 63, wv = tid >> 6;
+    i64 c0, c1;
+    compact_chunk(n_taken, &c0, &c1);
+    const double scale = (double)BS_NB / (mx - mn);
+    bool fast = mx > mn && scale < 1e300 && n_taken > 192;
+    double tval = 0.0;
+    if (tid < SEL_NT / 64) { s_gt[tid] = 0; s_eq[tid] = 0; }
+    if (fast) {
+        if (tid == 0) { sm.nlev = 0; sm.k = n_taken - num_cpts; sm.cnt = n_taken; sm.n_cand = 0; }
+        for (int b = tid; b < BS_NB; b += SEL_NT) sm.hist[b] = 0;
+        __syncthreads();
+        for (i64 i0 = c0; i0 < c1; i0 += 64 * COMPACT_RB) {
+            double ld[COMPACT_RB];
+#pragma unroll
+            for (int k = 0; k < COMPACT_RB; k++) {
+                const i64 i = i0 + 64 * k + lane;
+                ld[k] = dn[i < c1 ? i : n_taken - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < COMPACT_RB; k++)
+                if (i0 + 64 * k + lane < c1) atomicAdd(&sm.hist[bs_bucket(ld[k], mn, scale)], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) bs_locate(&sm, 0, mn, scale);
+        __syncthreads();
+        fast = sm.cnt <= BS_CAP;
     }
-    if ((tid & 63) == 0) { sm.redd[2 * (tid >> 6)] = mn; sm.redd[2 * (tid >> 6) + 1] = mx; }
-    if (tid == 0) s_ntie = 0;
-    __syncthreads();
-    mn = sm.redd[0]; mx = sm.redd[1];
-    for (int qq = 1; qq < SEL_NT / 64; qq++) {
-        mn = sm.redd[2 * qq] < mn ? sm.redd[2 * qq] : mn;
-        mx = sm.redd[2 * qq + 1] > mx ? sm.redd[2 * qq + 1] : mx;
+    if (fast) {
+        // bs_bucket is monotone in the score: a higher bucket is a higher score
+        const int bk = sm.bk[0];
+        i32 above = 0;
+        for (i64 i0 = c0; i0 < c1; i0 += 64 * COMPACT_RB) {
+            double ld[COMPACT_RB];
+#pragma unroll
+            for (int k = 0; k < COMPACT_RB; k++) {
+                const i64 i = i0 + 64 * k + lane;
+                ld[k] = dn[i < c1 ? i : n_taken - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < COMPACT_RB; k++) {
+                const bool in = i0 + 64 * k + lane < c1;
+                const int b = bs_bucket(ld[k], mn, scale);
+                above += __popcll(__ballot(in && b > bk));
+                if (in && b == bk) { const u32 p = atomicAdd(&sm.n_cand, 1u); sm.cand[p] = ld[k]; s_tie[p] = wv; }
+            }
+        }
+        __syncthreads();
+        // rank the bucket's members (sm.cnt <= BS_CAP of them) by counting, as block_kth_fe does
+        const int m = (int)sm.cnt;
+        const i64 kk = sm.k;
+        for (int a = tid; a < m; a += SEL_NT) {
+            const double va = sm.cand[a];
+            int less = 0, eq_before = 0;
+            for (int b2 = 0; b2 < m; b2++) {
+                const double vb = sm.cand[b2];
+                less += vb < va;
+                eq_before += (vb == va) && (b2 < a);
+            }
+            if (less + eq_before == kk) sm.result = va;    // exactly one member has this rank
+        }
+        __syncthreads();
+        tval = sm.result;
+        for (int a = tid; a < m; a += SEL_NT) {
+            const double va = sm.cand[a];
+            if (va > tval) atomicAdd(&s_gt[s_tie[a]], 1);
+            if (va == tval) atomicAdd(&s_eq[s_tie[a]], 1);
+        }
+        if (lane == 0) atomicAdd(&s_gt[wv], above);
+    } else {
+        // (few or equal scores, or a crowded bucket: the general select, then the counts)
+        auto elems = [&](auto visit) {
+            constexpr int U = 8;
+            for (i64 base = 0; base < n_taken; base += (i64)U * SEL_NT) {
+                double vv[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const i64 i = base + (i64)u * SEL_NT + tid;
+                    vv[u] = dn[i < n_taken ? i : n_taken - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) visit(vv[u], base + (i64)u * SEL_NT + tid < n_taken);
+            }
+        };
+        tval = block_kth_fe(elems, n_taken, n_taken - num_cpts, mn, mx, &sm);
+        __syncthreads();
+        i32 gt = 0, eq = 0;
+        for (i64 i0 = c0; i0 < c1; i0 += 64 * COMPACT_RB) {
+            double ld[COMPACT_RB];
+#pragma unroll
+            for (int k = 0; k < COMPACT_RB; k++) {
+                const i64 i = i0 + 64 * k + lane;
+                ld[k] = dn[i < c1 ? i : n_taken - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < COMPACT_RB; k++) {
+                const bool in = i0 + 64 * k + lane < c1;
+                gt += __popcll(__ballot(in && ld[k] > tval));
+                eq += __popcll(__ballot(in && ld[k] == tval));
+            }
+        }
+        if (lane == 0) { s_gt[wv] = gt; s_eq[wv] = eq; }
     }
     __syncthreads();
-    // score of the num_cpts-th best taken position (ascending rank n_taken - num_cpts)
-    const double tval = block_kth([&](i64 i) { return dn[i]; }, n_taken, n_taken - num_cpts, mn, mx, &sm);
-    __syncthreads();
-    // taken above / at the threshold; the taken positions AT it, in position order
-    i64 c_gt = 0, c_eq = 0;
-    block_compact(
-        n_taken, [&](i64 i) { return dn[i]; },
-        [&](i64, double v) { c_gt += v > tval; c_eq += v == tval; return v == tval; },
-        [&](i64 i, i64 o) { if (o < 2048) s_tie[o] = pn[i]; }, s_w);
-    c_gt = block_sum_i64(c_gt, &sm.rad);
-    c_eq = block_sum_i64(c_eq, &sm.rad);
+    TBA_PHASE(8, 0);
+    i64 c_gt = 0, c_eq = 0, off = 0;
+    for (int q = 0; q < SEL_NT / 64; q++) {
+        if (q < wv) off += s_gt[q] + s_eq[q];
+        c_gt += s_gt[q]; c_eq += s_eq[q];
+    }
+    TBA_PHASE(8, 1);
     const i64 need_eq = num_cpts - c_gt;              // 1 <= need_eq <= c_eq
     // The reference raises when the rank of the last pick in the argsort order, + 1, reaches
     // num_cands (_c_helper.pyx:116-118).  That rank is below ns minus the positions that score
@@ -486,12 +591,28 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevPara
         if (tid == 0) r.ed_flag = 1;
         return;
     }
-    // ties on the threshold score fall to the higher index: the need_eq last of them
-    const i64 idx_thr = need_eq < c_eq ? (i64)s_tie[c_eq - need_eq] : -1;
-    block_compact(
-        n_taken, [&](i64 i) { return dn[i]; },
-        [&](i64 i, double v) { return v > tval || (v == tval && (i64)pn[i] >= idx_thr); },
-        [&](i64 i, i64 o) { if (o < num_cpts) cpts[o] = (i64)pn[i] + w; }, s_w);
+    // (the positions are fetched with the scores: a load inside the emit would be one memory
+    // round trip per row of 64 -- 51 in a row for a 10 kb read's wavefront)
+    struct SP { double v; i32 p; };
+    auto load = [&](i64 i) { return SP{dn[i], pn[i]}; };
+    auto emit = [&](i64, i64 o, SP e) { if (o < num_cpts) cpts[o] = (i64)e.p + w; };
+    if (need_eq == c_eq) {
+        // every position at the threshold is kept: the wavefronts' offsets are known
+        compact_chunk_emit(n_taken, off, load, [&](i64, SP e) { return e.v >= tval; }, emit);
+    } else {
+        // ties on the threshold score fall to the higher index: the need_eq last of them (rare:
+        // the tied positions are listed, in position order, only then)
+        block_compact(
+            n_taken, [&](i64 i) { return dn[i]; }, [&](i64, double v) { return v == tval; },
+            [&](i64 i, i64 o) { if (o < 2048) s_tie[o] = pn[i]; }, s_w);
+        __syncthreads();
+        const i64 idx_thr = (i64)s_tie[c_eq - need_eq];
+        block_compact_chunks(
+            n_taken, load, [&](i64, SP e) { return e.v > tval || (e.v == tval && (i64)e.p >= idx_thr); },
+            emit, s_w);
+    }
+    TBA_PHASE(8, 2);
+    TBA_PHASE_END(8);
     if (tid == 0) { r.n_cpts = num_cpts; r.n_ev = num_cpts - 1; }
 }
 
@@ -577,6 +698,7 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const De
     u32 prevT = 0, prev_emitted = 0, prevX[R + 1];
 #pragma unroll
     for (int d = 0; d <= R; d++) prevX[d] = 0;
+    double smin = INFINITY, smax = -INFINITY;            // range of the emitted scores (k_pick's select)
     for (int i = 0; i <= n_tiles; i++) {                 // (one more step finishes the carried word)
         const double *sb = sbuf[i & 1];
         const int P0 = i * TT_NEW;                       // first new position of the tile
@@ -691,7 +813,9 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const De
             u32 o = base + (u32)(inc - ce);
             for (u32 m = E; m != 0; m &= m - 1u) {
                 const int t = __ffs((int)m) - 1;
-                dn[o] = row[t];
+                const double sv = row[t];
+                smin = sv < smin ? sv : smin; smax = sv > smax ? sv : smax;
+                dn[o] = sv;
                 pn[o] = pos0 + t;
                 o++;
             }
@@ -703,5 +827,11 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const De
         }
         __syncthreads();
     }
-    if (tid == 0) { r.n_taken = (i64)s_cnt; r.ed_flag = s_bad; }
+    if (wave == 0) {
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+            const double a = shfl_xor_f64(smin, mm), b = shfl_xor_f64(smax, mm);
+            smin = a < smin ? a : smin; smax = b > smax ? b : smax;
+        }
+    }
+    if (tid == 0) { r.n_taken = (i64)s_cnt; r.ed_flag = s_bad; r.ed_min = smin; r.ed_max = smax; }
 }

@@ -283,7 +283,15 @@ struct BucketSmem {
     i64 n_le;            // number of elements <= result (valid when has_le)
     double redd[2 * (SEL_NT / 64)];
     SelectSmem rad;      // fallback
+#ifdef TBA_PHASE_DEBUG
+    i64 stamp[4];        // cycle counter after: histogram pass, bucket search, gather pass, ranking
+#endif
 };
+#ifdef TBA_PHASE_DEBUG
+#define BS_STAMP(i_) do { if (threadIdx.x == 0) sm->stamp[i_] = (i64)__builtin_readcyclecounter(); } while (0)
+#else
+#define BS_STAMP(i_) do { } while (0)
+#endif
 
 __device__ __forceinline__ int bs_bucket(double v, double lo, double scale)
 {
@@ -296,6 +304,38 @@ __device__ __forceinline__ bool bs_member(const BucketSmem *sm, int nlev, double
     for (int l = 0; l < nlev; l++)
         if (bs_bucket(v, sm->lo[l], sm->scale[l]) != sm->bk[l]) return false;
     return true;
+}
+
+// wave 0 (all 64 lanes): the histogram bucket that holds rank sm->k (BS_NB/64 bins per lane);
+// records it as level nlev and leaves the rank inside it / its member count in sm->k / sm->cnt.
+// (k_pick's copy of the search inside block_kth_fe: sharing one function moves k_normalize's
+// register allocation, which sits exactly on its 128-VGPR step, into spills)
+__device__ __forceinline__ void bs_locate(BucketSmem *sm, int nlev, double lo, double scale)
+{
+    const int tid = threadIdx.x;
+    const int per = BS_NB / 64;
+    i64 c = 0;
+    for (int q = 0; q < per; q++) c += sm->hist[tid * per + q];
+    i64 inc = c;
+    for (int d = 1; d < 64; d <<= 1) {
+        i64 t = shfl_i64(inc, tid - d < 0 ? 0 : tid - d);
+        if (tid >= d) inc += t;
+    }
+    i64 exc = inc - c, kk = sm->k;
+    if (exc <= kk && kk < inc) {
+        i64 acc = exc;
+        for (int q = 0; q < per; q++) {
+            u32 h = sm->hist[tid * per + q];
+            if (kk < acc + h) {
+                sm->bk[nlev] = tid * per + q;
+                sm->lo[nlev] = lo; sm->scale[nlev] = scale;
+                sm->k = kk - acc; sm->cnt = h;
+                break;
+            }
+            acc += h;
+        }
+        sm->nlev = nlev + 1;
+    }
 }
 
 // Element enumeration for block_kth: a functor fe(visit) must call visit(value, valid) for every
@@ -349,6 +389,7 @@ __device__ double block_kth_fe(FE fe, i64 n, i64 k, double lo, double hi, Bucket
             if (ok && bs_member(sm, nlev, v)) atomicAdd(&sm->hist[bs_bucket(v, lo, scale)], 1u);
         });
         __syncthreads();
+        BS_STAMP(0);
         if (tid < 64) { // wave 0: locate the bucket of rank k (BS_NB/64 bins per lane)
             const int per = BS_NB / 64;
             i64 c = 0;
@@ -376,6 +417,7 @@ __device__ double block_kth_fe(FE fe, i64 n, i64 k, double lo, double hi, Bucket
         }
         } // !small
         __syncthreads();
+        BS_STAMP(1);
         const i64 cnt = sm->cnt;
         const int nl = sm->nlev;
         if (cnt <= BS_CAP) {
@@ -386,6 +428,7 @@ __device__ double block_kth_fe(FE fe, i64 n, i64 k, double lo, double hi, Bucket
                 if (ok && bs_member(sm, nl, v)) { u32 p = atomicAdd(&sm->n_cand, 1u); if (p < BS_CAP) sm->cand[p] = v; }
             });
             __syncthreads();
+            BS_STAMP(2);
             const int m = (int)cnt;
             const i64 kk = sm->k;
             for (int a = tid; a < m; a += SEL_NT) {
@@ -409,6 +452,7 @@ __device__ double block_kth_fe(FE fe, i64 n, i64 k, double lo, double hi, Bucket
                 }
             }
             __syncthreads();
+            BS_STAMP(3);
             return sm->result;
         }
         // too many members: re-bucket them over their exact min / max
@@ -869,4 +913,74 @@ __device__ i64 block_compact(i64 n, Load load, Pred pred, Emit emit, i64 *s_w)
         __syncthreads();
     }
     return run;
+}
+
+// Ordered stream compaction with TWO workgroup barriers whatever n: every wavefront takes one
+// contiguous chunk of [0, n) (compact_chunk), counts its hits (pass 1: row ballots), the chunk totals
+// are exchanged once, and the hits are emitted in a second pass over the same chunk (the predicate is
+// evaluated twice: it must be pure).  block_compact above costs two barriers per 4 096 items -- 12
+// for the 23 k entries of a 10 kb read's taken list.  A caller that already has the wavefronts'
+// hit counts (k_pick: from its pass that counts the scores above the threshold) calls
+// compact_chunk_emit alone.
+#define COMPACT_RB 16 // rows of 64 whose loads are in flight together
+__device__ __forceinline__ void compact_chunk(i64 n, i64 *c0, i64 *c1)
+{
+    constexpr int NW = SEL_NT / 64;
+    const i64 chunk = (((n + NW - 1) / NW) + 63) & ~(i64)63;
+    *c0 = (i64)(threadIdx.x >> 6) * chunk;
+    *c1 = *c0 + chunk < n ? *c0 + chunk : n;
+}
+// this wavefront's hits go to emit(i, o, item) with o = off, off + 1, ... in index order
+template <class Load, class Pred, class Emit>
+__device__ __forceinline__ void compact_chunk_emit(i64 n, i64 off, Load load, Pred pred, Emit emit)
+{
+    const int lane = threadIdx.x & 63;
+    const u64 below = (1ull << lane) - 1ull;
+    i64 c0, c1;
+    compact_chunk(n, &c0, &c1);
+    i64 o = off;
+    for (i64 i0 = c0; i0 < c1; i0 += 64 * COMPACT_RB) {
+        decltype(load((i64)0)) ld[COMPACT_RB];
+#pragma unroll
+        for (int k = 0; k < COMPACT_RB; k++) {
+            const i64 i = i0 + 64 * k + lane;
+            ld[k] = load(i < c1 ? i : (n > 0 ? n - 1 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < COMPACT_RB; k++) {
+            const i64 i = i0 + 64 * k + lane;
+            const u64 m = __ballot(i < c1 && pred(i, ld[k]));
+            if ((m >> lane) & 1ull) emit(i, o + __popcll(m & below), ld[k]);
+            o += __popcll(m);
+        }
+    }
+}
+template <class Load, class Pred, class Emit>
+__device__ i64 block_compact_chunks(i64 n, Load load, Pred pred, Emit emit, i64 *s_w)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int NW = SEL_NT / 64;
+    i64 c0, c1;
+    compact_chunk(n, &c0, &c1);
+    i64 cnt = 0;
+    for (i64 i0 = c0; i0 < c1; i0 += 64 * COMPACT_RB) {
+        decltype(load((i64)0)) ld[COMPACT_RB];
+#pragma unroll
+        for (int k = 0; k < COMPACT_RB; k++) {
+            const i64 i = i0 + 64 * k + lane;
+            ld[k] = load(i < c1 ? i : (n > 0 ? n - 1 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < COMPACT_RB; k++) {
+            const i64 i = i0 + 64 * k + lane;
+            cnt += __popcll(__ballot(i < c1 && pred(i, ld[k])));
+        }
+    }
+    if (lane == 0) s_w[w] = cnt;
+    __syncthreads();
+    i64 off = 0, tot = 0;
+    for (int q = 0; q < NW; q++) { const i64 cc = s_w[q]; off += q < w ? cc : 0; tot += cc; }
+    compact_chunk_emit(n, off, load, pred, emit);
+    __syncthreads();
+    return tot;
 }

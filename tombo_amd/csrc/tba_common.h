@@ -25,12 +25,14 @@ typedef uint32_t u32;
 // three parts of k_peaks' tiles, summed over wave 0's tiles; 5: the parts of a k_dp row, summed
 // over the rows of the read)
 #ifdef TBA_PHASE_DEBUG
+#define TBA_PHASE_DEBUG_OR0 TBA_PHASE_DEBUG
 #define TBA_PHASE_T0(k_) const i64 tba_t0_ = (k_) == TBA_PHASE_DEBUG ? (i64)__builtin_readcyclecounter() : 0; \
     const i64 tba_w0_ = (k_) == TBA_PHASE_DEBUG ? (i64)__builtin_amdgcn_s_memrealtime() : 0
 // dbg[7]: the same interval on the constant 100 MHz counter (gives the shader clock of the run)
 #define TBA_PHASE_END(k_) do { if ((k_) == TBA_PHASE_DEBUG && threadIdx.x == 0) r.dbg[7] = (i64)__builtin_amdgcn_s_memrealtime() - tba_w0_; } while (0)
 #define TBA_PHASE(k_, i_) do { if ((k_) == TBA_PHASE_DEBUG && threadIdx.x == 0) r.dbg[i_] = (i64)__builtin_readcyclecounter() - tba_t0_; } while (0)
 #else
+#define TBA_PHASE_DEBUG_OR0 0
 #define TBA_PHASE_T0(k_) do { } while (0)
 #define TBA_PHASE(k_, i_) do { } while (0)
 #define TBA_PHASE_END(k_) do { } while (0)
@@ -55,6 +57,7 @@ struct ReadState {
     i32 tb_done;              // the main traceback of this read is finished (k_tb_par.h)
     i32 ed_flag, pad3;        // event detection: 1 = this read needs the kernels that keep the scores (k_detect.h)
     i64 n_taken;              // entries of the taken (score, position) list k_detect left
+    double ed_min, ed_max;    // ... and the range of its scores
     i64 n_cpts, n_ev;
     double start_res[4];      // (loc, events_per_base) of start-discovery call 0 / 1
     i64 mapped_start; double epb;
