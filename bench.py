@@ -325,6 +325,153 @@ def init_control_plane(rank, world):
     return dist
 
 
+def run_job(ctx, job_reads, batch_reads, n_bases, job_seed):
+    """One resquiggle job of `job_reads` DISTINCT synthetic reads (BASELINE.json cfg5): the job is
+    cut into batches of `batch_reads`, the ranks draw batch indices from the shared counter
+    (sharding.BatchQueue) and every drawn batch is synthesised on the drawing rank's device
+    (_native.Synth: read r of the job is a function of (job_seed, r) alone, whichever rank makes it,
+    whatever the batch size), copied device to device into a pipeline slot, resquiggled (Theil-Sen
+    subsample drawn on the device under a key of the batch index), and its compact results (64-byte
+    record + int32 boundaries per read) land in page-locked host memory.  Nothing is synthesised on
+    the host and no rank touches a batch it did not draw.  Collective over the ranks."""
+    _native, streaming, sharding = ctx['_native'], ctx['streaming'], ctx['sharding']
+    from tombo_amd import synth as synth_mod
+    model, dev, world, slots = ctx['model'], ctx['dev'], ctx['world'], ctx['slots']
+    n_batches = (job_reads + batch_reads - 1) // batch_reads
+    pipe = streaming.StreamPipeline(model, ctx['params'], n_slots=slots, device=dev, outlier_thresh=5.0,
+                                    seq_samp_type=ctx['samp'], want_norm=False, segs_dtype=np.int32,
+                                    subsample_seed=job_seed, in_order=True)
+    # a generator's batch must outlive the slot's copy of it: two generators per slot
+    gens = [_native.Synth(model, dev) for _ in range(2 * slots)]
+    sp = _native.make_synth_params(dac_per_pa=DAC_PER_PA, dac_offset=DAC_OFFSET, **synth_mod.DNA_SYNTH)
+    cnt = dict(reads=0, ok=0, nb=0, chk=0, gen_s=0.0, submit_s=0.0, out=0)
+    est = np.zeros(32)
+    drawn = []
+    state = dict(i=0)
+
+    def consume(res, count=True):
+        if res is None or not count:
+            return
+        r = res.results
+        ok = r['status'] == 0
+        cnt['reads'] += res.n
+        cnt['ok'] += int(ok.sum())
+        cnt['nb'] += 1
+        cnt['out'] += r.nbytes + res.segs.nbytes
+        est[:] += res.stage_ms
+        # a checksum of the batch that does not depend on who computed it: the records of the reads
+        # that succeeded + their last base boundary
+        last = np.asarray(res.segs)[np.asarray(res.seg_off[1:]) - 1].astype(np.int64)
+        cnt['chk'] += int(((r['read_start_rel_to_raw'] + r['norm_len'] + last) * ok).sum()) % (1 << 40)
+
+    def one(k, first_read, n_k, count=True):
+        g = gens[state['i'] % len(gens)]
+        state['i'] += 1
+        t0 = time.perf_counter()
+        raw, raw_off, seq, seq_off = g.generate(sp, job_seed, np.full(n_k, n_bases, np.int64),
+                                                raw_dtype=np.int16, first_read=first_read)
+        t1 = time.perf_counter()
+        b = streaming.ReadBatch(raw, raw_off, seq, seq_off, tag=k)
+        b.subsample_seed = (job_seed * 0x9E3779B97F4A7C15 + first_read) & 0xffffffffffffffff
+        done = pipe.submit(b)
+        if count:
+            cnt['gen_s'] += t1 - t0
+            cnt['submit_s'] += time.perf_counter() - t1
+        consume(done, count)
+
+    # warm-up: reads outside the job (behind its last read), every slot and generator sees a full batch
+    for w in range(2 * slots + 2):
+        one(-1 - w, job_reads + w * batch_reads, batch_reads, count=False)
+    for done in pipe.flush():
+        pass
+    algo_bytes, dp_cells = pipe.slots[0].eng.stats()
+    queue = sharding.BatchQueue(n_batches, key='distinct_read_job')
+    ctx['barrier']()
+    t0 = time.perf_counter()
+    for k in queue:
+        first = k * batch_reads
+        drawn.append((int(k), int(first)))
+        one(k, first, min(batch_reads, job_reads - first))
+    for done in pipe.flush():
+        consume(done)
+    ctx['dev_sync']()
+    my_dt = time.perf_counter() - t0
+    ctx['barrier']()
+    dt = ctx['max_over_ranks'](time.perf_counter() - t0)
+    tot = {k: ctx['sum_over_ranks'](float(cnt[k])) for k in ('reads', 'ok', 'nb', 'chk', 'out')}
+    pipe.close()
+    for g in gens:
+        g.close()
+    names = _native.STAGE_NAMES
+    nb = max(cnt['nb'], 1)
+    report = {
+        'what': 'one job of %d distinct synthetic 10 kb DNA reads (read r = f(job seed, r)), %d batches of <= %d '
+                'drawn from the host work queue by %d rank(s); each batch synthesised as int16 DAC samples on the '
+                'device of the rank that drew it, resquiggled, 64-byte record + int32 boundaries per read '
+                'downloaded to page-locked host memory' % (job_reads, n_batches, batch_reads, world),
+        'value': round(tot['reads'] / dt, 2), 'unit': 'reads/s', 'job_reads': int(job_reads),
+        'reads_done': int(tot['reads']), 'batches': int(tot['nb']), 'seconds': round(dt, 4),
+        'success_rate': round(tot['ok'] / max(tot['reads'], 1), 4),
+        'checksum_mod_2_40_summed': int(tot['chk']), 'job_seed': int(job_seed),
+        'out_GB': round(tot['out'] / 1e9, 3),
+        'host_s_in_generate_rank0': round(cnt['gen_s'], 4), 'host_s_in_submit_rank0': round(cnt['submit_s'], 4),
+        'stage_ms_per_batch_rank0': {k: round(float(v) / nb, 3) for k, v in zip(names, est[:16]) if v > 0}}
+    return dict(report=report, dt=dt, my_dt=my_dt, my_batches=cnt['nb'], my_reads=cnt['reads'], drawn=drawn,
+                stage=est / nb, algo_bytes=algo_bytes, dp_cells=dp_cells, n_batches=n_batches, tot=tot)
+
+
+def finish_cfg5(a, job, ctx, dist, json_fd, cpu_legs, dev_name, ndev, t_start, t_cpu, scaling):
+    """the JSON line of --preset cfg5 (rank 0 prints)"""
+    _native = ctx['_native']
+    rank, world = ctx['rank'], ctx['world']
+    rank_rec = dict(rank=rank, device=ctx['dev'], device_name=dev_name, steps=job['my_batches'],
+                    job_batches=job['my_batches'], job_reads=job['my_reads'],
+                    first_reads_drawn=[f for _, f in job['drawn']],
+                    reads_per_s=round(job['my_reads'] / job['my_dt'], 2) if job['my_dt'] > 0 else 0.0,
+                    busy_s=round(job['my_dt'], 4))
+    per_rank = [rank_rec]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, rank_rec)
+    if rank == 0:
+        rep = job['report']
+        sms = dict(zip(_native.STAGE_NAMES, [float(x) for x in job['stage'][:16]]))
+        grp = max(STAGE_GROUPS, key=lambda g: sum(sms.get(k, 0.0) for k in g[1]))
+        dom_ms = sum(sms.get(k, 0.0) for k in grp[1])
+        achieved = job['algo_bytes'] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        rates = [r['reads_per_s'] for r in per_rank if r['job_batches']]
+        res = {
+            'metric': 'resquiggle reads/s (10 kb DNA, bw=500)', 'value': rep['value'], 'unit': 'reads/s',
+            'n_gpus': world, 'steps': int(job['n_batches']), 'warmup': 2 * a.slots + 2,
+            'ms_per_step': round(job['dt'] / max(job['n_batches'], 1) * 1e3, 3), 'higher_is_better': True,
+            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': rep['what'], 'job_reads': rep['job_reads'], 'reads_per_batch': a.reads,
+                       'bases': int(a.bases), 'bandwidth': a.bandwidth, 'success_rate': rep['success_rate'],
+                       'parallelism': 'batches of one job sharded over %d process(es) through a shared batch '
+                                      'counter; no collective on the data path, gloo control plane' % world,
+                       'devices': [r['device'] for r in per_rank], 'visible_devices': ndev,
+                       'ranks_share_devices': ndev < world,
+                       'setup_s': {'synthesis': 0.0, 'cpu_legs': round(t_cpu, 1),
+                                   'total_wall': round(time.perf_counter() - t_start, 1)},
+                       'stage_ms': {k: round(v, 3) for k, v in sms.items() if v > 0}},
+            'per_rank': per_rank,
+            'per_rank_reads_per_s': {'min': min(rates) if rates else None, 'max': max(rates) if rates else None},
+            'distinct_read_job': rep,
+            'roofline': {'bound': 'hbm', 'kernel': grp[2], 'stage_group': grp[0],
+                         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'traffic_scope': 'not measured in the job form (the cfg2 line carries the counter passes)',
+                         'algorithmic_bytes_per_launch': job['algo_bytes'], 'kernel_ms': round(dom_ms, 3)},
+        }
+        if cpu_legs:
+            res['cpu_baseline'] = dict(cpu_legs[0], cpu=cpu_model(),
+                                       all_cores=cpu_legs[1] if len(cpu_legs) > 1 else None)
+        os.write(json_fd, (json.dumps(res) + '\n').encode())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -336,10 +483,16 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=150, help='reads of the 1-thread CPU leg')
     ap.add_argument('--cpu-per-core', type=int, default=4, help='reads per core of the all-core CPU leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--preset', choices=['cfg2', 'cfg3', 'cfg1', 'cfg4', 'longtail'], default=None,
+    ap.add_argument('--preset', choices=['cfg2', 'cfg3', 'cfg1', 'cfg4', 'cfg5', 'longtail'], default=None,
                     help='BASELINE.json configs: cfg2 10kb/W=500 (default), cfg3 10kb/W=300, '
-                         'cfg1 2kb/W=100, cfg4 RNA 3kb/W=500; longtail: log-normal 1-200 kb DNA '
-                         'reads (median 8 kb), W=500, batches cut by the planner')
+                         'cfg1 2kb/W=100, cfg4 RNA 3kb/W=500; cfg5: one job of --job-reads DISTINCT 10 kb '
+                         'DNA reads (W=500) drawn batch by batch from the host work queue, every batch '
+                         'synthesised on the device of the rank that drew it; longtail: log-normal '
+                         '1-200 kb DNA reads (median 8 kb), W=500, batches cut by the planner')
+    ap.add_argument('--job-reads', type=int, default=None,
+                    help='cfg5: reads of the whole job (default 125000 per rank = a million on 8 GPUs; '
+                         'given explicitly the job is fixed and the scaling strong)')
+    ap.add_argument('--job-seed', type=int, default=20260927, help='cfg5: seed of the job (read r of the job is a function of (seed, r) alone)')
     ap.add_argument('--e2e', choices=['compact', 'full', 'none'], default='compact',
                     help='end-to-end (reads in -> results out) measurement: int16 in / records + '
                          'int32 boundaries out, float64 in / float64 signal + int64 boundaries '
@@ -381,6 +534,9 @@ def main():
         a.bases, a.bandwidth = 2000, 100
     elif a.preset == 'cfg4':
         samp_name, a.bases, a.bandwidth = 'RNA', 3000, 500
+    cfg5 = a.preset == 'cfg5'
+    if cfg5:
+        a.bases, a.bandwidth = 10000, 500
     longtail = a.preset == 'longtail'
     if longtail and a.reads == 10000:
         a.reads = 16000   # enough work per pass to hide the serial time of a 200 kb read
@@ -418,11 +574,14 @@ def main():
     bases = longtail_bases(a.reads, seed0, a.longtail_max_bases) if longtail else np.full(a.reads, a.bases, np.int64)
     want_dac = a.e2e == 'compact' or a.api_reads > 0
     t_gen = time.perf_counter()
-    seqs, raws, dacs = make_reads(bases, seed0, workers, samp_name, want_dac)
+    if cfg5:   # no rank synthesises anything on the host: every batch of the job is drawn on the device
+        seqs, raws, dacs = [], [], []
+    else:
+        seqs, raws, dacs = make_reads(bases, seed0, workers, samp_name, want_dac)
     t_gen = time.perf_counter() - t_gen
     rng = np.random.RandomState(12345 + rank)
     si = np.zeros((a.reads, 1000), np.int64)
-    for i in range(a.reads):
+    for i in range(a.reads if not cfg5 else 0):
         if bases[i] > 1000:
             si[i] = rng.choice(int(bases[i]), 1000, replace=False)
     if not (bases > 1000).any():
@@ -483,6 +642,17 @@ def main():
     p = _native.make_params(params)
     o = _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name],
                           stall_params=stall_params)
+
+    if cfg5 or (world > 1 and not longtail and not rna and a.bandwidth == 500 and a.bases == 10000):
+        # the job of BASELINE.json's cfg5: distinct reads, made on the device batch by batch
+        job_reads = a.job_reads if (cfg5 and a.job_reads) else (125000 if cfg5 else 4 * a.reads) * world
+        ctx = dict(_native=_native, streaming=streaming, sharding=sharding, model=model, params=params, samp=samp,
+                   dev=dev, rank=rank, world=world, barrier=barrier, max_over_ranks=max_over_ranks,
+                   sum_over_ranks=sum_over_ranks, dev_sync=dev_sync, slots=a.slots)
+    if cfg5:
+        job = run_job(ctx, job_reads, a.reads, a.bases, a.job_seed)
+        return finish_cfg5(a, job, ctx, dist, json_fd, cpu_legs, dev_name, ndev, t_start, t_cpu,
+                           'strong' if a.job_reads else 'weak')
 
     # ---- phase 1: resident ---------------------------------------------------------------
     # one engine per planned batch (the uniform presets are a single batch); a pass = every
@@ -753,6 +923,12 @@ def main():
                                              'p90': round(float(np.percentile(lat[4:], 90)) * 1e3, 3),
                                              'calls': len(lat) - 4}
 
+    # ---- phase 4 (N > 1, the default configuration): a short job of distinct reads ---------------
+    job = None
+    if world > 1 and not longtail and not rna and a.bandwidth == 500 and a.bases == 10000:
+        job = run_job(ctx, job_reads, a.reads, a.bases, a.job_seed)
+        rank_rec.update(job_batches=job['my_batches'], job_reads=job['my_reads'])
+
     per_rank = [rank_rec]
     if dist is not None:
         per_rank = [None] * world
@@ -828,6 +1004,7 @@ def main():
             'per_rank_reads_per_s': {'min': min(rates) if rates else None, 'max': max(rates) if rates else None},
             'end_to_end': e2e,
             'api': api,
+            'distinct_read_job': None if job is None else job['report'],
             'roofline': {'bound': 'hbm', 'kernel': grp[2], 'stage_group': grp[0],
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 5),

@@ -170,7 +170,9 @@ int tba_batch_upload(tba_engine *e, const tba_params *p, const tba_opts *o, int6
 /* Same with a typed raw buffer (TBA_RAW_*), enqueue only: every copy is issued on the engine's
  * stream and the call returns; the caller's buffers (raw, seq, sv_in, samp_ind, stall_ints) must
  * stay valid and unchanged until tba_batch_sync / tba_batch_query reports the engine idle.
- * tba_batch_upload == this with TBA_RAW_F64 followed by tba_batch_sync. */
+ * tba_batch_upload == this with TBA_RAW_F64 followed by tba_batch_sync.
+ * raw and seq may also be device memory of the engine's GPU (a batch made by tba_synth_generate):
+ * the copy kind is taken from the pointers. */
 int tba_batch_upload_async(tba_engine *e, const tba_params *p, const tba_opts *o, int64_t n_reads,
                            const void *raw, int raw_dtype, const int64_t *raw_off,
                            const uint8_t *seq, const int64_t *seq_off,
@@ -421,10 +423,41 @@ int tba_pack_reads(int64_t n_reads, const void *const *raw_ptrs, int raw_dtype, 
 int tba_unpack_reads(int64_t n_reads, const void *src, int64_t elem_bytes, const int64_t *src_off,
     const int64_t *count, void *const *dst_ptrs, int n_threads);
 
+/* ---- synthetic reads made on the device (bench / test support) ---------------------------------
+ * No counterpart in the reference: its benchmark input is a directory of FAST5 files.  The
+ * multi-GPU job of BASELINE.json (a million distinct 10 kb reads through a host work queue) cannot
+ * be synthesised on the host cores inside a benchmark's set-up, so every batch of that job is
+ * drawn on the device from a counter-based generator keyed by (seed, first_read + read, element):
+ * the reads of tombo_amd/synth.py (uniform ACGT, level = the model's k-mer mean, dwell =
+ * max(min_dwell, Geometric(1 / mean_dwell)), level + noise per sample, n_lead / n_trail samples
+ * of open-pore-like signal around them), reproducible on any rank and bit for bit by the numpy
+ * restatement tombo_amd.synth.device_reads_reference (csrc/k_synth.h states the draws). */
+typedef struct tba_synth tba_synth;
+typedef struct {
+    int64_t mean_dwell, min_dwell, n_lead, n_trail;
+    double scale, offset, noise_sd;   /* pA = (level + noise * noise_sd) * scale + offset */
+    double dac_per_pa, dac_offset;    /* TBA_RAW_I16: rint(pA * dac_per_pa + dac_offset) */
+    int32_t reverse, pad;             /* reverse: samples in acquisition order of a 3'->5' (RNA) run */
+} tba_synth_params;
+int tba_synth_create(int device, const double *kmer_means, int64_t kmer_width, tba_synth **out);
+void tba_synth_destroy(tba_synth *g);
+/* n_reads reads of n_bases[i] bases (sequence: n_bases[i] + kmer_width - 1 codes), raw_dtype
+ * TBA_RAW_I16 or TBA_RAW_F64.  Returns when the batch is in device memory: raw_off / seq_off
+ * (n_reads + 1, host) get its CSR offsets, *d_raw / *d_seq the device arrays (owned by the
+ * generator, valid until its next call) -- tba_batch_upload_async takes them in place of host
+ * arrays. */
+int tba_synth_generate(tba_synth *g, const tba_synth_params *p, uint64_t seed, int64_t first_read,
+    int64_t n_reads, const int64_t *n_bases, int raw_dtype, int64_t *raw_off, int64_t *seq_off,
+    const void **d_raw, const uint8_t **d_seq);
+/* the last generated batch to host memory (either may be NULL) */
+int tba_synth_download(tba_synth *g, void *raw, uint8_t *seq);
+/* host only: the generator's dwell thresholds (n <= 256) and noise constant under p */
+int tba_synth_dwell_thresholds(const tba_synth_params *p, uint32_t *thr, int64_t n, double *noise_norm);
+
 /* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build, out[3]
  * (n >= 4) = TBA_ABI_VERSION: lets a binding without a C compiler (ctypes) check its struct mirrors
  * and refuse a stale build of the library */
-#define TBA_ABI_VERSION 4
+#define TBA_ABI_VERSION 5
 int tba_abi_sizes(int64_t *out, int64_t n);
 
 /* self-test: out[t] = index t of the subsample tba_opts.device_subsample draws for read

@@ -87,5 +87,23 @@ def install(_native):
         def close(self):
             pass
 
+    class StubSynth(object):
+        """_native.Synth without a device: offsets only (lead 200 + 9 samples per base + trail 100)"""
+        calls = []
+
+        def __init__(self, std_ref, device=0):
+            self.device = device
+
+        def generate(self, sp, seed, n_bases, raw_dtype=np.int16, first_read=0):
+            nb = np.asarray(n_bases, np.int64)
+            StubSynth.calls.append((int(seed), int(first_read), int(nb.shape[0])))
+            raw_off = np.concatenate([[0], np.cumsum(300 + 9 * nb)]).astype(np.int64)
+            seq_off = np.concatenate([[0], np.cumsum(nb + K - 1)]).astype(np.int64)
+            return None, raw_off, None, seq_off
+
+        def close(self):
+            pass
+
     _native.Engine = StubEngine
     _native.PinnedArray = StubPinned
+    _native.Synth = StubSynth

@@ -72,3 +72,29 @@ def test_four_ranks_under_torch_distributed_run():
     assert r['n_gpus'] == 4 and r['steps'] == 3 and [x['rank'] for x in r['per_rank']] == [0, 1, 2, 3]
     assert sum(x['steps'] for x in r['per_rank']) == 12
     assert r['cpu_baseline']['value'] > 0 and r['roofline']['frac'] > 0
+
+
+def test_cfg5_job_hands_out_every_distinct_batch_once():
+    """--preset cfg5: the job's batches are keyed by their first read (read r of the job is a function
+    of (job seed, r) alone); two ranks draw every batch exactly once between them and nobody
+    synthesises anything on the host"""
+    r = _run(['--gpus', '2', '--preset', 'cfg5', '--job-reads', '47', '--reads', '5'])
+    assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['unit'] == 'reads/s'
+    job = r['distinct_read_job']
+    assert job['job_reads'] == 47 and job['reads_done'] == 47 and job['batches'] == 10
+    firsts = sorted(f for x in r['per_rank'] for f in x['first_reads_drawn'])
+    assert firsts == list(range(0, 47, 5))               # distinct seeds (first reads), each once
+    assert sum(x['job_reads'] for x in r['per_rank']) == 47
+    assert sum(x['job_batches'] for x in r['per_rank']) == 10
+    assert r['config']['setup_s']['synthesis'] == 0.0
+    assert r['cpu_baseline']['value'] > 0 and r['roofline']['frac'] > 0
+    # the default job size: 125 000 reads per rank (a million on eight), weak scaling
+    r = _run(['--preset', 'cfg5', '--reads', '25000'])
+    assert r['scaling'] == 'weak' and r['distinct_read_job']['job_reads'] == 125000 and r['steps'] == 5
+
+
+def test_default_two_rank_run_carries_the_distinct_read_job():
+    r = _run(['--gpus', '2', '--bases', '10000', '--reads', '3', '--cpu-sample', '1'])
+    job = r['distinct_read_job']
+    assert job['job_reads'] == 24 and job['reads_done'] == 24 and job['batches'] == 8
+    assert sum(x['job_reads'] for x in r['per_rank']) == 24

@@ -89,7 +89,7 @@ STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, S
 PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
     PUT_START_STATE = range(1, 8)
 MAX_BAND = 3072
-ABI_VERSION = 4  # TBA_ABI_VERSION of include/tombo_amd.h
+ABI_VERSION = 5  # TBA_ABI_VERSION of include/tombo_amd.h
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
                "rescale_score", "stalls", "total"]
@@ -294,9 +294,11 @@ class Engine(object):
         seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
         n = raw_off.shape[0] - 1
         self.n = n
-        if raw.dtype not in RAW_DTYPES or not raw.flags.c_contiguous:
-            raw = np.ascontiguousarray(raw, dtype=np.float64)
-        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        on_device = isinstance(raw, DeviceArray)   # (a Synth batch: copied device to device)
+        if not on_device:
+            if raw.dtype not in RAW_DTYPES or not raw.flags.c_contiguous:
+                raw = np.ascontiguousarray(raw, dtype=np.float64)
+            seq = np.ascontiguousarray(seq, dtype=np.uint8)
         K = self.kmer_width
         self.raw_off, self.seq_off = raw_off, seq_off
         self.B = np.maximum(np.diff(seq_off) - K + 1, 0)
@@ -320,9 +322,10 @@ class Engine(object):
         self._keep = (raw, seq, raw_off, seq_off, svi, svf, si, st, sto)
         self.skip_norm_out = bool(opts.skip_norm_out)
         self._check(self._L.tba_batch_upload_async(
-            self._h, C.byref(params), C.byref(opts), i64(n), raw.ctypes.data_as(C.c_void_p),
+            self._h, C.byref(params), C.byref(opts), i64(n),
+            C.c_void_p(raw.ptr) if on_device else raw.ctypes.data_as(C.c_void_p),
             C.c_int(RAW_DTYPES[raw.dtype]), _p(raw_off, i64),
-            _p(seq, C.c_uint8), _p(seq_off, i64), _p(svi, f64), _p(svf, i32), _p(si, i64),
+            C.cast(C.c_void_p(seq.ptr), C.POINTER(C.c_uint8)) if on_device else _p(seq, C.c_uint8), _p(seq_off, i64), _p(svi, f64), _p(svf, i32), _p(si, i64),
             _p(st, i64), _p(sto, i64)), 'tba_batch_upload_async')
         self.n_raw_total = int(raw_off[-1])
         if wait:
@@ -496,6 +499,90 @@ class Engine(object):
         a, c = f64(0), f64(0)
         self._check(self._L.tba_batch_stats(self._h, C.byref(a), C.byref(c)), 'tba_batch_stats')
         return a.value, c.value
+
+
+class DeviceArray(object):
+    """A flat array in device memory owned by someone else (a Synth's last batch): address, element
+    type, element count.  Engine.upload_packed takes it in place of a numpy array."""
+
+    def __init__(self, ptr, dtype, size, owner=None):
+        self.ptr, self.dtype, self.size, self.owner = int(ptr or 0), np.dtype(dtype), int(size), owner
+        self.nbytes = self.size * self.dtype.itemsize
+        self.shape = (self.size,)
+
+
+class SynthParams(C.Structure):
+    _fields_ = [('mean_dwell', i64), ('min_dwell', i64), ('n_lead', i64), ('n_trail', i64),
+                ('scale', f64), ('offset', f64), ('noise_sd', f64), ('dac_per_pa', f64), ('dac_offset', f64),
+                ('reverse', i32), ('pad', i32)]
+
+
+def make_synth_params(mean_dwell=9, min_dwell=2, scale=12.0, offset=90.0, noise_sd=0.25, n_lead=200,
+                      n_trail=100, dac_per_pa=1.0 / 0.1709, dac_offset=10.0, reverse=False):
+    """tba_synth_params: the keywords of synth.DNA_SYNTH / RNA_SYNTH + the digitisation"""
+    return SynthParams(int(mean_dwell), int(min_dwell), int(n_lead), int(n_trail), float(scale), float(offset),
+                       float(noise_sd), float(dac_per_pa), float(dac_offset), int(bool(reverse)), 0)
+
+
+def synth_tables(sp):
+    """(dwell thresholds uint32[256], noise constant) of the device generator under `sp` (host only)"""
+    thr = np.zeros(256, np.uint32)
+    c = f64(0.0)
+    rc = lib().tba_synth_dwell_thresholds(C.byref(sp), _p(thr, C.c_uint32), i64(256), C.byref(c))
+    if rc != 0:
+        raise EngineError('tba_synth_dwell_thresholds failed (%d): %s' % (rc, lib().tba_last_error().decode()))
+    return thr, float(c.value)
+
+
+class Synth(object):
+    """Synthetic reads drawn on the device (tba_synth_*, csrc/k_synth.h): a batch is a function of
+    (seed, first_read, lengths, parameters) alone."""
+
+    def __init__(self, std_ref, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        km = np.ascontiguousarray(std_ref.level_means, dtype=np.float64)
+        rc = self._L.tba_synth_create(C.c_int(device), _p(km, f64), i64(int(std_ref.kmer_width)), C.byref(self._h))
+        if rc != 0:
+            raise EngineError('tba_synth_create failed (%d): %s' % (rc, self._L.tba_last_error().decode()))
+        self.device = int(device)
+
+    def generate(self, sp, seed, n_bases, raw_dtype=np.int16, first_read=0):
+        """-> (raw DeviceArray, raw_off int64[n+1], seq DeviceArray, seq_off int64[n+1]); the device
+        arrays are valid until the next call"""
+        nb = np.ascontiguousarray(n_bases, dtype=np.int64)
+        n = nb.shape[0]
+        raw_off, seq_off = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        d_raw, d_seq = C.c_void_p(), C.c_void_p()
+        rc = self._L.tba_synth_generate(
+            self._h, C.byref(sp), C.c_uint64(int(seed) & 0xffffffffffffffff), i64(int(first_read)), i64(n),
+            _p(nb, i64), C.c_int(RAW_DTYPES[np.dtype(raw_dtype)]), _p(raw_off, i64), _p(seq_off, i64),
+            C.byref(d_raw), C.byref(d_seq))
+        if rc != 0:
+            raise EngineError('tba_synth_generate failed (%d): %s' % (rc, self._L.tba_last_error().decode()))
+        self._last = (np.dtype(raw_dtype), int(raw_off[-1]), int(seq_off[-1]))
+        return (DeviceArray(d_raw.value, raw_dtype, raw_off[-1], self), raw_off,
+                DeviceArray(d_seq.value, np.uint8, seq_off[-1], self), seq_off)
+
+    def download(self):
+        """the last batch as host arrays (raw, seq codes)"""
+        dt, n_raw, n_seq = self._last
+        raw, seq = np.empty(n_raw, dt), np.empty(n_seq, np.uint8)
+        rc = self._L.tba_synth_download(self._h, raw.ctypes.data_as(C.c_void_p), _p(seq, C.c_uint8))
+        if rc != 0:
+            raise EngineError('tba_synth_download failed (%d): %s' % (rc, self._L.tba_last_error().decode()))
+        return raw, seq
+
+    def close(self):
+        if self._h:
+            self._L.tba_synth_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def identify_stalls(eng, raw, sp):

@@ -13,6 +13,7 @@
 #include "k_dp_wg.h"
 #include "k_tail.h"
 #include "k_cabi.h"
+#include "k_synth.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -467,8 +468,9 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
     memcpy(e->h_dp.p, &e->hp, sizeof(DevParams));
     HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.p, N * sizeof(ReadState), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(e->d_dp.p, e->h_dp.p, sizeof(DevParams), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(e->d_raw.p, raw, (size_t)e->S_tot * raw_elem_bytes(raw_dtype), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(e->d_seq.p, seq, (size_t)e->seq_tot, hipMemcpyHostToDevice, s));
+    // (raw / seq may be device memory -- a batch made by tba_synth_generate: the kind is taken from the pointer)
+    HIP_TRY(hipMemcpyAsync(e->d_raw.p, raw, (size_t)e->S_tot * raw_elem_bytes(raw_dtype), hipMemcpyDefault, s));
+    HIP_TRY(hipMemcpyAsync(e->d_seq.p, seq, (size_t)e->seq_tot, hipMemcpyDefault, s));
     if (e->have_sv) HIP_TRY(hipMemcpyAsync(e->d_sv_in.p, sv_in, N * 32, hipMemcpyHostToDevice, s));
     if (e->have_samp)
         HIP_TRY(hipMemcpyAsync(e->d_samp.p, samp_ind, N * MAX_TS_POINTS * 8, hipMemcpyHostToDevice, s));
@@ -1828,6 +1830,152 @@ extern "C" int tba_pack_reads(int64_t n_reads, const void *const *raw_ptrs, int 
 }
 
 // sizeof of the ABI structs, so that a binding can check its mirrors without a C compiler
+// ---- synthetic reads on the device (k_synth.h) --------------------------------------------------
+struct tba_synth {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    i64 kmer_width = 0;
+    i64 n_reads = 0, S_tot = 0, seq_tot = 0;
+    int raw_dtype = TBA_RAW_I16;
+    DevBuf d_kmeans, d_sp, d_seq_off, d_base_off, d_raw_off, d_seq, d_starts, d_nraw, d_raw;
+    PinBuf h_sp, h_off, h_nraw;
+};
+
+extern "C" int tba_synth_create(int device, const double *kmer_means, int64_t kmer_width, tba_synth **out)
+{
+    if (!out || !kmer_means || kmer_width < 1 || kmer_width > 12) return set_err(TBA_E_ARG, "bad arguments");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return set_err(TBA_E_HIP, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    tba_synth *g = new tba_synth();
+    g->device = device;
+    g->kmer_width = kmer_width;
+    const size_t n = (size_t)1 << (2 * kmer_width);
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess || g->d_kmeans.ensure(n * 8) ||
+        hipMemcpy(g->d_kmeans.p, kmer_means, n * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        g->d_kmeans.release();
+        if (g->stream) (void)hipStreamDestroy(g->stream);
+        delete g;
+        return set_err(TBA_E_HIP, "tba_synth_create: stream / model upload failed");
+    }
+    *out = g;
+    return 0;
+}
+
+extern "C" void tba_synth_destroy(tba_synth *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    (void)hipStreamSynchronize(g->stream);
+    for (DevBuf *b : {&g->d_kmeans, &g->d_sp, &g->d_seq_off, &g->d_base_off, &g->d_raw_off, &g->d_seq,
+                      &g->d_starts, &g->d_nraw, &g->d_raw})
+        b->release();
+    g->h_sp.release(); g->h_off.release(); g->h_nraw.release();
+    (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+// the dwell thresholds and the noise constant of k_synth.h (plain IEEE operations only: the numpy
+// restatement builds the same values)
+static void synth_fill(SynthParams &sp, const tba_synth_params *p, i64 kmer_width)
+{
+    memset(&sp, 0, sizeof(sp));
+    sp.mean_dwell = p->mean_dwell; sp.min_dwell = p->min_dwell; sp.n_lead = p->n_lead; sp.n_trail = p->n_trail;
+    sp.scale = p->scale; sp.offset = p->offset; sp.noise_sd = p->noise_sd;
+    sp.dac_per_pa = p->dac_per_pa; sp.dac_offset = p->dac_offset;
+    sp.noise_norm = 1.0 / std::sqrt((65536.0 * 65536.0 - 1.0) / 3.0);
+    sp.reverse = p->reverse; sp.kmer_width = (i32)kmer_width;
+    const double q = 1.0 - 1.0 / (double)p->mean_dwell;
+    double t = 1.0;
+    for (int k = 0; k < SYNTH_DWELL_MAX; k++) {
+        t = t * q;                                   // q^(k+1) = P(dwell > k + 1)
+        const double v = std::floor(4294967296.0 * (1.0 - t));
+        sp.thr[k] = v >= 4294967295.0 ? 0xffffffffu : (u32)v;
+    }
+}
+
+extern "C" int tba_synth_dwell_thresholds(const tba_synth_params *p, uint32_t *thr, int64_t n, double *noise_norm)
+{
+    if (!p || !thr || n < 0 || p->mean_dwell < 1) return set_err(TBA_E_ARG, "bad arguments");
+    SynthParams sp;
+    synth_fill(sp, p, 1);
+    for (i64 k = 0; k < n && k < SYNTH_DWELL_MAX; k++) thr[k] = sp.thr[k];
+    if (noise_norm) *noise_norm = sp.noise_norm;
+    return 0;
+}
+
+extern "C" int tba_synth_generate(tba_synth *g, const tba_synth_params *p, uint64_t seed, int64_t first_read,
+                                  int64_t n_reads, const int64_t *n_bases, int raw_dtype,
+                                  int64_t *raw_off, int64_t *seq_off, const void **d_raw, const uint8_t **d_seq)
+{
+    if (!g || !p || n_reads <= 0 || !n_bases || !raw_off || !seq_off || !d_raw || !d_seq)
+        return set_err(TBA_E_ARG, "bad arguments");
+    if (raw_dtype != TBA_RAW_I16 && raw_dtype != TBA_RAW_F64) return set_err(TBA_E_ARG, "raw dtype must be TBA_RAW_I16 or TBA_RAW_F64");
+    if (p->mean_dwell < 1 || p->min_dwell < 1 || p->min_dwell > SYNTH_DWELL_MAX || p->n_lead < 0 || p->n_trail < 0)
+        return set_err(TBA_E_ARG, "bad synthesis parameters");
+    HIP_TRY(hipSetDevice(g->device));
+    const i64 n = n_reads, K = g->kmer_width;
+    hipStream_t s = g->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    const size_t N = (size_t)n;
+    if (g->h_sp.ensure(sizeof(SynthParams)) || g->h_off.ensure(3 * (N + 1) * 8) || g->h_nraw.ensure(N * 8)) return TBA_E_NOMEM;
+    synth_fill(*g->h_sp.as<SynthParams>(), p, K);
+    i64 *h_seq_off = g->h_off.as<i64>(), *h_base_off = h_seq_off + (n + 1), *h_raw_off = h_base_off + (n + 1);
+    h_seq_off[0] = h_base_off[0] = 0;
+    for (i64 i = 0; i < n; i++) {
+        if (n_bases[i] < 1 || n_bases[i] * SYNTH_DWELL_MAX > 0x7fff0000ll) return set_err(TBA_E_ARG, "bad read length");
+        h_seq_off[i + 1] = h_seq_off[i] + n_bases[i] + K - 1;
+        h_base_off[i + 1] = h_base_off[i] + n_bases[i];
+    }
+    const i64 B_tot = h_base_off[n];
+    if (g->d_sp.ensure(sizeof(SynthParams)) || g->d_seq_off.ensure((N + 1) * 8) || g->d_base_off.ensure((N + 1) * 8) ||
+        g->d_raw_off.ensure((N + 1) * 8) || g->d_seq.ensure((size_t)h_seq_off[n]) ||
+        g->d_starts.ensure((size_t)(B_tot + n) * 4) || g->d_nraw.ensure(N * 8))
+        return TBA_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(g->d_sp.p, g->h_sp.p, sizeof(SynthParams), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->d_seq_off.p, h_seq_off, (N + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->d_base_off.p, h_base_off, (N + 1) * 8, hipMemcpyHostToDevice, s));
+    k_synth_plan<<<(unsigned)n, SYNTH_NT, 0, s>>>(g->d_sp.as<SynthParams>(), seed, first_read, g->d_seq_off.as<i64>(),
+        g->d_base_off.as<i64>(), g->d_seq.as<uint8_t>(), g->d_starts.as<i32>(), g->d_nraw.as<i64>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(g->h_nraw.p, g->d_nraw.p, N * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const i64 *nr = g->h_nraw.as<i64>();
+    h_raw_off[0] = 0;
+    i64 max_b = 0;
+    for (i64 i = 0; i < n; i++) { h_raw_off[i + 1] = h_raw_off[i] + nr[i]; max_b = std::max(max_b, n_bases[i]); }
+    const i64 S_tot = h_raw_off[n];
+    if (g->d_raw.ensure((size_t)S_tot * raw_elem_bytes(raw_dtype) + 64)) return TBA_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(g->d_raw_off.p, h_raw_off, (N + 1) * 8, hipMemcpyHostToDevice, s));
+    const unsigned gx = (unsigned)std::min<i64>(std::max<i64>((max_b + 4 * SYNTH_NT - 1) / (4 * SYNTH_NT), 1), 64);
+    if (raw_dtype == TBA_RAW_I16)
+        k_synth_raw<int16_t><<<dim3(gx, (unsigned)n), SYNTH_NT, 0, s>>>(g->d_sp.as<SynthParams>(), seed, first_read,
+            g->d_seq_off.as<i64>(), g->d_base_off.as<i64>(), g->d_raw_off.as<i64>(), g->d_seq.as<uint8_t>(),
+            g->d_starts.as<i32>(), g->d_kmeans.as<double>(), g->d_raw.as<int16_t>());
+    else
+        k_synth_raw<double><<<dim3(gx, (unsigned)n), SYNTH_NT, 0, s>>>(g->d_sp.as<SynthParams>(), seed, first_read,
+            g->d_seq_off.as<i64>(), g->d_base_off.as<i64>(), g->d_raw_off.as<i64>(), g->d_seq.as<uint8_t>(),
+            g->d_starts.as<i32>(), g->d_kmeans.as<double>(), g->d_raw.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(raw_off, h_raw_off, (N + 1) * 8);
+    memcpy(seq_off, h_seq_off, (N + 1) * 8);
+    g->n_reads = n; g->S_tot = S_tot; g->seq_tot = h_seq_off[n]; g->raw_dtype = raw_dtype;
+    *d_raw = g->d_raw.p;
+    *d_seq = g->d_seq.as<uint8_t>();
+    return 0;
+}
+
+extern "C" int tba_synth_download(tba_synth *g, void *raw, uint8_t *seq)
+{
+    if (!g || g->n_reads <= 0) return set_err(TBA_E_STATE, "nothing generated");
+    HIP_TRY(hipSetDevice(g->device));
+    if (raw) HIP_TRY(hipMemcpy(raw, g->d_raw.p, (size_t)g->S_tot * raw_elem_bytes(g->raw_dtype), hipMemcpyDeviceToHost));
+    if (seq) HIP_TRY(hipMemcpy(seq, g->d_seq.p, (size_t)g->seq_tot, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int tba_abi_sizes(int64_t *out, int64_t n)
 {
     if (!out || n < 3) return set_err(TBA_E_ARG, "bad arguments");

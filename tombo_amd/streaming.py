@@ -243,6 +243,10 @@ class StreamPipeline(object):
         if self.subsample_seed is not None:   # another key for every batch of the job
             self.opts.subsample_seed = (int(self.subsample_seed) + 0x9e3779b97f4a7c15 * self.n_submitted) \
                 & 0xffffffffffffffff
+            # (a batch that names its own key -- a job sharded over ranks: the draw must not depend on
+            # which rank got the batch, or when)
+            if getattr(batch, 'subsample_seed', None) is not None:
+                self.opts.subsample_seed = int(batch.subsample_seed) & 0xffffffffffffffff
         eng.upload_packed(self.params, self.opts, batch.raw, batch.raw_off, batch.seq,
                           batch.seq_off, samp_ind=batch.samp_ind, stall_ints=batch.stall_ints,
                           stall_off=batch.stall_off)

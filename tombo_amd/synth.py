@@ -84,3 +84,75 @@ def edit_read(seq, raw, true_starts, edit):
         a = len(seq) // 2
         return seq[:a] + ins + seq[a:], raw
     raise ValueError('unknown edit %r' % (kind,))
+
+
+# ---- the device generator (csrc/k_synth.h), restated in numpy ----------------------------------
+# Test infrastructure for tba_synth_generate / _native.Synth: same draws, same IEEE operations in the
+# same order, so the arrays are equal bit for bit.  (The product path never calls this.)
+_U64 = np.uint64
+
+
+def _synth_hash(x):
+    with np.errstate(over='ignore'):
+        x = x + _U64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> _U64(27))) * _U64(0x94D049BB133111EB)
+        return x ^ (x >> _U64(31))
+
+
+def _synth_draw(key, stream, idx):
+    with np.errstate(over='ignore'):
+        return _synth_hash(key + _U64(stream << 40) + idx.astype(np.uint64))
+
+
+def device_synth_tables(mean_dwell):
+    """(dwell thresholds uint32[256], noise constant): thr[k] = floor(2^32 (1 - q^(k+1))) by repeated
+    multiplication, c = 1 / sqrt((65536^2 - 1) / 3)"""
+    q = np.float64(1.0) - np.float64(1.0) / np.float64(mean_dwell)
+    thr = np.zeros(256, np.uint32)
+    t = np.float64(1.0)
+    for k in range(256):
+        t = t * q
+        v = np.floor(np.float64(4294967296.0) * (np.float64(1.0) - t))
+        thr[k] = 0xffffffff if v >= 4294967295.0 else int(v)
+    return thr, float(np.float64(1.0) / np.sqrt((np.float64(65536.0) * np.float64(65536.0) - np.float64(1.0)) / np.float64(3.0)))
+
+
+def device_reads_reference(std_ref, seed, n_bases, raw_dtype=np.int16, first_read=0, mean_dwell=9,
+                           min_dwell=2, scale=12.0, offset=90.0, noise_sd=0.25, n_lead=200, n_trail=100,
+                           dac_per_pa=1.0 / 0.1709, dac_offset=10.0, reverse=False):
+    """The batch tba_synth_generate makes for these arguments: (list of raw arrays, list of code arrays)."""
+    thr, c = device_synth_tables(mean_dwell)
+    k = std_ref.kmer_width
+    means = np.asarray(std_ref.level_means, dtype=np.float64)
+    raws, codes_out = [], []
+    with np.errstate(over='ignore'):
+        seed_h = _synth_hash(_U64(int(seed) & 0xffffffffffffffff))
+    for i, nb in enumerate(n_bases):
+        nb = int(nb)
+        with np.errstate(over='ignore'):
+            key = _synth_hash(seed_h + _U64(first_read + i))
+        codes = ((_synth_draw(key, 0, np.arange(nb + k - 1)) >> _U64(11)) & _U64(3)).astype(np.int64)
+        u = (_synth_draw(key, 1, np.arange(nb)) >> _U64(32)).astype(np.uint32)
+        dwell = np.maximum(1 + np.searchsorted(thr, u, side='right'), min_dwell).astype(np.int64)
+        idx = np.zeros(nb, dtype=np.int64)
+        for j in range(k):
+            idx = idx * 4 + codes[j:j + nb]
+        body = int(dwell.sum())
+        S = n_lead + body + n_trail
+        h = _synth_draw(key, 2, np.arange(S))
+        m16 = _U64(0xffff)
+        tot = ((h & m16) + ((h >> _U64(16)) & m16) + ((h >> _U64(32)) & m16) + (h >> _U64(48))).astype(np.int64)
+        noise = (tot - 131070).astype(np.float64) * np.float64(c)
+        x = np.empty(S, np.float64)
+        x[:n_lead] = np.float64(0.5) + noise[:n_lead]
+        x[n_lead:n_lead + body] = np.repeat(means[idx], dwell) + noise[n_lead:n_lead + body] * np.float64(noise_sd)
+        x[n_lead + body:] = np.float64(-0.5) + noise[n_lead + body:]
+        pa = x * np.float64(scale) + np.float64(offset)
+        if np.dtype(raw_dtype) == np.int16:
+            out = np.clip(np.rint(pa * np.float64(dac_per_pa) + np.float64(dac_offset)), -32768.0, 32767.0).astype(np.int16)
+        else:
+            out = pa
+        raws.append(np.ascontiguousarray(out[::-1]) if reverse else out)
+        codes_out.append(codes.astype(np.uint8))
+    return raws, codes_out
