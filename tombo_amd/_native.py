@@ -82,7 +82,8 @@ RAW_DTYPES = {np.dtype(np.float64): RAW_F64, np.dtype(np.float32): RAW_F32,
 GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START, \
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
     GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL, \
-    GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND, GET_TB_PARALLEL, GET_ED_FUSED, GET_ED_TAKEN_POS, GET_ED_N_TAKEN = range(1, 28)
+    GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND, GET_TB_PARALLEL, GET_ED_FUSED, GET_ED_TAKEN_POS, GET_ED_N_TAKEN, \
+    GET_DP_WORKGROUP = range(1, 29)
 GET_DEBUG_COUNTERS = 99  # ReadState.dbg of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS profiling build
 STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, STAGE_SKIP, \
     STAGE_RESCALE = range(7)
@@ -360,6 +361,13 @@ class Engine(object):
         """scheduling hint: `n_engines` engines are fed concurrently on this device (tba_engine_set_sharing)"""
         self._check(self._L.tba_engine_set_sharing(self._h, int(n_engines)), 'tba_engine_set_sharing')
 
+    def set_dp_workgroup_batch(self, max_reads):
+        """batches of at most max_reads reads run the main forward pass one workgroup per read
+        (0: only the long reads of any batch, < 0 -- the default -- never); from the next upload.
+        Same results, measured slower (csrc/k_dp_wgm.h): for A/B runs and that kernel's parity test"""
+        self._check(self._L.tba_engine_set_dp_workgroup_batch(self._h, i64(int(max_reads))),
+                    'tba_engine_set_dp_workgroup_batch')
+
     def host_stage(self):
         """this engine's reusable page-locked staging arrays (PinnedStage)"""
         st = getattr(self, '_stage', None)
@@ -434,7 +442,7 @@ class Engine(object):
             GET_STATUS: (np.int32, n), GET_START_FAIL: (np.int32, n),
             GET_N_STALL: (np.int64, n), GET_STALL_OFF: (np.int64, n),
             GET_SAMP_IND: (np.int64, (n, 1000)),
-            GET_TB_PARALLEL: (np.int32, n), GET_ED_FUSED: (np.int32, n),
+            GET_TB_PARALLEL: (np.int32, n), GET_ED_FUSED: (np.int32, n), GET_DP_WORKGROUP: (np.int32, n),
             GET_ED_TAKEN_POS: (np.int32, 2 * self.n_raw_total), GET_ED_N_TAKEN: (np.int64, n),
         }
         if what in (GET_VALID_CPTS, GET_EVENT_MEANS):

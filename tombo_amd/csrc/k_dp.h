@@ -29,6 +29,25 @@ __host__ __device__ inline int cpl_class(i64 W)
     return 0;
 }
 
+// The main forward pass of a read can be run by a whole workgroup (k_dp_wgm.h) instead of one
+// wavefront: every read of a batch of at most dp_wg_batch reads (DevParams.dp_wg_mode 2), the is_long
+// reads of any batch (1); bands of 129..512 cells.  k_dp and k_dp_multi leave those reads alone.
+// OFF by default (TBA_WG_BATCH -1: never): measured on a 10 kb read at W = 500 the workgroup form
+// takes 20.3 ms against k_dp's 12.9 (k_dp_wgm.h says why); tba_engine_set_dp_workgroup_batch /
+// TBA_DP_WG_BATCH switch it on for A/B runs and for the parity test that keeps it bit-exact.
+#ifndef TBA_WG_BATCH
+#define TBA_WG_BATCH -1
+#endif
+#define WGM_NT 256
+#define WGM_CPL 2
+#define WGM_MAXW (WGM_NT * WGM_CPL)
+__device__ __forceinline__ bool dp_by_workgroup(const DevParams *dp, const ReadState &r)
+{
+    const int m = dp->dp_wg_mode;
+    return (m == 2 || (m == 1 && r.is_long)) && r.W > 128 && r.W <= WGM_MAXW;
+}
+
+
 enum { DP_START_TRY = 0, DP_START_RETRY = 1, DP_MAIN = 2, DP_DIRECT = 3 };
 
 // Narrow adaptive bands are run several reads per wavefront (k_dp_multi.h): the class of a
@@ -270,7 +289,7 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
     } else {
         i64 ev_base;
         if (mode == DP_MAIN) {
-            if (r.path == PATH_NONE) return;
+            if (r.path == PATH_NONE || dp_by_workgroup(dp, r)) return;
             W = (int)r.W;
             if (cpl_class(W) != CPL) return;
             // an adaptive read at a narrow batch bandwidth belongs to k_dp_multi
@@ -928,6 +947,7 @@ __global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const D
     ReadState &r = rs[ri];
     r.moves_off = 0;
     r.tb_done = 0;
+    r.dp_wg = 0;
     if (r.status != TBA_OK) return;
     const tba_params &P = dp->p;
     i64 *bst = band_starts + r.ref_off;

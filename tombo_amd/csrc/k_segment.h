@@ -941,7 +941,8 @@ __global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const 
     __shared__ double s_seg[4 * CAP];
     const int wave = threadIdx.x >> 6;
     wave_segment_sums<CAP>(x, c, n, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
-                      [&](i64 e, double s, i64 len) { em[e] = s / (double)len; });
+                      [&](i64 e, double s, i64 len) { em[e] = s / (double)len; },
+                      (double)r.n_raw / (double)(r.n_cpts > 1 ? r.n_cpts - 1 : 1));
 }
 
 // ts.get_scale_values_from_events (tombo_stats.py:217-233): median / MAD of the first

@@ -55,7 +55,7 @@ struct ReadState {
     double shift, scale, lower, upper; // scale values in force after segment_signal
     i32 has_lims;
     i32 tb_done;              // the main traceback of this read is finished (k_tb_par.h)
-    i32 ed_flag, pad3;        // event detection: 1 = this read needs the kernels that keep the scores (k_detect.h)
+    i32 ed_flag, dp_wg; // dp_wg: the main forward pass was run by a workgroup (k_dp_wgm.h)        // event detection: 1 = this read needs the kernels that keep the scores (k_detect.h)
     i64 n_taken;              // entries of the taken (score, position) list k_detect left
     double ed_min, ed_max;    // ... and the range of its scores
     i64 n_cpts, n_ev;
@@ -74,6 +74,7 @@ struct DevParams {
     i64 kmer_width, central_pos;
     double fill_masked; // (MASK_FILL_Z_SCORE - z_shift) + z_shift, the round trip of
                         // resquiggle.py:665-668,678
+    i32 dp_wg_mode, pad; // main forward pass by workgroup (k_dp_wgm.h): 0 no read, 1 the long reads, 2 all
 };
 
 // Two consecutive float64 as ONE 16-byte memory access at 8-byte alignment (global_load /
