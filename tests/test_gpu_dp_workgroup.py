@@ -58,8 +58,8 @@ def _same(a, b, W):
         assert np.array_equal(a['last_row'][i, :Wi], b['last_row'][i, :Wi]), i
     for k in ('read_start', 'norm_len', 'sv', 'score', 'changed'):
         assert np.array_equal(a[k][ok], b[k][ok]), k
-    for i in np.flatnonzero(ok):   # (a failed read's slice of the signal buffer is whatever the buffer held)
-        u = slice(a['raw_off'][i], a['raw_off'][i + 1])
+    for i in np.flatnonzero(ok):   # (behind a read's norm_len samples, and in a failed read's slice, the buffer is whatever it held)
+        u = slice(a['raw_off'][i], a['raw_off'][i] + a['norm_len'][i])
         assert np.array_equal(a['norm'][u], b['norm'][u]), i
 
 

@@ -835,87 +835,41 @@ __device__ __forceinline__ double seq_sum_lds(const double *p, i64 j0, i64 j1)
 // load instead.  Spans longer than SEGW_CAP samples (long dwell, RNA) take the direct loop; the
 // cap is per kernel: a smaller LDS slice lets more workgroups share a CU (these kernels are
 // bandwidth bound, occupancy is what keeps bytes in flight).
-// The loop is software-pipelined: a step needs the boundaries of its segments (one memory round
-// trip) and then their samples (a second, dependent one) -- taken in turn that is two round trips
-// per 2.5 KB and wavefront (2.0 TB/s at full occupancy).  So while group k is summed out of LDS,
-// the samples of group k + 1 are already on their way into registers and the boundaries of group
-// k + 2 behind them.
-// seg has n_segs + 1 ascending boundaries; emit(i, sum, length) per segment.  mean_len: the
-// caller's estimate of the segments' mean length (picks the group size, any value is correct).
-#ifndef TBA_EM_EXP
-#define TBA_EM_EXP 0
-#endif
-struct SegGroup { i64 a, b, lo, hi; bool ok; };
+// seg has n_segs + 1 ascending boundaries; emit(i, sum, length) per segment.
 template <int SEGW_CAP, class Sig, class Emit>
 __device__ __forceinline__ void wave_segment_sums(Sig x,
     const i64 *__restrict__ seg, i64 n_segs, i64 first_group, i64 group_stride, double *lds,
     Emit emit, double mean_len)
 {
-    constexpr int NP = (SEGW_CAP + 127) / 128;
     const int lane = threadIdx.x & 63;
     // segments per wave step: 64, or fewer (a power of two) when the segments are long, so that
     // a step's samples still fit the slice (RNA: 15-sample events, 43-sample bases); the lanes
     // beyond the group only help loading
+    // (mean_len: the caller's estimate of the mean segment length -- any value is correct, it only
+    // picks the group size; reading it off seg[] would be two more dependent loads per workgroup)
     int gs = 64;
     while (gs > 4 && (double)gs * mean_len * 1.3 > (double)SEGW_CAP) gs >>= 1;
-    auto bounds = [&](i64 g) {      // (a group past the end: empty, nothing is loaded for it)
-        SegGroup q;
+    for (i64 g = first_group; g * gs < n_segs; g += group_stride) {
         const i64 i = g * gs + lane;
-        const bool in = g * gs < n_segs;
+        const bool ok = lane < gs && i < n_segs;
         const i64 i_end = g * gs + gs < n_segs ? g * gs + gs : n_segs;
-        q.ok = in && lane < gs && i < n_segs;
-        q.a = seg[q.ok ? i : (in ? i_end : 0)]; q.b = seg[q.ok ? i + 1 : (in ? i_end : 0)];
-        q.lo = seg[in ? g * gs : 0]; q.hi = seg[in ? i_end : 0];
-        return q;
-    };
-    double pa[NP], pb[NP];
-    auto fetch = [&](const SegGroup &q) {   // the group's samples, two per lane and access
-        const int spn = __builtin_amdgcn_readfirstlane((int)(q.hi - q.lo));
-        if (spn > SEGW_CAP) return;
-#pragma unroll
-        for (int u = 0; u < NP; u++) {
-            if (128 * u < spn) {
-                int k = 2 * lane + 128 * u;
-                k = k < spn ? k : (spn - 1) & ~1;   // (lanes past the end re-read the last pair)
-                sig_pair(x, q.lo + k, pa[u], pb[u]);
-            }
-        }
-    };
-    i64 g = first_group;
-    if (g * gs >= n_segs) return;
-    SegGroup cur = bounds(g);
-    fetch(cur);
-    SegGroup nxt = bounds(g + group_stride);
-    for (; g * gs < n_segs; g += group_stride) {
-        const SegGroup nn = bounds(g + 2 * group_stride);
-        const int spn = __builtin_amdgcn_readfirstlane((int)(cur.hi - cur.lo));
-        const bool staged = spn <= SEGW_CAP;
-        __builtin_amdgcn_wave_barrier();     // the previous group's lanes are done with the slice
-        if (staged) {
-#pragma unroll
-            for (int u = 0; u < NP; u++) {
-                if (128 * u < spn) {
-                    const int k = 2 * lane + 128 * u;
-                    if (k + 1 < spn) { lds[k] = pa[u]; lds[k + 1] = pb[u]; }
-                    else if (k < spn) lds[k] = pa[u];
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#if TBA_EM_EXP != 2
-        fetch(nxt);
-#endif
+        // one coalesced load of the group's boundaries, the neighbour's by DPP, the last one by lane 0
+        const i64 a = seg[ok ? i : i_end];
+        const i64 hi = seg[i_end];                      // (one address for the whole wavefront)
+        const i64 an = shfl_i64(a, lane + 1 < 64 ? lane + 1 : 63);
+        const i64 b = ok ? (i + 1 < i_end && lane + 1 < 64 ? an : hi) : a;
+        const i64 lo = shfl_i64(a, 0);
+        const i64 span = hi - lo;
         double s = 0;
-#if TBA_EM_EXP == 1
-        s = lds[lane];
-#elif TBA_EM_EXP == 2
-        s = lds[lane] + (double)(cur.b - cur.a);
-#else
-        if (staged) s = seq_sum_lds(lds, cur.a - cur.lo, cur.b - cur.lo);
-        else for (i64 j = cur.a; j < cur.b; j++) s += x[j];
-#endif
-        if (cur.ok) emit(g * gs + lane, s, cur.b - cur.a);
-        cur = nxt; nxt = nn;
+        if (span <= SEGW_CAP) {
+            __builtin_amdgcn_wave_barrier(); // the previous group's lanes are done with the slice
+            wave_stage<(SEGW_CAP + 127) / 128>(x, lo, span, lds, nullptr, [](double v) { return v; });
+            __builtin_amdgcn_wave_barrier();
+            s = seq_sum_lds(lds, a - lo, b - lo);
+        } else {
+            for (i64 j = a; j < b; j++) s += x[j];
+        }
+        if (ok) emit(i, s, b - a);
     }
 }
 
