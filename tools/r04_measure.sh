@@ -8,7 +8,10 @@ for cfg in cfg2 cfg3 cfg1 cfg4; do
   python bench.py --preset $cfg --steps 20 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
 done
 python bench.py --preset longtail --steps 4 --no-pmc --api-reads 0 > $O/bench_longtail.json 2> $O/bench_longtail.err
-python bench.py --gpus 2 --steps 6 > $O/bench_cfg5_rehearsal_2ranks_on_1gpu.json 2> $O/bench_n2.err
+python bench.py --gpus 2 --steps 6 > $O/bench_default_2ranks_on_1gpu.json 2> $O/bench_n2.err
+# cfg5 as written: one job of distinct reads through the work queue (2 ranks sharing the one GPU, then 1 rank: same checksum)
+python bench.py --gpus 2 --preset cfg5 --job-reads 200000 > $O/bench_cfg5_job_200k_2ranks_on_1gpu.json 2> $O/bench_cfg5_n2.err
+python bench.py --preset cfg5 --job-reads 200000 --no-cpu-baseline > $O/bench_cfg5_job_200k_1rank.json 2> $O/bench_cfg5_n1.err
 # kernel stats of the cfg2 run (rocprofv3 --kernel-trace --stats), same command as the bench line
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/r04_stats
