@@ -96,3 +96,43 @@ def test_device_batch_through_the_engine():
         if want['status'] == 0:
             assert np.array_equal(want['segs'], segs0[seg_off[i]:seg_off[i + 1]]), i
     g.close()
+
+
+def test_a_batch_of_a_job_gives_the_same_result_whoever_runs_it():
+    """what the job checksum of bench.py --preset cfg5 rests on: device-made batches keyed by their
+    first read, the Theil-Sen draw keyed by the batch (ReadBatch.subsample_seed) -- submission order
+    and slot count do not show in the results"""
+    from tombo_amd import _native, streaming
+    samp, model, params = _model()
+    sp = _native.make_synth_params()
+    gens = [_native.Synth(model, 0) for _ in range(4)]
+    n_b, per = 4, 6
+
+    def run(order, n_slots):
+        pipe = streaming.StreamPipeline(model, params, n_slots=n_slots, outlier_thresh=5.0, seq_samp_type=samp,
+                                        want_norm=False, segs_dtype=np.int32, subsample_seed=77)
+        out = {}
+        batches = []
+        for i, k in enumerate(order):
+            raw, raw_off, seq, seq_off = gens[i % 4].generate(sp, 77, [1500, 900, 2100, 1200, 1800, 1000][:per],
+                                                              first_read=k * per)
+            b = streaming.ReadBatch(raw, raw_off, seq, seq_off, tag=k)
+            b.subsample_seed = 1000 + k
+            batches.append(b)
+        for res in pipe.run(batches):
+            out[res.tag] = (res.results.copy(), np.asarray(res.segs).copy())
+        pipe.close()
+        return out
+
+    a = run([0, 1, 2, 3], 2)
+    b = run([2, 0, 3, 1], 3)
+    assert sorted(a) == sorted(b) == list(range(n_b))
+    n_ok = 0
+    for k in range(n_b):
+        assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1]), k
+        n_ok += int((a[k][0]['status'] == 0).sum())
+    assert n_ok >= n_b * per - 2
+    # ... and another key is another draw for the reads that have one (more than 1000 bases)
+    assert not np.array_equal(a[0][0]['shift'], a[1][0]['shift'])
+    for g in gens:
+        g.close()
