@@ -165,14 +165,8 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
                     const bool full = k + 1 < n, one = k < n;
                     i64 kc = k < n - 2 ? k : n - 2;
                     kc = kc < 0 ? 0 : kc;
-#if defined(TBA_DT_EXP) && (TBA_DT_EXP & 2)
-                    const double va = pa[u], vb = pb[u];   // (timing experiment: no normalisation)
-#else
                     const double va = norm_one(pa[u], u), vb = norm_one(pb[u], u);
-#endif
-#if !(defined(TBA_DT_EXP) && (TBA_DT_EXP & 1))
                     st2(norm + s_st[u] + kc, va, vb);
-#endif
                     t[u * DT_STRIDE + pc] = one ? (full ? va : vb) : 0.0;
                     t[u * DT_STRIDE + pc + 1] = full ? vb : 0.0;
                 }
@@ -189,11 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
             }
         }
     };
-#ifdef TBA_DT_INSTEP
-    if (wave == 1) { loader_step(-1, nullptr, 0); loader_step(0, DT_TILEP(0), -1); }
-#else
     if (wave == 1) { loader_step(-1, nullptr, 0); loader_step(0, DT_TILEP(0), n_steps > 1 ? 1 : -1); }
-#endif
     __syncthreads();
 
     // ---- wave 0: the scan (lane = read)
@@ -232,11 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
             }
             DT_T(0);
         } else if (wave == 1) {
-#ifdef TBA_DT_INSTEP
-            if (i + 1 < n_steps) { loader_step(-1, nullptr, i + 1); loader_step(i + 1, DT_TILEP((i + 1) % 3), -1); }
-#else
             if (i + 1 < n_steps) loader_step(i + 1, DT_TILEP((i + 1) % 3), i + 2 < n_steps ? i + 2 : -1);
-#endif
             DT_T(1);
         } else if (i >= 1) {
             // tile j = i - 1: column t holds c[jC + 1 + t]; slot s = jC + t is the score whose window
