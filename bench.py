@@ -342,9 +342,9 @@ def run_job(ctx, job_reads, batch_reads, n_bases, job_seed):
                                     seq_samp_type=ctx['samp'], want_norm=False, segs_dtype=np.int32,
                                     subsample_seed=job_seed, in_order=True)
     # a generator's batch must outlive the slot's copy of it: two generators per slot
-    gens = [_native.Synth(model, dev) for _ in range(2 * slots)]
+    gens = [_native.Synth(model, dev) for _ in range(2 * slots + 2)]   # (+ the one being made, + one spare)
     sp = _native.make_synth_params(dac_per_pa=DAC_PER_PA, dac_offset=DAC_OFFSET, **synth_mod.DNA_SYNTH)
-    cnt = dict(reads=0, ok=0, nb=0, chk=0, gen_s=0.0, submit_s=0.0, out=0)
+    cnt = dict(reads=0, ok=0, nb=0, chk=0, gen_s=0.0, submit_s=0.0, wait_s=0.0, out=0)
     est = np.zeros(32)
     drawn = []
     state = dict(i=0)
@@ -364,40 +364,63 @@ def run_job(ctx, job_reads, batch_reads, n_bases, job_seed):
         last = np.asarray(res.segs)[np.asarray(res.seg_off[1:]) - 1].astype(np.int64)
         cnt['chk'] += int(((r['read_start_rel_to_raw'] + r['norm_len'] + last) * ok).sum()) % (1 << 40)
 
-    def one(k, first_read, n_k, count=True):
+    def make(k, first_read, n_k):
+        """batch k of the job in device memory (blocks until the generator's kernels have run)"""
         g = gens[state['i'] % len(gens)]
         state['i'] += 1
         t0 = time.perf_counter()
         raw, raw_off, seq, seq_off = g.generate(sp, job_seed, np.full(n_k, n_bases, np.int64),
                                                 raw_dtype=np.int16, first_read=first_read)
-        t1 = time.perf_counter()
         b = streaming.ReadBatch(raw, raw_off, seq, seq_off, tag=k)
         b.subsample_seed = (job_seed * 0x9E3779B97F4A7C15 + first_read) & 0xffffffffffffffff
+        return b, time.perf_counter() - t0
+
+    def submit(b, dt_gen, count=True):
+        t1 = time.perf_counter()
         done = pipe.submit(b)
         if count:
-            cnt['gen_s'] += t1 - t0
+            cnt['gen_s'] += dt_gen
             cnt['submit_s'] += time.perf_counter() - t1
         consume(done, count)
 
     # warm-up: reads outside the job (behind its last read), every slot and generator sees a full batch
-    for w in range(2 * slots + 2):
-        one(-1 - w, job_reads + w * batch_reads, batch_reads, count=False)
+    for w in range(len(gens) + 2):
+        submit(*make(-1 - w, job_reads + w * batch_reads, batch_reads), count=False)
     for done in pipe.flush():
         pass
     algo_bytes, dp_cells = pipe.slots[0].eng.stats()
     queue = sharding.BatchQueue(n_batches, key='distinct_read_job')
-    ctx['barrier']()
-    t0 = time.perf_counter()
-    for k in queue:
+    # The generator's kernels wait for SIMD slots behind the wavefronts of the batches in flight (a k_dp
+    # wavefront lives for tens of milliseconds), so a batch is made one draw ahead on a helper thread
+    # while the previous one is submitted: the draw of batch k + 1 happens before batch k is submitted.
+    from concurrent.futures import ThreadPoolExecutor
+    helper = ThreadPoolExecutor(1)
+
+    def draw(it):
+        k = next(it, None)
+        if k is None:
+            return None
         first = k * batch_reads
         drawn.append((int(k), int(first)))
-        one(k, first, min(batch_reads, job_reads - first))
+        return helper.submit(make, k, first, min(batch_reads, job_reads - first))
+
+    ctx['barrier']()
+    t0 = time.perf_counter()
+    it = iter(queue)
+    pending = draw(it)
+    while pending is not None:
+        tw = time.perf_counter()
+        b, dt_gen = pending.result()
+        cnt['wait_s'] += time.perf_counter() - tw
+        pending = draw(it)
+        submit(b, dt_gen)
     for done in pipe.flush():
         consume(done)
     ctx['dev_sync']()
     my_dt = time.perf_counter() - t0
     ctx['barrier']()
     dt = ctx['max_over_ranks'](time.perf_counter() - t0)
+    helper.shutdown()
     tot = {k: ctx['sum_over_ranks'](float(cnt[k])) for k in ('reads', 'ok', 'nb', 'chk', 'out')}
     pipe.close()
     for g in gens:
@@ -414,7 +437,8 @@ def run_job(ctx, job_reads, batch_reads, n_bases, job_seed):
         'success_rate': round(tot['ok'] / max(tot['reads'], 1), 4),
         'checksum_mod_2_40_summed': int(tot['chk']), 'job_seed': int(job_seed),
         'out_GB': round(tot['out'] / 1e9, 3),
-        'host_s_in_generate_rank0': round(cnt['gen_s'], 4), 'host_s_in_submit_rank0': round(cnt['submit_s'], 4),
+        'helper_s_in_generate_rank0': round(cnt['gen_s'], 4), 'host_s_waiting_for_generator_rank0': round(cnt['wait_s'], 4),
+        'host_s_in_submit_rank0': round(cnt['submit_s'], 4),
         'stage_ms_per_batch_rank0': {k: round(float(v) / nb, 3) for k, v in zip(names, est[:16]) if v > 0}}
     return dict(report=report, dt=dt, my_dt=my_dt, my_batches=cnt['nb'], my_reads=cnt['reads'], drawn=drawn,
                 stage=est / nb, algo_bytes=algo_bytes, dp_cells=dp_cells, n_batches=n_batches, tot=tot)
