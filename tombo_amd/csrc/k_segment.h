@@ -917,7 +917,9 @@ __global__ __launch_bounds__(SEL_NT) void k_remove_stalls(ReadState *rs, i64 n_r
 
 // c_new_means (_c_helper.pyx:59-71) over the event boundaries: sequential sum, one divide.
 // grid: (blocks, reads)
-template <class RT>
+// CAP: samples a wavefront stages per step (wave_segment_sums): 448 = 64 events of ~5 samples (DNA);
+// RNA events are ~15 samples, at 448 a step would be 16 events on a quarter of the lanes: 1 280.
+template <class RT, int CAP = 448>
 // scale_events != 0: only the events ts.get_scale_values_from_events looks at are needed (the
 // first min(rna_scale_num_events, int(frac * n_cpts)) - 1, tombo_stats.py:220-224).
 __global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const DevParams *dp,
@@ -937,7 +939,6 @@ __global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const 
         if (ne > r.n_cpts) ne = r.n_cpts;
         n = ne - 1 < n ? (ne - 1 > 0 ? ne - 1 : 0) : n;
     }
-    constexpr int CAP = 448; // 64 events of ~5 samples
     __shared__ double s_seg[4 * CAP];
     const int wave = threadIdx.x >> 6;
     wave_segment_sums<CAP>(x, c, n, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,

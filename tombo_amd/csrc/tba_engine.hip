@@ -675,14 +675,17 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         launch_peaks(P.min_obs_per_base, nb, s, rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0, only_flagged);
         if (e->any_stall) k_remove_stalls<<<nb, SEL_NT, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>(), e->d_csum.as<double>());
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
-            RAW_DISPATCH(rdt, (k_event_means<RT><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 1)));
+            RAW_DISPATCH(rdt, (k_event_means<RT, 1280><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 1)));
             k_rna_event_scale<<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_evm.as<double>());
             RAW_DISPATCH(rdt, (k_normalize<RT><<<nb, SEL_NT, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_norm.as<double>(), e->d_sv_in.as<double>(), 1, 1)));
         }
     }
     MARK(); // 4 event means
-    if (ON(TBA_STAGE_EVENT_MEANS))
-        k_event_means<double><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+    if (ON(TBA_STAGE_EVENT_MEANS)) {
+        // long events (RNA: mean_obs_per_event 15): the wide staging slice
+        if (P.mean_obs_per_event >= 10) k_event_means<double, 1280><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+        else k_event_means<double><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
+    }
     MARK(); // 5 ref levels
     if (ON(TBA_STAGE_REF_LEVELS))
         k_ref_levels<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_seq.as<uint8_t>(), e->d_kmeans.as<double>(), e->d_ksds.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>());
