@@ -39,7 +39,8 @@ int main()
     report("k_detect<2,int16_t>", k_detect<2, int16_t>, 256);
     report("k_pick", k_pick, SEL_NT);
     report("k_detect_tt<5,12,double>", k_detect_tt<5, 12, double>, SEL_NT);
-    report("k_event_means<double>", k_event_means<double>, 256);
+    report("k_event_means<double>", k_event_means<double, 448>, 256);
+    report("k_event_means<double, 1280>", k_event_means<double, 1280>, 256);
     report("k_dp<8,false>", k_dp<8, false>, 64);
     report("k_dp8_lowreg", k_dp8_lowreg, 64);
     report("k_dp<5,false>", k_dp<5, false>, 64);
