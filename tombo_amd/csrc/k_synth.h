@@ -1,6 +1,6 @@
 // Synthetic reads made on the device (bench / test support: no counterpart in the reference, whose
 // benchmark input is FAST5 files; SURVEY.md section 8d describes the workload these stand in for).
-// A job of a million distinct 10 kb reads is 100 GB of samples: made by numpy on the host cores
+// A job of a million distinct 10 kb reads is 190 GB of int16 samples: made by numpy on the host cores
 // (tombo_amd/synth.py, ~1 ms per read) that is most of an hour, so the multi-GPU job of
 // BASELINE.json's cfg5 draws every batch here instead, from a counter-based generator keyed by
 // (batch seed, read, element) -- any rank produces the same batch for the same seed, no state is
