@@ -37,3 +37,17 @@ def test_restated_reads_look_like_synth_reads():
     quiet, _ = synth.device_reads_reference(model, 3, [4000], raw_dtype=np.float64, noise_sd=0.0)
     resid = (raws[0] - quiet[0])[200:-100] / 12.0
     assert abs(resid.std() - 0.25) < 0.01 and abs(resid.mean()) < 0.01 and np.abs(resid).max() <= 0.25 * 3.47
+
+
+def test_restatement_is_pinned():
+    """the draws of csrc/k_synth.h as recorded when the device generator was held to this restatement on
+    an MI355X (tests/test_gpu_synth.py): a change of either side shows here without a GPU"""
+    import hashlib
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    model = ts.TomboModel(seq_samp_type=th.seqSampleType('DNA', False))
+    raws, codes = synth.device_reads_reference(model, 20260927, [700, 1300], first_read=41)
+    h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    assert [len(r) for r in raws] == [6916, 12763]
+    assert [h(r) for r in raws] == ['ff36502a6f096453', 'dbf06206530e2e7f']
+    assert [h(c) for c in codes] == ['4fb2e7d2adf0ba47', '144199660e1e925c']
+    assert raws[0][:6].tolist() == [671, 589, 551, 486, 659, 656] and codes[0][:8].tolist() == [2, 2, 0, 0, 3, 3, 3, 1]
