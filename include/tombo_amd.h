@@ -318,6 +318,13 @@ int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pass, int64_t 
     int64_t n_events, const double *r_ref_means, const double *r_ref_sds, double z_shift,
     double skip_pen, double stay_pen, int64_t start_seq_pos, double mask_fill_z_score,
     int do_winsorize_z, double max_half_z_score);
+/* ... with return_z_scores=True (pyx:324,339,387-388,409-410): z_scores[(n_bases - start_seq_pos) * bw]
+ * receives the shifted z-scores of every row the pass computed (NULL: as above) */
+int tba_c_adaptive_banded_forward_pass_z(tba_engine *e, double *fwd_pass, int64_t *fwd_pass_tb,
+    int64_t n_bases, int64_t bandwidth, int64_t *event_starts, const double *event_means,
+    int64_t n_events, const double *r_ref_means, const double *r_ref_sds, double z_shift,
+    double skip_pen, double stay_pen, int64_t start_seq_pos, double mask_fill_z_score,
+    int do_winsorize_z, double max_half_z_score, double *z_scores);
 /* c_banded_forward_pass, pyx:240-279 */
 int tba_c_banded_forward_pass(tba_engine *e, const double *shifted_z_scores, int64_t n_bases,
     int64_t bandwidth, const int64_t *event_starts, double skip_pen, double stay_pen,

@@ -139,6 +139,21 @@ def test_forward_pass_and_traceback_kernels(read):
     np.testing.assert_array_equal(st_a, o_st)
     np.testing.assert_array_equal(fwd_a, o_fwd)
     np.testing.assert_array_equal(tb_a[1:], o_tb[1:].astype(np.int64))
+    # return_z_scores=True (pyx:339,387-388,409-410): same pass, plus the shifted z-scores of every row
+    # it computed -- those are a function of the band starts it chose (pyx:361-386)
+    fwd_z, tb_z, st_z = fwd_a.copy(), tb_a.copy(), st_a.copy()
+    fwd_z[nb + 1:], tb_z[nb + 1:], st_z[nb:] = 0, 0, 0
+    zs = cdp.c_adaptive_banded_forward_pass(
+        fwd_z, tb_z, st_z, ev, mu[:n_bases], sd[:n_bases], p.z_shift, p.skip_pen, p.stay_pen, nb,
+        -15.0, True, p.max_half_z_score, return_z_scores=True)
+    np.testing.assert_array_equal(st_z, o_st)
+    np.testing.assert_array_equal(fwd_z, o_fwd)
+    assert zs.shape == (n_bases - nb, bw)
+    want_z = np.full((n_bases - nb, bw), -15.0)
+    for r in range(nb, n_bases):
+        e = ev[o_st[r]:o_st[r] + bw]
+        want_z[r - nb, :e.shape[0]] = p.z_shift - np.minimum(p.max_half_z_score, np.abs(e - mu[r]) / sd[r])
+    np.testing.assert_array_equal(zs, want_z)
     # band start pushed past the last event (argmax at the right edge of a row that already sits
     # at the end of the events): the reference's error, pyx:349-357
     fwd_b, tb_b, st_b = fwd_a.copy(), tb_a.copy(), st_a.copy()

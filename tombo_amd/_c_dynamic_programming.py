@@ -94,8 +94,6 @@ def c_adaptive_banded_forward_pass(
         skip_pen, stay_pen, start_seq_pos, mask_fill_z_score, do_winsorize_z, max_half_z_score,
         return_z_scores=False):
     """fwd_pass, fwd_pass_tb and event_starts are updated in place (rows after start_seq_pos)."""
-    if return_z_scores:
-        raise NotImplementedError('return_z_scores is a debug-plot feature of the reference')
     for a, dt in ((fwd_pass, np.float64), (fwd_pass_tb, np.int64), (event_starts, np.int64)):
         if a.dtype != dt or not a.flags['C_CONTIGUOUS']:
             raise ValueError('in-place arguments must be C-contiguous %s arrays' % dt.__name__)
@@ -103,14 +101,17 @@ def c_adaptive_banded_forward_pass(
         _f8(r_ref_sds, 'r_ref_sds')
     n_bases, bw = fwd_pass.shape[0] - 1, fwd_pass.shape[1]
     eng = _engine()
-    _raise(eng._L.tba_c_adaptive_banded_forward_pass(
+    # return_z_scores (pyx:339,387-388,409-410): the shifted z-scores of the rows the pass computed
+    z = np.empty((n_bases - int(start_seq_pos), bw), dtype=np.float64) if return_z_scores else None
+    _raise(eng._L.tba_c_adaptive_banded_forward_pass_z(
         eng._h, fwd_pass.ctypes.data_as(_pd), fwd_pass_tb.ctypes.data_as(_pi), C.c_int64(n_bases),
         C.c_int64(bw), event_starts.ctypes.data_as(_pi), ev.ctypes.data_as(_pd),
         C.c_int64(ev.shape[0]), mu.ctypes.data_as(_pd), sd.ctypes.data_as(_pd),
         C.c_double(z_shift), C.c_double(skip_pen), C.c_double(stay_pen),
         C.c_int64(int(start_seq_pos)), C.c_double(mask_fill_z_score),
-        C.c_int(bool(do_winsorize_z)), C.c_double(max_half_z_score)), eng)
-    return None
+        C.c_int(bool(do_winsorize_z)), C.c_double(max_half_z_score),
+        None if z is None else z.ctypes.data_as(_pd)), eng)
+    return z
 
 
 def _raise_index(rc, eng):

@@ -90,6 +90,7 @@ struct DpJob {
     i64 *starts;                  // band starts [n_rows] (static rows in, adaptive rows out)
     const double *init_row;       // forward row `row0` [W] or NULL (zeros)
     double *fwd_out;              // all forward rows [(n_rows+1)][W] or NULL
+    double *z_out;                // shifted z-scores of rows row0.. [(n_rows-row0)][W] or NULL (return_z_scores, pyx:339,387)
     unsigned char *mv;            // moves, rows of 64*CPL bytes
     double z_shift, skip_pen, stay_pen, max_half_z, fill;
     i32 winsor, status;
@@ -531,6 +532,12 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
                     z[j] = j < nvalid ? z[j] : NEG_INF;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (DIRECT) {
+            if (job->z_out != nullptr) { // all_shifted_z_scores[seq_pos - start_seq_pos, :] (pyx:387-388)
+#pragma unroll
+                for (int j = 0; j < CPL; j++) if (j < nvalid) job->z_out[(i64)(row - row0) * W + b0 + j] = z[j];
             }
         }
         DP_PH(0);

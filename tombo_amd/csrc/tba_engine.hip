@@ -1187,11 +1187,12 @@ static int run_direct_dp(tba_engine *e, DpJob hj, int cpl, i64 n_rows, i64 W, i6
 }
 } // namespace
 
-extern "C" int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pass,
+extern "C" int tba_c_adaptive_banded_forward_pass_z(tba_engine *e, double *fwd_pass,
     int64_t *fwd_pass_tb, int64_t n_bases, int64_t bandwidth, int64_t *event_starts,
     const double *event_means, int64_t n_events, const double *r_ref_means,
     const double *r_ref_sds, double z_shift, double skip_pen, double stay_pen,
-    int64_t start_seq_pos, double mask_fill_z_score, int do_winsorize_z, double max_half_z_score)
+    int64_t start_seq_pos, double mask_fill_z_score, int do_winsorize_z, double max_half_z_score,
+    double *z_scores)
 {
     if (!e || !fwd_pass || !fwd_pass_tb || !event_starts || !event_means || !r_ref_means ||
         !r_ref_sds || n_bases < 1 || bandwidth < 2 || start_seq_pos < 1 || start_seq_pos > n_bases)
@@ -1203,7 +1204,9 @@ extern "C" int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pas
         if (event_starts[i] < 0 || event_starts[i] >= n_events || (i > 0 && event_starts[i] < event_starts[i - 1]))
             return set_err(TBA_E_ARG, "event_starts must be non-decreasing inside [0, n_events)");
     HIP_TRY(hipSetDevice(e->device));
-    Tmp d_ev, d_mu, d_sd, d_st, d_init;
+    Tmp d_ev, d_mu, d_sd, d_st, d_init, d_z;
+    const size_t z_bytes = (size_t)(n_bases - start_seq_pos) * (size_t)bandwidth * 8;
+    if (z_scores && z_bytes && d_z.alloc(z_bytes)) return set_err(TBA_E_NOMEM, "hipMalloc failed");
     if (d_ev.alloc((size_t)n_events * 8) || d_mu.alloc((size_t)n_bases * 8) ||
         d_sd.alloc((size_t)n_bases * 8) || d_st.alloc((size_t)n_bases * 8) ||
         d_init.alloc((size_t)bandwidth * 8))
@@ -1218,11 +1221,26 @@ extern "C" int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pas
     j.W = bandwidth; j.n_rows = n_bases; j.row0 = start_seq_pos; j.n_static = start_seq_pos;
     j.n_ev = n_events; j.ev = d_ev.as<double>(); j.mu = d_mu.as<double>(); j.sd = d_sd.as<double>();
     j.zmat = nullptr; j.starts = d_st.as<i64>(); j.init_row = d_init.as<double>();
+    j.z_out = z_scores && z_bytes ? d_z.as<double>() : nullptr;
     j.z_shift = z_shift; j.skip_pen = skip_pen; j.stay_pen = stay_pen; j.max_half_z = max_half_z_score;
     j.fill = mask_fill_z_score; j.winsor = do_winsorize_z ? 1 : 0;
-    return run_direct_dp(e, j, cpl, n_bases, bandwidth, start_seq_pos, fwd_pass, fwd_pass_tb,
-                         event_starts, start_seq_pos);
+    const int rc = run_direct_dp(e, j, cpl, n_bases, bandwidth, start_seq_pos, fwd_pass, fwd_pass_tb,
+                                 event_starts, start_seq_pos);
+    if (rc == TBA_OK && j.z_out) C_TRY(hipMemcpy(z_scores, d_z.p, z_bytes, hipMemcpyDeviceToHost));
+    return rc;
 }
+
+extern "C" int tba_c_adaptive_banded_forward_pass(tba_engine *e, double *fwd_pass,
+    int64_t *fwd_pass_tb, int64_t n_bases, int64_t bandwidth, int64_t *event_starts,
+    const double *event_means, int64_t n_events, const double *r_ref_means,
+    const double *r_ref_sds, double z_shift, double skip_pen, double stay_pen,
+    int64_t start_seq_pos, double mask_fill_z_score, int do_winsorize_z, double max_half_z_score)
+{
+    return tba_c_adaptive_banded_forward_pass_z(e, fwd_pass, fwd_pass_tb, n_bases, bandwidth, event_starts,
+        event_means, n_events, r_ref_means, r_ref_sds, z_shift, skip_pen, stay_pen, start_seq_pos,
+        mask_fill_z_score, do_winsorize_z, max_half_z_score, nullptr);
+}
+
 
 extern "C" int tba_c_banded_forward_pass(tba_engine *e, const double *shifted_z_scores,
     int64_t n_bases, int64_t bandwidth, const int64_t *event_starts, double skip_pen,
