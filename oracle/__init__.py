@@ -214,6 +214,20 @@ def banded_traceback(tb, starts, band_pos, thresh=-1):
     return rc, out
 
 
+def resolve_skipped_bases(dp_segs, norm, ref_means, ref_sds, p, max_raw_cpts=200, del_fix_window=2,
+                          max_del_fix_window=10, extra_sig_factor=1.1):
+    """rq.resolve_skipped_bases_with_raw (resquiggle.py:402-540) with its window keyword arguments
+    -> (status, resolved base boundaries)"""
+    segs, norm = _c(dp_segs, np.int64), _c(norm, np.float64)
+    mu, sd = _c(ref_means, np.float64), _c(ref_sds, np.float64)
+    out = np.empty_like(segs)
+    rc = lib().orc_resolve_skipped_bases_w(
+        _p(segs, C.c_int64), i64(segs.shape[0]), _p(norm), i64(norm.shape[0]), _p(mu), _p(sd), C.byref(p),
+        i64(-1 if max_raw_cpts is None else int(max_raw_cpts)), i64(int(del_fix_window)),
+        i64(int(max_del_fix_window)), f64(float(extra_sig_factor)), _p(out, C.c_int64))
+    return rc, out
+
+
 def new_means(sig, segs):
     sig, segs = _c(sig, np.float64), _c(segs, np.int64)
     out = np.empty(segs.shape[0] - 1)

@@ -1057,18 +1057,19 @@ static inline i64 seg_at(const i64 *segs, i64 n_segs, i64 i)
     return segs[i < 0 ? i + n_segs : i]; /* numpy negative index */
 }
 
-static int window_too_small(const i64 *segs, i64 n_segs, win_t w, i64 m)
+static int window_too_small(const i64 *segs, i64 n_segs, win_t w, i64 m, double extra_sig_factor)
 {
     i64 n_events = w.e - w.s;
     if (w.e >= n_segs || w.s < -n_segs) return -1;
     i64 sig_len = seg_at(segs, n_segs, w.e) - seg_at(segs, n_segs, w.s);
-    return (double)sig_len <= (double)((n_events + 1) * m) * EXTRA_SIG_FACTOR;
+    return (double)sig_len <= (double)((n_events + 1) * m) * extra_sig_factor;
 }
 
-/* rq.resolve_skipped_bases_with_raw, resquiggle.py:402-540 */
-int orc_resolve_skipped_bases(const i64 *dp_segs, i64 n_segs, const double *norm, i64 n_norm,
+/* rq.resolve_skipped_bases_with_raw, resquiggle.py:402-540, with its keyword arguments
+ * del_fix_window / max_del_fix_window / extra_sig_factor (:405-407) */
+int orc_resolve_skipped_bases_w(const i64 *dp_segs, i64 n_segs, const double *norm, i64 n_norm,
     const double *ref_means, const double *ref_sds, const orc_params *p, i64 max_raw_cpts,
-    i64 *out_segs)
+    i64 del_fix_window, i64 max_del_fix_window, double extra_sig_factor, i64 *out_segs)
 {
     i64 m = p->raw_min_obs_per_base;
     memcpy(out_segs, dp_segs, sizeof(i64) * (size_t)n_segs);
@@ -1076,18 +1077,18 @@ int orc_resolve_skipped_bases(const i64 *dp_segs, i64 n_segs, const double *norm
     i64 nw = 0;
     for (i64 d = 0; d + 1 < n_segs; d++) {
         if (dp_segs[d + 1] - dp_segs[d] != 0) continue;
-        if (nw > 0 && d < w[nw - 1].e + DEL_FIX_WINDOW) w[nw - 1].e = d + DEL_FIX_WINDOW + 1;
-        else { w[nw].s = d - DEL_FIX_WINDOW; w[nw].e = d + DEL_FIX_WINDOW + 1; nw++; }
+        if (nw > 0 && d < w[nw - 1].e + del_fix_window) w[nw - 1].e = d + del_fix_window + 1;
+        else { w[nw].s = d - del_fix_window; w[nw].e = d + del_fix_window + 1; nw++; }
     }
     if (nw == 0) { free(w); goto checks; }
     {
         int expanded = 0;
         nw = merge_windows(w, nw);
         trim_windows(w, nw, n_segs);
-        for (int it = 0; it < MAX_DEL_FIX_WINDOW - DEL_FIX_WINDOW; it++) {
+        for (i64 it = 0; it < max_del_fix_window - del_fix_window; it++) {
             expanded = 0;
             for (i64 i = 0; i < nw; i++) {
-                int ts = window_too_small(dp_segs, n_segs, w[i], m);
+                int ts = window_too_small(dp_segs, n_segs, w[i], m, extra_sig_factor);
                 if (ts < 0) { free(w); return ORC_INTERNAL; }
                 if (ts) { expanded = 1; w[i].s -= 1; w[i].e += 1; }
             }
@@ -1097,7 +1098,7 @@ int orc_resolve_skipped_bases(const i64 *dp_segs, i64 n_segs, const double *norm
         }
         if (expanded) {
             for (i64 i = 0; i < nw; i++) {
-                int ts = window_too_small(dp_segs, n_segs, w[i], m);
+                int ts = window_too_small(dp_segs, n_segs, w[i], m, extra_sig_factor);
                 if (ts < 0) { free(w); return ORC_INTERNAL; }
                 if (ts) { free(w); return ORC_NOT_ENOUGH_DEL_SIGNAL; }
             }
@@ -1128,6 +1129,15 @@ checks:
     if (out_segs[0] < 0) return ORC_NEG_START;
     if (out_segs[n_segs - 1] > n_norm) return ORC_PAST_END;
     return ORC_OK;
+}
+
+/* ... at the reference's defaults (_default_parameters.py:67,72,73) */
+int orc_resolve_skipped_bases(const i64 *dp_segs, i64 n_segs, const double *norm, i64 n_norm,
+    const double *ref_means, const double *ref_sds, const orc_params *p, i64 max_raw_cpts,
+    i64 *out_segs)
+{
+    return orc_resolve_skipped_bases_w(dp_segs, n_segs, norm, n_norm, ref_means, ref_sds, p, max_raw_cpts,
+                                       DEL_FIX_WINDOW, MAX_DEL_FIX_WINDOW, EXTRA_SIG_FACTOR, out_segs);
 }
 
 /* rq.segment_signal, resquiggle.py:1057-1120.  Returns n valid cpts via *n_cpts. */

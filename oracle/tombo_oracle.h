@@ -136,6 +136,9 @@ void orc_linspace(double start, double stop, i64 num, double *out);
 int orc_normalize_raw_signal(const double *raw, i64 n, const orc_opts *o, int use_sv,
                              double sv_shift, double sv_scale, int sv_has_lims, double sv_lo,
                              double sv_hi, double *norm, double *sv_out);
+int orc_resolve_skipped_bases_w(const i64 *dp_segs, i64 n_segs, const double *norm, i64 n_norm,
+    const double *ref_means, const double *ref_sds, const orc_params *p, i64 max_raw_cpts,
+    i64 del_fix_window, i64 max_del_fix_window, double extra_sig_factor, i64 *out_segs);
 int orc_resolve_skipped_bases(const i64 *dp_segs, i64 n_segs, const double *norm, i64 n_norm,
     const double *ref_means, const double *ref_sds, const orc_params *p, i64 max_raw_cpts,
     i64 *out_segs);

@@ -71,3 +71,32 @@ def test_static_assignment_and_errors(golden_case):
     mr = _map_res(c)
     with pytest.raises(th.TomboError, match='Fewer changepoints found than requested'):
         rq.segment_signal(mr._replace(raw_signal=c.raw[:900]), 400, c.params, 5.0)
+
+
+def test_resolve_skipped_bases_window_arguments():
+    """del_fix_window / max_del_fix_window / extra_sig_factor of resolve_skipped_bases_with_raw
+    (resquiggle.py:405-407) are run-time parameters of the engine: results and error messages
+    recorded from the live reference (tests/golden/gen_golden_skipwin.py)"""
+    import os
+    import json
+    from tombo_amd import resquiggle as rq, tombo_stats as ts, tombo_helper as th
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'kernels_skipwin.npz'))
+    settings = json.loads(str(g['settings']))
+    n_err = 0
+    for name in g['names']:
+        p = 'sw_%s_' % name
+        params = ts.load_resquiggle_parameters(th.seqSampleType(str(g[p + 'samp']), False))
+        segs = g[p + 'segs']
+        dp = th.dpResults(read_start_rel_to_raw=0, segs=segs, ref_means=g[p + 'means'], ref_sds=g[p + 'sds'],
+                          genome_seq='A' * (segs.shape[0] - 1))
+        for k, (dfw, mdfw, esf, mrc) in enumerate(settings):
+            err = str(g[p + 'err%d' % k])
+            if err:
+                n_err += 1
+                with pytest.raises(th.TomboError) as ei:
+                    rq.resolve_skipped_bases_with_raw(dp, g[p + 'norm'], params, mrc, dfw, mdfw, esf)
+                assert str(ei.value) == err, (name, settings[k])
+            else:
+                got = rq.resolve_skipped_bases_with_raw(dp, g[p + 'norm'], params, mrc, dfw, mdfw, esf)
+                np.testing.assert_array_equal(got, g[p + 'res%d' % k], err_msg='%s %r' % (name, settings[k]))
+    assert n_err >= 10

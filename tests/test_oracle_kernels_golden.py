@@ -84,3 +84,29 @@ def test_llh_ratio_kernels(kt):
         assert oracle.calc_llh_ratio_const_var(m[sl], r[sl], a[sl], rv[i]) == kt['llh_const'][i]
         assert oracle.calc_scaled_llh_ratio_const_var(m[sl], r[sl], a[sl], rv[i], sf, hf, hp) == \
             kt['llh_scaled'][i]
+
+
+def test_resolve_skipped_bases_off_the_default_windows():
+    """rq.resolve_skipped_bases_with_raw with non-default del_fix_window / max_del_fix_window /
+    extra_sig_factor (resquiggle.py:405-407): results and errors recorded from the live reference
+    (tests/golden/gen_golden_skipwin.py)"""
+    import json
+    import oracle
+    from tombo_amd import errors, tombo_stats as ts, tombo_helper as th
+    g = np.load(os.path.join(HERE, 'golden', 'kernels_skipwin.npz'))
+    settings = json.loads(str(g['settings']))
+    n_err = 0
+    for name in g['names']:
+        p = 'sw_%s_' % name
+        params = ts.load_resquiggle_parameters(th.seqSampleType(str(g[p + 'samp']), False))
+        for k, (dfw, mdfw, esf, mrc) in enumerate(settings):
+            rc, out = oracle.resolve_skipped_bases(g[p + 'segs'], g[p + 'norm'], g[p + 'means'], g[p + 'sds'],
+                                                   oracle.make_params(params), mrc, dfw, mdfw, esf)
+            err = str(g[p + 'err%d' % k])
+            if err:
+                n_err += 1
+                assert rc != 0 and errors.MESSAGES[rc] == err, (name, settings[k], rc, err)
+            else:
+                assert rc == 0, (name, settings[k], rc)
+                np.testing.assert_array_equal(out, g[p + 'res%d' % k], err_msg='%s %r' % (name, settings[k]))
+    assert n_err >= 10

@@ -55,7 +55,8 @@ class Opts(C.Structure):
                 ('stall_window_size', i64), ('stall_n_windows', i64),
                 ('stall_mini_window_size', i64), ('stall_min_consecutive_obs', i64),
                 ('stall_edge_buffer', i64), ('stall_threshold', f64),
-                ('device_subsample', i64), ('subsample_seed', C.c_uint64)]
+                ('device_subsample', i64), ('subsample_seed', C.c_uint64),
+                ('del_fix_window', i64), ('max_del_fix_window', i64), ('extra_sig_factor', f64)]
 
 
 class ReadResult(C.Structure):
@@ -90,7 +91,7 @@ STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, S
 PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
     PUT_START_STATE = range(1, 8)
 MAX_BAND = 3072
-ABI_VERSION = 5  # TBA_ABI_VERSION of include/tombo_amd.h
+ABI_VERSION = 6  # TBA_ABI_VERSION of include/tombo_amd.h
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
                "rescale_score", "stalls", "total"]
@@ -143,11 +144,16 @@ def make_params(rp):
 
 def make_opts(outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
               sig_match_thresh=None, max_raw_cpts=200, min_event_to_seq_ratio=1.1,
-              skip_norm_out=False, reverse_raw=False, stall_params=None, subsample_seed=None):
+              skip_norm_out=False, reverse_raw=False, stall_params=None, subsample_seed=None,
+              del_fix_window=2, max_del_fix_window=10, extra_sig_factor=1.1):
     """tba_opts.  `reverse_raw` / `stall_params` (a th.stallParams of the running-window-mean
     method): the worker's RNA preparation on the device (resquiggle.py:1506-1530);
-    `subsample_seed` (int): the Theil-Sen subsample is drawn on the device."""
+    `subsample_seed` (int): the Theil-Sen subsample is drawn on the device;
+    `del_fix_window` / `max_del_fix_window` / `extra_sig_factor`: the keyword arguments of
+    resolve_skipped_bases_with_raw (resquiggle.py:405-407)."""
     o = Opts()
+    o.del_fix_window, o.max_del_fix_window = int(del_fix_window), int(max_del_fix_window)
+    o.extra_sig_factor = float(extra_sig_factor)
     o.reverse_raw = int(bool(reverse_raw))
     if stall_params is not None:
         sp = stall_params

@@ -25,12 +25,12 @@ __device__ inline void trim_windows(Win *w, i64 n, i64 n_segs)
     if (w[0].s < 0) w[0].s = 0;
     if (w[n - 1].e > n_segs - 1) w[n - 1].e = n_segs - 1;
 }
-__device__ inline int window_too_small(const i64 *segs, i64 n_segs, Win w, i64 m)
+__device__ inline int window_too_small(const i64 *segs, i64 n_segs, Win w, i64 m, double extra_sig_factor)
 {
     if (w.e >= n_segs || w.s < -n_segs) return -1;
     i64 n_events = w.e - w.s;
     i64 se = segs[w.e < 0 ? w.e + n_segs : w.e], ss = segs[w.s < 0 ? w.s + n_segs : w.s];
-    return (double)(se - ss) <= (double)((n_events + 1) * m) * EXTRA_SIG_FACTOR;
+    return (double)(se - ss) <= (double)((n_events + 1) * m) * extra_sig_factor;
 }
 
 // raw-signal DP of one window.  scratch (8-byte units): fw[n*len] forward scores of every base
@@ -229,20 +229,24 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
     // windows are built in place as (s, e) pairs, then widened to (s, e, off) triples back to
     // front; capacity 3 * (B + 1) entries per read
     Win *w = (Win *)(win_scratch + 3 * r.seg_off);
+    // del_fix_window / max_del_fix_window / extra_sig_factor of resolve_skipped_bases_with_raw
+    // (resquiggle.py:405-407; defaults _default_parameters.py:67,72,73)
+    const i64 dfw = dp->o.del_fix_window, mdfw = dp->o.max_del_fix_window;
+    const double esf = dp->o.extra_sig_factor;
     i64 nw = 0;
     for (i64 q = 0; q < n_del; q++) {
         const i64 d = dels[q];
-        if (nw > 0 && d < w[nw - 1].e + DEL_FIX_WINDOW) w[nw - 1].e = d + DEL_FIX_WINDOW + 1;
-        else { w[nw].s = d - DEL_FIX_WINDOW; w[nw].e = d + DEL_FIX_WINDOW + 1; nw++; }
+        if (nw > 0 && d < w[nw - 1].e + dfw) w[nw - 1].e = d + dfw + 1;
+        else { w[nw].s = d - dfw; w[nw].e = d + dfw + 1; nw++; }
     }
     if (nw == 0) return;
     bool expanded = false;
     nw = merge_windows(w, nw);
     trim_windows(w, nw, n_segs);
-    for (int it = 0; it < MAX_DEL_FIX_WINDOW - DEL_FIX_WINDOW; it++) {
+    for (i64 it = 0; it < mdfw - dfw; it++) {
         expanded = false;
         for (i64 i = 0; i < nw; i++) {
-            int ts = window_too_small(ds, n_segs, w[i], m);
+            int ts = window_too_small(ds, n_segs, w[i], m, esf);
             if (ts < 0) { r.status = TBA_INTERNAL; return; }
             if (ts) { expanded = true; w[i].s -= 1; w[i].e += 1; }
         }
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
     }
     if (expanded) {
         for (i64 i = 0; i < nw; i++) {
-            int ts = window_too_small(ds, n_segs, w[i], m);
+            int ts = window_too_small(ds, n_segs, w[i], m, esf);
             if (ts < 0) { r.status = TBA_INTERNAL; return; }
             if (ts) { r.status = TBA_NOT_ENOUGH_DEL_SIGNAL; return; }
         }

@@ -394,6 +394,8 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
     // several kernels index the read with the y dimension of the grid
     if (n_reads > TBA_MAX_BATCH_READS) return set_err(TBA_E_ARG, "more than TBA_MAX_BATCH_READS reads in one batch");
     if (!e->have_model) return set_err(TBA_E_STATE, "tba_set_model has not been called");
+    if (o->del_fix_window < 0 || o->max_del_fix_window < 0 || !(o->extra_sig_factor >= 0.0))
+        return set_err(TBA_E_ARG, "bad skipped-base window parameters");
     if (p->bandwidth < 2 || p->running_stat_width < 1 || p->min_obs_per_base < 1 ||
         p->raw_min_obs_per_base < 1 || p->mean_obs_per_event < 1 || p->start_n_bases < 1)
         return set_err(TBA_E_ARG, "bad resquiggle parameters");
@@ -432,6 +434,11 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
     e->hp.p = *p;
     e->hp.o = *o;
     e->hp.fill_masked = (MASK_FILL_Z_SCORE - p->z_shift) + p->z_shift;
+    if (o->del_fix_window == 0 && o->max_del_fix_window == 0 && o->extra_sig_factor == 0.0) {
+        // a zero-initialised tba_opts: the reference's defaults
+        e->hp.o.del_fix_window = DEL_FIX_WINDOW; e->hp.o.max_del_fix_window = MAX_DEL_FIX_WINDOW;
+        e->hp.o.extra_sig_factor = EXTRA_SIG_FACTOR;
+    }
     const i64 n = n_reads;
     if (e->h_rs.ensure((size_t)n * sizeof(ReadState)) || e->h_dp.ensure(sizeof(DevParams))) return TBA_E_NOMEM;
     BatchSizes z;

@@ -14,6 +14,7 @@ from . import tombo_stats as ts
 from . import errors
 from . import _native
 from ._default_parameters import (
+    DEL_FIX_WINDOW, MAX_DEL_FIX_WINDOW, EXTRA_SIG_FACTOR,
     MAX_RAW_CPTS, MIN_EVENT_TO_SEQ_RATIO, SIG_MATCH_THRESH, DNA_SAMP_TYPE, RNA_SAMP_TYPE,
     MAX_POINTS_FOR_THEIL_SEN)
 from .mapping import get_read_seq, map_read   # (tombo.resquiggle's names; the glue lives there)
@@ -575,13 +576,13 @@ def find_static_base_assignment(event_means, r_ref_means, r_ref_sds, rsqgl_param
 
 
 def resolve_skipped_bases_with_raw(dp_res, norm_signal, rsqgl_params, max_raw_cpts=MAX_RAW_CPTS,
-                                   del_fix_window=None, max_del_fix_window=None,
-                                   extra_sig_factor=None):
+                                   del_fix_window=DEL_FIX_WINDOW, max_del_fix_window=MAX_DEL_FIX_WINDOW,
+                                   extra_sig_factor=EXTRA_SIG_FACTOR):
     """Raw-signal DP over the windows around skipped bases (resquiggle.py:402-540).  Returns
     the resolved segment boundaries."""
-    if (del_fix_window, max_del_fix_window, extra_sig_factor) != (None, None, None):
-        raise NotImplementedError('the window constants are compiled into the engine '
-                                  '(DEL_FIX_WINDOW=2, MAX_DEL_FIX_WINDOW=10, EXTRA_SIG_FACTOR=1.1)')
+    del_fix_window = DEL_FIX_WINDOW if del_fix_window is None else int(del_fix_window)
+    max_del_fix_window = MAX_DEL_FIX_WINDOW if max_del_fix_window is None else int(max_del_fix_window)
+    extra_sig_factor = EXTRA_SIG_FACTOR if extra_sig_factor is None else float(extra_sig_factor)
     eng = get_engine()
     _set_model(eng, _LevelsOnly)
     norm = np.ascontiguousarray(norm_signal, dtype=np.float64)
@@ -590,7 +591,9 @@ def resolve_skipped_bases_with_raw(dp_res, norm_signal, rsqgl_params, max_raw_cp
     w = int(rsqgl_params.running_stat_width)
     pad = max(0, 4 * w + 2 - norm.shape[0])
     eng.set_num_events([2])
-    eng.upload(_native.make_params(rsqgl_params), _native.make_opts(max_raw_cpts=max_raw_cpts),
+    eng.upload(_native.make_params(rsqgl_params),
+               _native.make_opts(max_raw_cpts=max_raw_cpts, del_fix_window=del_fix_window,
+                                 max_del_fix_window=max_del_fix_window, extra_sig_factor=extra_sig_factor),
                [np.concatenate([norm, np.zeros(pad)])], [np.zeros(B + 1, np.uint8)])
     eng.put(_native.PUT_NORM, np.concatenate([norm, np.zeros(pad)]))
     eng.put(_native.PUT_REF_MEANS, np.ascontiguousarray(dp_res.ref_means, dtype=np.float64))
