@@ -83,18 +83,61 @@ def _under_profiler():
     return any('rocprof' in os.environ.get(k, '').lower() for k in keys)
 
 
+def _gen_chunk(args):
+    """a worker's share of make_reads: the reads of one chunk, their sample arrays concatenated into
+    files of a memory-backed directory (the parent maps them: pickling 9 GB of samples through the
+    pool's pipes -- one parent thread unpickles -- was most of the 11.5 s the set-up spent here)"""
+    jobs, k, shm_dir = args
+    res = [_gen(j) for j in jobs]
+    out = dict(k=k, seqs=[r[0] for r in res], n=[len(r[1]) for r in res])
+    for key, col in (('raw', 1), ('dac', 2)):
+        if res[0][col] is None:
+            out[key] = None
+            continue
+        path = os.path.join(shm_dir, 'chunk%d_%s.npy' % (k, key))
+        np.save(path, np.concatenate([r[col] for r in res]))
+        out[key] = path
+    return out
+
+
 def make_reads(bases, base_seed, workers, samp_name='DNA', want_dac=False):
     """Synthetic reads (read i: bases[i] bases, seed base_seed + i) -> (seq strings, float64 pA in
     5'->3' order, int16 DAC in acquisition order or None).  Worker processes are forked before any
-    HIP state exists; under rocprofv3 forked workers deadlock in the tool's signal handler, so
+    HIP state exists and hand their samples over through files in /dev/shm (pipes when that is
+    missing or small); under rocprofv3 forked workers deadlock in the tool's signal handler, so
     threads are used there."""
     n_reads = len(bases)
     jobs = [(int(bases[i]), base_seed + i, samp_name, want_dac) for i in range(n_reads)]
     _gen(jobs[0])
     if workers > 1 and n_reads >= 64 and not _under_profiler():
         import multiprocessing as mp
+        import shutil
+        import tempfile
+        need = float(np.sum(bases)) * 9.5 * (8 + 2) * 1.3     # samples x bytes, with margin
+        shm_dir = None
+        try:
+            st = os.statvfs('/dev/shm')
+            if st.f_bavail * st.f_frsize > need:
+                shm_dir = tempfile.mkdtemp(prefix='tba_bench_', dir='/dev/shm')
+        except OSError:
+            shm_dir = None
         with mp.get_context('fork').Pool(workers) as pool:
-            res = pool.map(_gen, jobs, chunksize=max(1, n_reads // (workers * 8)))
+            if shm_dir is None:
+                res = pool.map(_gen, jobs, chunksize=max(1, n_reads // (workers * 8)))
+            else:
+                try:
+                    step = max(1, n_reads // (workers * 4))
+                    chunks = [(jobs[a:a + step], a, shm_dir) for a in range(0, n_reads, step)]
+                    res = []
+                    for c in sorted(pool.imap_unordered(_gen_chunk, chunks), key=lambda c: c['k']):
+                        off = np.concatenate([[0], np.cumsum(c['n'])])
+                        raw = np.load(c['raw'])
+                        dac = None if c['dac'] is None else np.load(c['dac'])
+                        for i, sq in enumerate(c['seqs']):
+                            sl = slice(off[i], off[i + 1])
+                            res.append((sq, raw[sl], None if dac is None else dac[sl]))
+                finally:
+                    shutil.rmtree(shm_dir, ignore_errors=True)
     elif workers > 1 and n_reads >= 64:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(workers) as ex:
