@@ -36,8 +36,11 @@ def main():
     if a.bandwidth <= 100:
         params = params._replace(band_bound_thresh=10)
     bases = np.full(a.reads, a.bases, np.int64)
-    seqs, raws, stalls, dacs, stalls_dac = bench.make_reads(bases, 1000003, min(32, os.cpu_count() or 8), sn, a.dac)
-    src, st = (dacs, stalls_dac) if a.dac else (raws, stalls)
+    seqs, raws, dacs = bench.make_reads(bases, 1000003, min(32, os.cpu_count() or 8), sn, a.dac)
+    # (RNA: the stalls are found on the device since round 3 -- stall_params below; the int16 arrays of
+    # make_reads are in acquisition order, hence reverse_raw)
+    src = dacs if a.dac else raws
+    from tombo_amd._default_parameters import STALL_PARAMS
     dt = {'i16': np.int16, 'f32': np.float32, 'f64': np.float64}[a.dtype]
     src = [r.astype(dt) for r in src]
     rng = np.random.RandomState(1)
@@ -55,8 +58,9 @@ def main():
         eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
         eng.upload(_native.make_params(params),
                    _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[sn],
-                                     skip_norm_out=a.skip_norm_out),
-                   src, seqs, samp_ind=si, stall_ints=st if a.rna else None)
+                                     skip_norm_out=a.skip_norm_out, reverse_raw=a.rna and a.dac,
+                                     stall_params=th.stallParams(**STALL_PARAMS) if a.rna else None),
+                   src, [ts.encode_seq(q) for q in seqs], samp_ind=si)
         eng.run()
         acc = np.zeros(32)
         for _ in range(a.repeat):
