@@ -76,7 +76,11 @@ static const char *STAGE_NAMES[N_STAGE] = {
 
 #define WIDE_BLOCKS 64 // workgroups of k_dp_wide (each owns two scratch rows)
 #define TB_LANES 16    // reads per wavefront of the latency-bound lane-per-read kernels
-#define TBA_SMALL_BATCH 256 // up to this many reads the scan of event detection runs a workgroup per read
+#ifndef TBA_SMALL_BATCH
+#define TBA_SMALL_BATCH 1024 // up to this many reads the scan of event detection runs a workgroup per read
+                             // (k_detect costs ~7 us per 128 samples whatever the batch: 10 kb reads, event detection
+                             // 384 reads 5.1 -> 1.4 ms, 1 024 reads 5.1 -> 3.2, 2 048 reads 5.4 -> 6.2: profiles/r04_small_batch_scan.txt)
+#endif
 
 // k_peaks is compiled per exclusion radius (min_obs_per_base - 1): 2 and 5 are the defaults of
 // the DNA / RNA parameter sets, anything else takes the generic kernel

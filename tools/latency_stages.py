@@ -13,8 +13,8 @@ model = ts.TomboModel(seq_samp_type=samp)
 params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=500)
 mrs = [synth.synth_map_res(model, 10000, 300 + k, **synth.DNA_SYNTH) for k in range(64)]
 eng = rq.get_engine(0)
-mrs += [synth.synth_map_res(model, 10000, 400 + k, **synth.DNA_SYNTH) for k in range(64, 1024 if len(sys.argv) > 1 else 64)]
-for nb in (1, 8, 64) + ((256, 384, 512, 1024) if len(sys.argv) > 1 else ()):
+mrs += [synth.synth_map_res(model, 10000, 400 + k, **synth.DNA_SYNTH) for k in range(64, 2048 if len(sys.argv) > 1 else 64)]
+for nb in (1, 8, 64) + ((256, 384, 512, 1024, 2048) if len(sys.argv) > 1 else ()):
     for _ in range(3):
         rq.resquiggle_batch(mrs[:nb], model, params, 5.0, seq_samp_type=samp)
     t0 = time.perf_counter()
