@@ -98,3 +98,20 @@ def test_default_two_rank_run_carries_the_distinct_read_job():
     job = r['distinct_read_job']
     assert job['job_reads'] == 24 and job['reads_done'] == 24 and job['batches'] == 8
     assert sum(x['job_reads'] for x in r['per_rank']) == 24
+
+
+def test_make_reads_through_shared_memory_equals_inline():
+    """bench.make_reads hands the workers' samples over through /dev/shm files: same reads, same order
+    as the inline generator"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    bases = np.array([300 + 7 * i for i in range(70)], np.int64)
+    seqs, raws, dacs = bench.make_reads(bases, 4242, 2, 'DNA', True)
+    assert len(seqs) == len(raws) == len(dacs) == 70
+    for i in (0, 1, 33, 69):
+        s, r, d = bench._gen((int(bases[i]), 4242 + i, 'DNA', True))
+        assert seqs[i] == s and np.array_equal(raws[i], r) and np.array_equal(dacs[i], d)
+        assert raws[i].dtype == np.float64 and dacs[i].dtype == np.int16
+    seqs2, raws2, dacs2 = bench.make_reads(bases[:5], 4242, 2, 'DNA', False)   # (few reads: inline)
+    assert dacs2[0] is None and np.array_equal(raws2[4], raws[4])
