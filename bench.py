@@ -256,6 +256,11 @@ def pmc_child(path):
     if meta['bandwidth'] <= 100:
         params = params._replace(band_bound_thresh=10)
     eng = _native.Engine(0)
+    # the sub-batch takes the dispatch forms of the TIMED batch (event detection and traceback switch
+    # kernels on the read count: a 2 048-read sub-batch of a 100-read run must not count k_detect's bytes,
+    # nor a 1 024-read sub-batch of a 10 000-read run those of k_peaks)
+    sb, tw = eng.get_dispatch()
+    eng.set_dispatch(0 if meta['timed_reads'] > sb else 1 << 40, 0 if meta['timed_reads'] > tw else 1 << 40)
     eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
     eng.upload_packed(_native.make_params(params),
                       _native.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[meta['samp']],
@@ -263,7 +268,12 @@ def pmc_child(path):
                       d['raw'], d['raw_off'], d['seq'], d['seq_off'],
                       samp_ind=d['samp_ind'] if 'samp_ind' in d.files else None, wait=True)
     eng.run()
-    print('pmc child ok', int((eng.download(want_norm=False)['status'] == 0).sum()))
+    ok = eng.download(want_norm=False)['status'] == 0
+    ed, tb = eng.get(_native.GET_ED_FORM)[ok], eng.get(_native.GET_TB_FORM)[ok]
+    with open(path + '.forms.json', 'w') as fp:   # which kernels the counted pass really ran, per read
+        json.dump({'ed_form': {str(k): int(v) for k, v in zip(*np.unique(ed, return_counts=True))},
+                   'tb_form': {str(k): int(v) for k, v in zip(*np.unique(tb, return_counts=True))}}, fp)
+    print('pmc child ok', int(ok.sum()))
 
 
 def measure_pmc_traffic(packed, meta, device=0, timeout=150):
@@ -271,7 +281,7 @@ def measure_pmc_traffic(packed, meta, device=0, timeout=150):
     being benchmarked), from two separate `rocprofv3 --pmc` passes of a child process -- the two
     counters do not fit one pass on gfx950 (MI355X_MICROARCH.md, HBM section; KiB units; FETCH
     raw and doubled).  The child sees only `device`.  Returns (bytes per read raw, bytes per read
-    with FETCH doubled, per-kernel dict) or raises."""
+    with FETCH doubled, per-kernel dict, the dispatch forms the counted pass took) or raises."""
     import glob
     import shutil
     import sqlite3
@@ -304,6 +314,8 @@ def measure_pmc_traffic(packed, meta, device=0, timeout=150):
                                      'where counter_name = ? group by kernel_name', (ctr,)):
                 k = name.split('(')[0].replace('void ', '')
                 tot.setdefault(k, {})[ctr] = float(v)
+        with open(path + '.forms.json') as fp:
+            forms = json.load(fp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     raw = up = 0.0
@@ -315,7 +327,7 @@ def measure_pmc_traffic(packed, meta, device=0, timeout=150):
         raw += f + w
         up += 2 * f + w
         kern[k] = round((f + w) / n_reads, 1)
-    return raw / n_reads, up / n_reads, kern
+    return raw / n_reads, up / n_reads, kern, forms
 
 
 def pack_lists(raws, seqs, samp_ind):
@@ -583,7 +595,7 @@ def main():
                     help='longtail preset: reads longer than this form batches of their own (planner.plan_batches)')
     ap.add_argument('--api-reads', type=int, default=5000, help='reads of the resquiggle_batch API leg (0: skip)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes behind roofline.traffic')
-    ap.add_argument('--pmc-reads', type=int, default=1024, help='reads of the counter passes')
+    ap.add_argument('--pmc-reads', type=int, default=2048, help='reads of the counter passes (they take the dispatch forms of the timed batch whatever this is)')
     ap.add_argument('--pmc-child', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-child', default=None, help=argparse.SUPPRESS)  # JSON job of the CPU legs
     ap.add_argument('--engine-stub', default=None, help=argparse.SUPPRESS)  # tests/: host logic without a GPU
@@ -1014,24 +1026,25 @@ def main():
         dp_ms = sms['main_dp']
         traffic = traffic_up = None
         traffic_note = 'not measured (--no-pmc, or already under a profiler)'
-        traffic_kernels = None
+        traffic_kernels = traffic_forms = None
         t_pmc = time.perf_counter()
         if not a.no_pmc and not _under_profiler() and stub is None:
             try:   # rank 0's child passes, after the timed regions, on rank 0's device
                 sub = np.arange(min(a.pmc_reads, a.reads))
                 packed = pack_lists([raws[i] for i in sub], [seqs[i] for i in sub],
                                     None if si is None else si[sub])
-                per_raw, per_up, traffic_kernels = measure_pmc_traffic(
-                    packed, dict(samp=samp_name, bandwidth=a.bandwidth), device=dev)
+                per_raw, per_up, traffic_kernels, traffic_forms = measure_pmc_traffic(
+                    packed, dict(samp=samp_name, bandwidth=a.bandwidth, timed_reads=int(a.reads)), device=dev)
                 # the counter passes run a sub-batch of the same reads; traffic scales with the
                 # samples / bases processed
                 scale = float(n_raw.sum()) / float(n_raw[sub].sum())
                 traffic = per_raw * len(sub) * scale
                 traffic_up = per_up * len(sub) * scale
                 traffic_note = ('whole pipeline, FETCH_SIZE + WRITE_SIZE (KiB) from two rocprofv3 --pmc '
-                                'passes of a %d-read sub-batch of this run, scaled by samples to the '
+                                'passes of a %d-read sub-batch of this run forced through the dispatch '
+                                'forms of the timed %d-read batch, scaled by samples to the '
                                 'launch; traffic_fetch_doubled applies the gfx950 wide-read correction '
-                                'to every read (upper bound)' % len(sub))
+                                'to every read (upper bound)' % (len(sub), a.reads))
             except Exception as e:  # counters are evidence, not the metric: never fail the bench
                 traffic_note = 'counter passes failed: %s' % (str(e)[:200],)
         t_pmc = time.perf_counter() - t_pmc
@@ -1079,6 +1092,9 @@ def main():
                          'traffic_scope': traffic_note,
                          'traffic_over_algorithmic': None if traffic is None else round(traffic / algo_bytes, 3),
                          'traffic_bytes_per_read_by_kernel': traffic_kernels,
+                         # TBA_ED_FORM_* / TBA_TB_FORM_* -> reads of the counted sub-batch (2: k_detect + k_pick,
+                         # 1: workgroup scan + k_peaks; 16 / 64: lanes per read of k_main_tb_par)
+                         'traffic_dispatch_forms': traffic_forms,
                          'algorithmic_bytes_per_launch': algo_bytes,
                          'kernel_ms': round(dom_ms, 3),
                          'pipeline_hbm_frac': round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -142,6 +142,24 @@ int  tba_engine_set_sharing(tba_engine *e, int n_engines);
  * < 0, the default: never), applied from the next upload.  For A/B measurements and the parity
  * test of that kernel; the environment variable TBA_DP_WG_BATCH sets the same at engine creation. */
 int  tba_engine_set_dp_workgroup_batch(tba_engine *e, int64_t max_reads);
+/* Event detection (c_valid_cpts_w_cap, _c_helper.pyx:89-120) and the main traceback
+ * (c_banded_traceback, _c_dynamic_programming.pyx:281-310) each have a LATENCY and a THROUGHPUT
+ * form with identical results; which one a batch takes depends on its read count alone:
+ *   - DNA event detection: batches of at most small_batch_reads reads scan a workgroup per read
+ *     and keep the score array (k_cumsum_scores_long + k_peaks); larger ones run the score-free
+ *     pipeline k_detect + k_pick (with the last pass of the normalisation in its loader);
+ *   - traceback: batches of at most tb_wave_below reads give every read a wavefront
+ *     (k_main_tb_par<64>), larger ones 16 lanes (k_main_tb_par<16>).
+ * Both thresholds default to 1 024 reads; a negative argument leaves a threshold as it is, 0 sends
+ * every batch through the throughput form.  Applied from the next tba_batch_enqueue /
+ * tba_batch_run_stages.  The parity tests run through both forms by this entry; the environment
+ * variables TBA_SMALL_BATCH_READS / TBA_TB_WAVE_BELOW set the same at engine creation.
+ * TBA_GET_ED_FORM / TBA_GET_TB_FORM report which kernels actually produced each read's result. */
+int  tba_engine_set_dispatch(tba_engine *e, int64_t small_batch_reads, int64_t tb_wave_below);
+int  tba_engine_get_dispatch(tba_engine *e, int64_t *small_batch_reads, int64_t *tb_wave_below);
+/* TBA_ED_FORM_* of the last tba_c_valid_cpts_w_cap / tba_c_valid_cpts_w_cap_t_test call on this engine
+ * (those entries follow the engine's dispatch like a batch of one read) */
+int  tba_c_last_ed_form(tba_engine *e);
 
 /* canonical k-mer level table, lexicographic k-mer order (TomboModel, tombo_stats.py:580-919;
  * lookup replaces get_exp_levels_from_seq :834-862) */
@@ -266,8 +284,27 @@ enum {
                                 * left, valid right after stage TBA_STAGE_SEGMENT only (later stages reuse the buffer) */
     TBA_GET_ED_N_TAKEN = 27,  /* int64[n]: its length per read */
     TBA_GET_DP_WORKGROUP = 28, /* int32[n]: 1 where the workgroup-per-read form ran the main forward pass (diagnostics) */
+    TBA_GET_ED_FORM = 29,     /* int32[n]: TBA_ED_FORM_*: the kernels that produced the read's change points
+                               * (0: none did -- the read had failed before) */
+    TBA_GET_TB_FORM = 30,     /* int32[n]: TBA_TB_FORM_*: the kernel that walked the read's main traceback */
     TBA_GET_DEBUG_COUNTERS = 99 /* int64[n][8]: ReadState.dbg, only filled by -DTBA_PHASE_DEBUG /
                                    -DTBA_SWEEP_STATS profiling builds (zeros otherwise) */
+};
+enum {
+    TBA_ED_FORM_NONE = 0,
+    TBA_ED_FORM_WG_SCAN_PEAKS = 1,  /* latency form: workgroup-per-read scan (k_cumsum_scores_long) + k_peaks */
+    TBA_ED_FORM_DETECT_PICK = 2,    /* throughput form: k_detect + k_pick, no score array */
+    TBA_ED_FORM_SCORES_PEAKS = 3,   /* pipelined k_cumsum_scores (or k_cumsum + k_scores_dna) + k_peaks: reads
+                                     * k_detect / k_pick flagged, parameter sets outside their limits */
+    TBA_ED_FORM_DETECT_TT_PICK = 4, /* RNA: k_detect_tt + k_pick */
+    TBA_ED_FORM_TTEST_PEAKS = 5     /* RNA: k_scores_ttest + k_peaks */
+};
+enum {
+    TBA_TB_FORM_NONE = 0,
+    TBA_TB_FORM_LANE = 1,           /* k_main_tb: a lane per read (static bands, broken chains) */
+    TBA_TB_FORM_LONG = 2,           /* k_main_tb_long */
+    TBA_TB_FORM_PAR16 = 16,         /* k_main_tb_par<16>: throughput form */
+    TBA_TB_FORM_PAR64 = 64          /* k_main_tb_par<64>: latency form, and the long reads of any batch */
 };
 int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_bytes);
 /* ---- stepwise execution (the reference's public per-stage API, resquiggle.py:63-67) ---------
@@ -479,7 +516,7 @@ int tba_synth_dwell_thresholds(const tba_synth_params *p, uint32_t *thr, int64_t
 /* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build, out[3]
  * (n >= 4) = TBA_ABI_VERSION: lets a binding without a C compiler (ctypes) check its struct mirrors
  * and refuse a stale build of the library */
-#define TBA_ABI_VERSION 6
+#define TBA_ABI_VERSION 7
 int tba_abi_sizes(int64_t *out, int64_t n);
 
 /* self-test: out[t] = index t of the subsample tba_opts.device_subsample draws for read

@@ -480,6 +480,11 @@ int orc_normalize_raw_signal(const double *raw, i64 n, const orc_opts *o, int us
             scale = orc_median(tmp, n);
         }
     }
+    /* the reference runs under np.seterr(all='raise') (resquiggle.py:29, tombo_stats.py:19): a scale
+     * of exactly 0 -- the MAD of a flat signal -- makes the division below raise FloatingPointError
+     * ('divide by zero' / 'invalid value'), an unexpected error of the read
+     * (tests/golden/gen_golden_degenerate.py records the live reference doing so) */
+    if (scale == 0.0) { free(tmp); return ORC_INTERNAL; }
     for (i64 i = 0; i < n; i++) norm[i] = (raw[i] - shift) / scale;
     double lo = NAN, hi = NAN;
     int have = 0;

@@ -106,3 +106,73 @@ def golden_case():
             cache[name] = GoldenCase(name)
         return cache[name]
     return get
+
+
+# ---- the two dispatch forms of event detection and traceback -------------------------------------
+# DNA event detection and the main traceback each have a latency form (small batches) and a
+# throughput form (what a 10 000-read batch -- the benchmark -- runs); the engine picks by read
+# count (tba_engine_set_dispatch).  Parity tests run through BOTH: 'latency' forces the small-batch
+# kernels for any batch, 'throughput' the large-batch ones (k_detect + k_pick, k_normalize without
+# its last pass, k_main_tb_par<16>), and `check_forms` asserts through TBA_GET_ED_FORM /
+# TBA_GET_TB_FORM that those kernels really produced every read's result.
+FORMS = ('latency', 'throughput')
+_FORM_THRESHOLDS = {'latency': (1 << 40, 1 << 40), 'throughput': (0, 0), 'default': (1024, 1024)}
+
+
+class engine_dispatch(object):
+    """context manager: the process-wide default engine in one dispatch form"""
+
+    def __init__(self, form):
+        self.form = form
+
+    def __enter__(self):
+        from tombo_amd import resquiggle as rq
+        self.eng = rq.get_engine(0)
+        self.eng.set_dispatch(*_FORM_THRESHOLDS[self.form])
+        return self.eng
+
+    def __exit__(self, *exc):
+        self.eng.set_dispatch(*_FORM_THRESHOLDS['default'])
+        return False
+
+
+@pytest.fixture(params=FORMS)
+def dispatch_form(request):
+    with engine_dispatch(request.param):
+        yield request.param
+
+
+def check_forms(eng, form, params, require_all_fused=False):
+    """every read's change points and main traceback came from the kernels of `form`.
+    Returns (ed_form, tb_form) arrays."""
+    from tombo_amd import _native as N
+    ed, tb = eng.get(N.GET_ED_FORM), eng.get(N.GET_TB_FORM)
+    path = eng.get(N.GET_PATH)[:, 0]
+    rna = bool(params.use_t_test_seg)
+    w, m = params.running_stat_width, params.min_obs_per_base
+    ran = ed != N.ED_FORM_NONE
+    if rna:
+        fused = m == 6 and w <= 64     # TT_MAXW (k_segment.h)
+        allowed = {N.ED_FORM_TTEST_PEAKS} | ({N.ED_FORM_DETECT_TT_PICK} if fused else set())
+        want = N.ED_FORM_DETECT_TT_PICK if fused else N.ED_FORM_TTEST_PEAKS
+    elif form == 'latency':
+        # (2w > 64: no fused scan at all, k_cumsum + k_scores_dna in every form)
+        want = N.ED_FORM_WG_SCAN_PEAKS if 2 * w <= 64 else N.ED_FORM_SCORES_PEAKS
+        allowed = {want}
+    else:
+        fused = 2 * w <= 32 and m == 3  # DT_W2MAX (k_detect.h)
+        want = N.ED_FORM_DETECT_PICK if fused else N.ED_FORM_SCORES_PEAKS
+        # flagged reads fall back to the kernels that keep the scores; long reads are scanned by k_long.h
+        allowed = {want, N.ED_FORM_SCORES_PEAKS, N.ED_FORM_WG_SCAN_PEAKS}
+    assert set(ed[ran].tolist()) <= allowed, (form, sorted(set(ed[ran].tolist())), sorted(allowed))
+    if require_all_fused:
+        assert np.all(ed[ran] == want), (form, np.flatnonzero(ran & (ed != want)).tolist())
+    # traceback: adaptive reads by the chunk-parallel walk of the form (64 lanes per read also for the
+    # long reads of any batch), static whole-read bands and broken chains by the lane-per-read walk
+    walked = tb != N.TB_FORM_NONE
+    want_tb = N.TB_FORM_PAR64 if form == 'latency' else N.TB_FORM_PAR16
+    assert set(tb[walked].tolist()) <= {want_tb, N.TB_FORM_PAR64, N.TB_FORM_LANE, N.TB_FORM_LONG}, (form, set(tb[walked].tolist()))
+    if form == 'latency':
+        assert N.TB_FORM_PAR16 not in set(tb.tolist())
+    assert np.all(tb[walked & (path == 2)] == N.TB_FORM_LANE)
+    return ed, tb

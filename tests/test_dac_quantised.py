@@ -113,9 +113,11 @@ def test_oracle_within_reference_envelope_on_dac_input(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', CASES)
 @pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
-def test_engine_equals_oracle_on_dac_input(name, dtype):
+def test_engine_equals_oracle_on_dac_input(name, dtype, dispatch_form):
     """the int16 / float32 upload paths convert on the device (exact): same bits as the float64
-    path and as the oracle, tie-heavy scores included"""
+    path and as the oracle, tie-heavy scores included -- in the latency and in the throughput form
+    (the latter: the three k_detect<2, T> loaders, k_normalize's int-histogram medians without its
+    last pass, k_pick on tie-heavy taken lists, k_main_tb_par<16>)"""
     import oracle
     from tombo_amd import resquiggle as rq, tombo_stats as ts, tombo_helper as th
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
@@ -143,3 +145,8 @@ def test_engine_equals_oracle_on_dac_input(name, dtype):
         assert r.sig_match_score == want['sig_match_score']
         assert r.scale_values.shift == want['scale_values'][0]
         assert r.scale_values.scale == want['scale_values'][1]
+    from conftest import check_forms
+    ed, tb = check_forms(rq.get_engine(0), dispatch_form, params)
+    if dispatch_form == 'throughput' and m['samp_name'] == 'DNA':
+        from tombo_amd import _native as N
+        assert (ed == N.ED_FORM_DETECT_PICK).sum() >= 1, ed

@@ -58,12 +58,30 @@ def test_change_point_kernels(read):
     assert rc == 2
 
 
-def test_change_points_with_exact_score_ties_and_tile_edges():
+def test_change_points_with_exact_score_ties_and_tile_edges(dispatch_form):
     """quantised (integer) signal: many exactly equal scores, also at the threshold score ->
     priority falls to the higher index (DESIGN.md tie rule) like the oracle's ordering; lengths
-    around the 3968-position tiles of the bit-sliced greedy; both exclusion radii"""
+    around the 3968-position tiles of the bit-sliced greedy; both exclusion radii.  In the
+    throughput form the stand-alone entries run k_detect / k_detect_tt + k_pick (what they leave:
+    the kernels that keep the scores), in the latency form k_cumsum_scores / k_scores_ttest + k_peaks."""
     import oracle
-    from tombo_amd import _c_helper as ch
+    from tombo_amd import _c_helper as _ch, _native as N
+    forms = []
+
+    class ch(object):   # every call also records which kernels answered it
+        @staticmethod
+        def c_valid_cpts_w_cap(*a):
+            try:
+                return _ch.c_valid_cpts_w_cap(*a)
+            finally:
+                forms.append(_ch.last_ed_form())
+
+        @staticmethod
+        def c_valid_cpts_w_cap_t_test(*a):
+            try:
+                return _ch.c_valid_cpts_w_cap_t_test(*a)
+            finally:
+                forms.append(_ch.last_ed_form())
     rng = np.random.default_rng(17)
     for n in (64, 700, 3968 + 10, 3968 + 74, 2 * 3968 + 9, 4096, 8192, 20011):
         sig = rng.integers(-3, 4, size=n).astype(np.float64)
@@ -97,6 +115,13 @@ def test_change_points_with_exact_score_ties_and_tile_edges():
         rc, want = oracle.valid_cpts(sig, 3, 5, k)
         assert rc == 0
         np.testing.assert_array_equal(ch.c_valid_cpts_w_cap(sig, 3, 5, k), want)
+    fused = {N.ED_FORM_DETECT_PICK, N.ED_FORM_DETECT_TT_PICK}
+    if dispatch_form == 'throughput':
+        # the continuous signals and most of the quantised ones are finished by the score-free kernels
+        assert sum(f == N.ED_FORM_DETECT_PICK for f in forms) >= 8, forms
+        assert sum(f == N.ED_FORM_DETECT_TT_PICK for f in forms) >= 3, forms
+    else:
+        assert not (set(forms) & fused), forms
 
 
 def test_forward_pass_and_traceback_kernels(read):

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st, HealthCheck
 
+from conftest import FORMS, engine_dispatch, check_forms
+
 pytestmark = pytest.mark.gpu
 
 
@@ -30,8 +32,14 @@ def param_points(draw):
 
 @settings(max_examples=200, deadline=None, derandomize=True,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
-@given(param_points())
-def test_engine_matches_oracle_over_the_parameter_box(pt):
+@given(pt=param_points())
+@pytest.mark.parametrize('form', FORMS)
+def test_engine_matches_oracle_over_the_parameter_box(form, pt):
+    with engine_dispatch(form):
+        _box_point(form, pt)
+
+
+def _box_point(form, pt):
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
     from test_gpu_parity import run_batch, compare_batch
     name = 'RNA' if pt['rna'] else 'DNA'
@@ -53,6 +61,7 @@ def test_engine_matches_oracle_over_the_parameter_box(pt):
                                   max_raw_cpts=pt['max_raw_cpts'])
     bad = compare_batch(eng, oracles, out, repr(pt))
     assert not bad, '\n'.join(bad[:20])
+    check_forms(eng, form, params)
 
 
 @st.composite
@@ -75,8 +84,14 @@ def disagreeing_reads(draw):
 
 @settings(max_examples=150, deadline=None, derandomize=True,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
-@given(disagreeing_reads())
-def test_engine_matches_oracle_on_reads_that_disagree_with_their_sequence(pt):
+@given(pt=disagreeing_reads())
+@pytest.mark.parametrize('form', FORMS)
+def test_engine_matches_oracle_on_reads_that_disagree_with_their_sequence(form, pt):
+    with engine_dispatch(form):
+        _disagreeing_point(form, pt)
+
+
+def _disagreeing_point(form, pt):
     """deletions / insertions against the mapped sequence, truncated signal, dwell and noise far
     from the model's, long leaders: the paths that end in resolve_skipped_bases_with_raw, the
     start retry and the failure strings (the oracle is pinned on 11 such reads recorded from the
@@ -105,6 +120,7 @@ def test_engine_matches_oracle_on_reads_that_disagree_with_their_sequence(pt):
     eng, out, oracles = run_batch(model, params, name, reads)
     bad = compare_batch(eng, oracles, out, repr(pt))
     assert not bad, '\n'.join(bad[:20])
+    check_forms(eng, form, params)
 
 
 def test_rna_without_outlier_thresh_is_an_unexpected_error():

@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 
-from conftest import golden_names
+from conftest import golden_names, check_forms
 
 pytestmark = pytest.mark.gpu
 
@@ -115,8 +115,10 @@ def compare_batch(eng, oracles, out, label=''):
 
 
 def run_batch(model, params, samp_name, reads, outlier_thresh=5.0, const_scale=None,
-              skip_seq_scaling=False, scale_values=None, seed0=None, max_raw_cpts=200):
-    """reads: list of (raw, seq, stall_ints, samp_ind).  Returns (engine, out, oracles)."""
+              skip_seq_scaling=False, scale_values=None, seed0=None, max_raw_cpts=200,
+              raw_dtype=np.float64):
+    """reads: list of (raw, seq, stall_ints, samp_ind); raw_dtype: the sample type of the upload
+    (the oracle always sees float64).  Returns (engine, out, oracles)."""
     from tombo_amd import _native as N, tombo_stats as ts
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
     eng = _engine()
@@ -136,7 +138,7 @@ def run_batch(model, params, samp_name, reads, outlier_thresh=5.0, const_scale=N
                           for sv in scale_values], dtype=np.float64)
         sv_flags = np.full(n, 3, np.int32)
     stalls = [r[2] for r in reads]
-    eng.upload(p, o, [np.asarray(r[0], np.float64) for r in reads],
+    eng.upload(p, o, [np.asarray(r[0], raw_dtype) for r in reads],
                [ts.encode_seq(r[1]) for r in reads], sv_in=sv_in, sv_flags=sv_flags,
                samp_ind=si, stall_ints=stalls if any(s is not None for s in stalls) else None)
     eng.run()
@@ -152,9 +154,10 @@ def run_batch(model, params, samp_name, reads, outlier_thresh=5.0, const_scale=N
 
 
 @pytest.mark.parametrize('name', golden_names())
-def test_golden_case_on_gpu(golden_case, name):
-    """every committed golden fixture through the HIP path (batch of one) vs the oracle, and the
-    final outputs vs the reference's recorded values"""
+def test_golden_case_on_gpu(golden_case, name, dispatch_form):
+    """every committed golden fixture through the HIP path (batch of one, in the latency AND in the
+    throughput form of event detection / traceback) vs the oracle, and the final outputs vs the
+    reference's recorded values"""
     from tombo_amd import errors
     c = golden_case(name)
     m = c.meta
@@ -164,6 +167,7 @@ def test_golden_case_on_gpu(golden_case, name):
         skip_seq_scaling=m['skip_seq_scaling'], max_raw_cpts=c.max_raw_cpts)
     bad = compare_batch(eng, oracles, out, name)
     assert not bad, '\n'.join(bad)
+    check_forms(eng, dispatch_form, c.params)
     g = c.g
     if c.error:
         assert errors.message(out['status'][0]) == c.error
@@ -175,7 +179,7 @@ def test_golden_case_on_gpu(golden_case, name):
         assert out['score'][0] == float(g['sig_match_score'])
 
 
-def test_mixed_dna_batch_on_gpu():
+def test_mixed_dna_batch_on_gpu(dispatch_form):
     """one ragged batch mixing lengths / paths (adaptive, static fallback, retry, failures)"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
     samp = th.seqSampleType('DNA', False)
@@ -200,10 +204,11 @@ def test_mixed_dna_batch_on_gpu():
     eng, out, oracles = run_batch(model, params, 'DNA', reads)
     bad = compare_batch(eng, oracles, out, 'mixed')
     assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params)
     assert sum(o['status'] == 0 for o in oracles) >= 8
 
 
-def test_many_seeds_w100_on_gpu():
+def test_many_seeds_w100_on_gpu(dispatch_form):
     """BASELINE configs[0] shape (2 kb reads, bandwidth 100, band_bound_thresh 10), 48 seeds"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
     samp = th.seqSampleType('DNA', False)
@@ -220,10 +225,11 @@ def test_many_seeds_w100_on_gpu():
     eng, out, oracles = run_batch(model, params, 'DNA', reads)
     bad = compare_batch(eng, oracles, out, 'w100')
     assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params, require_all_fused=True)
     assert all(o['status'] == 0 for o in oracles)
 
 
-def test_second_iteration_on_gpu(golden_case):
+def test_second_iteration_on_gpu(golden_case, dispatch_form):
     """run_rsqgl_iters (resquiggle.py:1492-1504): re-run with fitted scale values"""
     from tombo_amd import tombo_helper as th
     c = golden_case('dna_b2000_w300')
@@ -234,6 +240,7 @@ def test_second_iteration_on_gpu(golden_case):
                                   [(c.raw, c.seq, None, c.samp_ind())], scale_values=svs)
     bad = compare_batch(eng, oracles, out, 'iter2')
     assert not bad, '\n'.join(bad)
+    check_forms(eng, dispatch_form, c.params)
     np.testing.assert_array_equal(out['segs'], g['it2_segs'])
     assert out['score'][0] == float(g['it2_sig_match_score'])
 
@@ -271,7 +278,7 @@ def _si(nb, seed):
     return si
 
 
-def test_full_size_reads_vs_oracle_on_gpu():
+def test_full_size_reads_vs_oracle_on_gpu(dispatch_form):
     """BASELINE configs[1] shape: 10 kb DNA reads, bandwidth 500 -- 40 reads against the oracle"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
     samp = th.seqSampleType('DNA', False)
@@ -284,6 +291,7 @@ def test_full_size_reads_vs_oracle_on_gpu():
     eng, out, oracles = run_batch(model, params, 'DNA', reads)
     bad = compare_batch(eng, oracles, out, 'cfg2')
     assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params, require_all_fused=True)
     assert all(o['status'] == 0 for o in oracles)
     # (performance guard, not parity: every one of these adaptive reads must have been walked by the
     # chunk-parallel traceback -- a read it leaves costs the whole batch the serial walk's 5 ms)
@@ -291,11 +299,14 @@ def test_full_size_reads_vs_oracle_on_gpu():
     done, path = eng.get(_native.GET_TB_PARALLEL), eng.get(_native.GET_PATH)[:, 0]
     assert np.all(done[path == 1] == 1), 'reads left to the lane-per-read traceback: %r' % (
         np.flatnonzero((path == 1) & (done != 1)).tolist(),)
-    # ... and the score-free event detection (k_detect.h) must have finished all of them
-    assert np.all(eng.get(_native.GET_ED_FUSED) == 1)
+    # ... by the kernel of the form under test (check_forms above has asserted the same of event
+    # detection: k_detect + k_pick finished every read of the throughput form, none was flagged)
+    tbf = eng.get(_native.GET_TB_FORM)
+    assert np.all(tbf[path == 1] == (_native.TB_FORM_PAR16 if dispatch_form == 'throughput' else _native.TB_FORM_PAR64))
+    assert np.all(eng.get(_native.GET_ED_FUSED) == (1 if dispatch_form == 'throughput' else 0))
 
 
-def test_long_reads_vs_oracle_on_gpu():
+def test_long_reads_vs_oracle_on_gpu(dispatch_form):
     """Reads well past one 8 192-element summation chunk of np.mean, 16-row traceback blocks by the
     thousand and several event-detection tiles: 18 kb, 25 kb and 37 kb next to a short one"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
@@ -309,10 +320,11 @@ def test_long_reads_vs_oracle_on_gpu():
     eng, out, oracles = run_batch(model, params, 'DNA', reads)
     bad = compare_batch(eng, oracles, out, 'long')
     assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params)
     assert all(o['status'] == 0 for o in oracles)
 
 
-def test_default_bandwidth_ragged_batch_on_gpu():
+def test_default_bandwidth_ragged_batch_on_gpu(dispatch_form):
     """BASELINE configs[2] shape: the adaptive path at Tombo's default bandwidth 300, ragged
     lengths"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
@@ -330,10 +342,11 @@ def test_default_bandwidth_ragged_batch_on_gpu():
     eng, out, oracles = run_batch(model, params, 'DNA', reads)
     bad = compare_batch(eng, oracles, out, 'w300')
     assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params)
     assert sum(o['status'] == 0 for o in oracles) >= 28
 
 
-def test_rna_batch_on_gpu():
+def test_rna_batch_on_gpu(dispatch_form):
     """BASELINE configs[3] shape: direct RNA model, t-test segmentation, stall masking, event
     based scaling, raw_min_obs_per_base = 2 in the skipped-base DP"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
@@ -351,10 +364,11 @@ def test_rna_batch_on_gpu():
     eng, out, oracles = run_batch(model, params, 'RNA', reads)
     bad = compare_batch(eng, oracles, out, 'rna')
     assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params)
     assert sum(o['status'] == 0 for o in oracles) >= 6
 
 
-def test_long_read_kernels_vs_oracle_on_gpu():
+def test_long_read_kernels_vs_oracle_on_gpu(dispatch_form):
     """k_long.h: reads past TBA_LONG_RAW samples / TBA_LONG_BASES bases get a workgroup-per-read
     cumulative sum and a wavefront-per-read traceback -- 60 kb and 29 kb reads (long by both / by
     samples only), a 26 kb read at bandwidth 300 whose band runs off the events (failure path),
@@ -377,10 +391,11 @@ def test_long_read_kernels_vs_oracle_on_gpu():
         eng, out, oracles = run_batch(model, params, 'DNA', reads)
         bad = compare_batch(eng, oracles, out, 'long%d' % bw)
         assert not bad, '\n'.join(bad[:40])
+        check_forms(eng, dispatch_form, params)
         assert sum(o['status'] == 0 for o in oracles) >= len(specs) - 1
 
 
-def test_long_rna_reads_vs_oracle_on_gpu():
+def test_long_rna_reads_vs_oracle_on_gpu(dispatch_form):
     """RNA reads of 6 and 9 kb (260 k / 390 k samples: dozens of event-detection tiles at radius
     5, every LDS class of the skipped-base windows, a stall in the longer one)"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
@@ -397,10 +412,11 @@ def test_long_rna_reads_vs_oracle_on_gpu():
     eng, out, oracles = run_batch(model, params, 'RNA', reads)
     bad = compare_batch(eng, oracles, out, 'rna_long')
     assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params)
     assert sum(o['status'] == 0 for o in oracles) >= 2
 
 
-def test_batch_properties_at_scale_on_gpu():
+def test_batch_properties_at_scale_on_gpu(dispatch_form):
     """size-independent properties on a larger batch (no oracle): monotone boundaries, trimmed
     signal covered exactly, determinism across runs, independence from batch composition"""
     import hashlib
@@ -449,7 +465,7 @@ def test_batch_properties_at_scale_on_gpu():
     assert [h for _, h, *_ in part] == [full[i][1] for i in sub], 'depends on batch composition'
 
 
-def test_degenerate_inputs_on_gpu():
+def test_degenerate_inputs_on_gpu(dispatch_form):
     """too-short sequence, tiny signal, constant signal: a status, never a crash"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th, resquiggle as rq
     samp = th.seqSampleType('DNA', False)
@@ -465,6 +481,92 @@ def test_degenerate_inputs_on_gpu():
     assert all(isinstance(r, Exception) for r in res[:4])
     assert isinstance(res[3], th.TomboError) and 'Invalid sequence' in str(res[3])
     assert not isinstance(res[4], Exception) and res[4].segs.shape[0] == 501
+
+
+def test_degenerate_scale_vs_oracle_on_gpu(dispatch_form):
+    """Scale values the throughput form's loader cannot take through its reciprocal division: a MAD of
+    exactly 0 (flat or saturated signal: the reference divides by it under np.seterr(all='raise') and
+    dies with a FloatingPointError -- tests/golden/degenerate_cases.json; TBA_INTERNAL in both forms),
+    and a signal scaled by 2^600 / 2^-600 (scale outside 2^-500 .. 2^500: k_normalize writes that read's
+    normalised signal itself by true division and flags it for the kernels that keep the scores)"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th, _native as N
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    seq, raw, _ = synth.synth_read(model, 700, 424242, **synth.DNA_SYNTH)
+    sat = raw.copy()
+    sat[np.argsort(raw)[:raw.shape[0] // 2 + 200]] = np.median(raw)    # more than half the samples equal
+    reads = [(raw, seq, None, None), (np.full(raw.shape[0], 431.0), seq, None, None), (sat, seq, None, None),
+             (raw * 2.0 ** 600, seq, None, None), (raw * 2.0 ** -600, seq, None, None), (raw, seq, None, None)]
+    eng, out, oracles = run_batch(model, params, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'degenerate')
+    assert not bad, '\n'.join(bad[:20])
+    assert [o['status'] for o in oracles] == [0, 100, 100, 0, 0, 0]
+    ed, _ = check_forms(eng, dispatch_form, params)
+    if dispatch_form == 'throughput':
+        assert ed.tolist() == [N.ED_FORM_DETECT_PICK, N.ED_FORM_NONE, N.ED_FORM_NONE, N.ED_FORM_SCORES_PEAKS,
+                               N.ED_FORM_SCORES_PEAKS, N.ED_FORM_DETECT_PICK]
+    # exact powers of two: the scaled reads are the first read again, boundary for boundary
+    s0, s1 = eng.seg_off[0], eng.seg_off[1]
+    for k in (3, 4):
+        np.testing.assert_array_equal(out['segs'][eng.seg_off[k]:eng.seg_off[k + 1]], out['segs'][s0:s1])
+    # the same on int16 DAC values (k_normalize's integer-histogram medians; the reference's recorded
+    # cases of tests/golden/degenerate_cases.json)
+    from test_oracle_golden import degenerate_cases, degenerate_signal
+    dac = np.round(raw).astype(np.int16)
+    reads = [(dac, seq, None, None)]
+    for case in degenerate_cases():
+        if case['dtype'] == 'int16':
+            assert case['raised'] == 'FloatingPointError'
+            reads.append((degenerate_signal(case), seq, None, None))
+    reads.append((dac[::-1].copy(), seq, None, None))
+    eng, out, oracles = run_batch(model, params, 'DNA', reads, raw_dtype=np.int16)
+    bad = compare_batch(eng, oracles, out, 'degenerate-i16')
+    assert not bad, '\n'.join(bad[:20])
+    assert [o['status'] for o in oracles][:3] == [0, 100, 100]
+
+
+def test_big_batch_in_the_default_dispatch_vs_oracle_on_gpu():
+    """One batch ABOVE both dispatch thresholds with the engine's defaults untouched -- 1 152 reads, what
+    any batch of more than 1 024 reads (the 10 000-read benchmark batch) runs: k_normalize without
+    its last pass, k_detect<2> + k_pick, k_main_tb_par<16> -- stage by stage against the oracle.
+    400-900-base reads (adaptive path), a few static-path and failing reads, two 10 kb reads (90 k
+    samples: 700 detector steps, 20-read workgroups with ragged lengths), int16-valued and flat ones."""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th, _native as N
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    rng = np.random.default_rng(2026)
+    reads = []
+    for i in range(1152):
+        nb = int(rng.integers(400, 900))
+        kw = dict(synth.DNA_SYNTH)
+        if i % 97 == 0:
+            nb = 10000
+        elif i % 53 == 0:
+            nb = int(rng.integers(20, 240))       # whole-read static band
+        elif i % 41 == 0:
+            kw['mean_dwell'] = 400                 # band failure
+        elif i % 29 == 0:
+            kw['noise_sd'] = 0.7
+        seq, raw, _ = synth.synth_read(model, nb, 5150000 + i, **kw)
+        if i % 31 == 0:
+            raw = np.round(raw)                    # DAC-like values: exact score ties
+        if i == 700:
+            raw = np.full(raw.shape[0], 500.0)     # flat: MAD == 0
+        reads.append((raw, seq, None, _si(nb, i)))
+    eng = _engine()
+    assert eng.get_dispatch() == (1024, 1024)
+    eng, out, oracles = run_batch(model, params, 'DNA', reads)
+    bad = compare_batch(eng, oracles, out, 'big')
+    assert not bad, '%d mismatches\n' % len(bad) + '\n'.join(bad[:40])
+    assert sum(o['status'] == 0 for o in oracles) >= 1000
+    ed, tb = check_forms(eng, 'throughput', params)
+    path = eng.get(N.GET_PATH)[:, 0]
+    ok = np.array([o['status'] == 0 for o in oracles])
+    assert (ed[ok] == N.ED_FORM_DETECT_PICK).mean() >= 0.95, np.bincount(ed)
+    assert np.all(tb[ok & (path == 1)] == N.TB_FORM_PAR16), np.bincount(tb)
+    assert (ok & (path == 1)).sum() >= 900 and (ok & (path == 2)).sum() >= 10
 
 
 def test_wide_static_band_matches_oracle():

@@ -128,3 +128,51 @@ def test_numpy_restatements():
         out = np.zeros(n)
         L.orc_linspace(a, b, n, out.ctypes.data_as(C.POINTER(C.c_double)))
         np.testing.assert_array_equal(out, np.linspace(a, b, n))
+
+
+def degenerate_signal(case):
+    """the signal of a tests/golden/degenerate_cases.json record (as gen_golden_degenerate.make)"""
+    rng = np.random.default_rng(case['seed'])
+    x = rng.normal(90.0, 12.0, case['n'])
+    if case['kind'] == 'flat':
+        x[:] = case['value']
+    elif case['kind'] == 'saturated':
+        x[rng.permutation(case['n'])[:case['n'] // 2 + case['extra']]] = case['value']
+    elif case['kind'] == 'half':
+        x[rng.permutation(case['n'])[:case['n'] // 2]] = case['value']
+    if case['dtype'] == 'int16':
+        x = np.round(x).astype(np.int16)
+    return x
+
+
+def degenerate_cases():
+    import os
+    import json
+    from conftest import GOLDEN_DIR
+    with open(os.path.join(GOLDEN_DIR, 'degenerate_cases.json')) as fp:
+        return json.load(fp)
+
+
+def test_oracle_follows_the_reference_on_a_zero_mad():
+    """a flat / saturated signal: the live reference raised FloatingPointError in the division by the
+    scale (np.seterr(all='raise')) -> the read's unexpected error, status 100; otherwise its scale values"""
+    from tombo_amd import synth, tombo_helper as th
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    seq = synth.synth_read(model, 400, 1, **synth.DNA_SYNTH)[0]
+    p = oracle.make_params(params)
+    o = oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0,
+                         sig_match_thresh=SIG_MATCH_THRESH['DNA'])
+    n_raised = 0
+    for case in degenerate_cases():
+        x = degenerate_signal(case).astype(np.float64)
+        r = oracle.resquiggle_read(x, ts.encode_seq(seq), model.level_means, model.level_sds, p, o, debug=True)
+        if case['raised']:
+            assert case['raised'] == 'FloatingPointError' and not case['is_tombo_error']
+            assert r['status'] == 100, case
+            n_raised += 1
+        else:
+            assert r['status'] != 100, case     # (noise against a sequence: some TomboError, not a crash)
+            assert r['dbg']['seg_scale_values'][0] == case['shift'] and r['dbg']['seg_scale_values'][1] == case['scale'], case
+    assert n_raised >= 4

@@ -51,6 +51,13 @@ def _cpts(fn, raw_signal, min_base_obs, running_stat_width, num_cpts):
     return out
 
 
+def last_ed_form():
+    """_native.ED_FORM_* of the kernels that produced the last c_valid_cpts_w_cap[_t_test] result
+    (these entries follow the engine's dispatch like a batch of one read: Engine.set_dispatch)"""
+    eng = _engine()
+    return int(eng._L.tba_c_last_ed_form(eng._h))
+
+
 def c_valid_cpts_w_cap(raw_signal, min_base_obs, running_stat_width, num_cpts):
     return _cpts('tba_c_valid_cpts_w_cap', raw_signal, min_base_obs, running_stat_width, num_cpts)
 

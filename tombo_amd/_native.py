@@ -84,14 +84,18 @@ GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
     GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL, \
     GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND, GET_TB_PARALLEL, GET_ED_FUSED, GET_ED_TAKEN_POS, GET_ED_N_TAKEN, \
-    GET_DP_WORKGROUP = range(1, 29)
+    GET_DP_WORKGROUP, GET_ED_FORM, GET_TB_FORM = range(1, 31)
+# TBA_ED_FORM_* / TBA_TB_FORM_*: which kernels produced a read's change points / main traceback
+ED_FORM_NONE, ED_FORM_WG_SCAN_PEAKS, ED_FORM_DETECT_PICK, ED_FORM_SCORES_PEAKS, ED_FORM_DETECT_TT_PICK, \
+    ED_FORM_TTEST_PEAKS = range(6)
+TB_FORM_NONE, TB_FORM_LANE, TB_FORM_LONG, TB_FORM_PAR16, TB_FORM_PAR64 = 0, 1, 2, 16, 64
 GET_DEBUG_COUNTERS = 99  # ReadState.dbg of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS profiling build
 STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, STAGE_SKIP, \
     STAGE_RESCALE = range(7)
 PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
     PUT_START_STATE = range(1, 8)
 MAX_BAND = 3072
-ABI_VERSION = 6  # TBA_ABI_VERSION of include/tombo_amd.h
+ABI_VERSION = 7  # TBA_ABI_VERSION of include/tombo_amd.h
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
                "rescale_score", "stalls", "total"]
@@ -374,6 +378,18 @@ class Engine(object):
         self._check(self._L.tba_engine_set_dp_workgroup_batch(self._h, i64(int(max_reads))),
                     'tba_engine_set_dp_workgroup_batch')
 
+    def set_dispatch(self, small_batch_reads=-1, tb_wave_below=-1):
+        """read-count thresholds between the latency and the throughput forms of DNA event detection
+        and of the main traceback (tba_engine_set_dispatch; identical results; default 1 024 each;
+        0: every batch takes the throughput form; negative: unchanged); from the next run"""
+        self._check(self._L.tba_engine_set_dispatch(self._h, i64(int(small_batch_reads)), i64(int(tb_wave_below))),
+                    'tba_engine_set_dispatch')
+
+    def get_dispatch(self):
+        a, b = i64(0), i64(0)
+        self._check(self._L.tba_engine_get_dispatch(self._h, C.byref(a), C.byref(b)), 'tba_engine_get_dispatch')
+        return int(a.value), int(b.value)
+
     def host_stage(self):
         """this engine's reusable page-locked staging arrays (PinnedStage)"""
         st = getattr(self, '_stage', None)
@@ -449,6 +465,7 @@ class Engine(object):
             GET_N_STALL: (np.int64, n), GET_STALL_OFF: (np.int64, n),
             GET_SAMP_IND: (np.int64, (n, 1000)),
             GET_TB_PARALLEL: (np.int32, n), GET_ED_FUSED: (np.int32, n), GET_DP_WORKGROUP: (np.int32, n),
+            GET_ED_FORM: (np.int32, n), GET_TB_FORM: (np.int32, n),
             GET_ED_TAKEN_POS: (np.int32, 2 * self.n_raw_total), GET_ED_N_TAKEN: (np.int64, n),
         }
         if what in (GET_VALID_CPTS, GET_EVENT_MEANS):

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_detect(ReadState *rs, i64 n_reads, c
     if (tid < DT_READS) {
         const i64 ri = r0 + tid;
         const bool ok = ri < n_reads && rs[ri].status == TBA_OK;
-        const bool live = ok && !rs[ri].is_long;
+        const bool live = ok && !rs[ri].is_long && !rs[ri].ed_flag; // (flagged by k_normalize: scale out of the loader's range)
         s_off[tid] = live ? rs[ri].raw_off : 0;
         s_n[tid] = live ? rs[ri].n_raw : 0;
         s_st[tid] = live ? rs[ri].raw_off : dump_off;  // where the row's normalised samples go
@@ -434,6 +434,8 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_pick(ReadState *rs, const DevPara
     ReadState &r = rs[blockIdx.x];
     if (r.status != TBA_OK || r.ed_flag) return;
     const int tid = threadIdx.x;
+    // (a read this kernel gives up below is flagged and k_peaks, which runs later, overwrites the form)
+    if (tid == 0) r.ed_form = ttest ? TBA_ED_FORM_DETECT_TT_PICK : TBA_ED_FORM_DETECT_PICK;
     const i64 w = dp->p.running_stat_width;
     const i64 ns = ttest ? r.n_raw - 2 * w : r.n_raw + 1 - 2 * w, num_cands = ttest ? ns : ns - 2 * w;
     const i64 num_cpts = r.num_events;

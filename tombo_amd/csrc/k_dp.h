@@ -954,6 +954,7 @@ __global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const D
     ReadState &r = rs[ri];
     r.moves_off = 0;
     r.tb_done = 0;
+    r.tb_form = TBA_TB_FORM_NONE;
     r.dp_wg = 0;
     if (r.status != TBA_OK) return;
     const tba_params &P = dp->p;
@@ -1091,6 +1092,7 @@ __global__ __launch_bounds__(64) void k_main_tb(ReadState *rs, i64 n_reads, cons
     if (r.path == PATH_NONE) { r.status = TBA_INTERNAL; return; }
     if (r.tb_done) return;                              // walked chunk-parallel (k_tb_par.h)
     if (r.is_long && r.path == PATH_ADAPTIVE && r.W <= 1024) return; // k_main_tb_long (k_long.h)
+    r.tb_form = TBA_TB_FORM_LANE;
     const i64 B = r.B;
     const int Wi = (int)r.W;
     const int rowb = (int)mv_row_bytes(r.W);            // bytes per packed row (multiple of 64)

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64) void k_main_tb_long(ReadState *rs, const i32 *l
     ReadState &r = rs[ri];
     if (r.status != TBA_OK || !tb_long_takes(r) || r.tb_done) return;
     const int lane = threadIdx.x;
+    if (lane == 0) r.tb_form = TBA_TB_FORM_LONG;
     const int B = (int)uni(r.B), Wi = (int)uni(r.W);
     const int rowb = (int)mv_row_bytes(Wi), roww = rowb / 4;
     const unsigned char *mv = uni(moves + r.moves_off);

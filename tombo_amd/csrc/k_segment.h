@@ -152,12 +152,24 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_normalize(ReadState *rs, const De
             have_lims = true;
         }
     }
+    // A scale of exactly 0 (the MAD of a flat signal, e.g. a saturated int16 read): the reference
+    // divides by it under np.seterr(all='raise') (resquiggle.py:29, tombo_stats.py:19,553) and dies
+    // with a FloatingPointError -- an unexpected error, whatever the batch size or the form.
+    if (scale == 0.0) {
+        if (tid == 0) r.status = TBA_INTERNAL;
+        return;
+    }
     // The normalised signal is written once, at the end: the passes in between recompute
     // (x - shift) / scale on the fly (same operation, same bits).
     TBA_PHASE(2, 3);
     // write_norm == 2: only the reads whose normalised signal k_detect's loader (k_detect.h) will not
-    // write on its way: the long ones (k_long.h takes their scan)
-    if (write_norm == 1 || (write_norm == 2 && r.is_long)) {
+    // write on its way: the long ones (k_long.h takes their scan), and the reads whose scale is
+    // outside the range in which the loader's reciprocal form of the division is the division bit
+    // for bit (no overflow or underflow of quotient and residuals for any sample: 2^-500 .. 2^500,
+    // NaN fails the test too) -- those are flagged for the kernels that keep the scores here
+    const bool recip_ok = fabs(scale) >= 0x1p-500 && fabs(scale) <= 0x1p500 && fabs(shift) <= 0x1p500;
+    if (write_norm == 2 && !recip_ok && tid == 0) r.ed_flag = 1;
+    if (write_norm == 1 || (write_norm == 2 && (r.is_long || !recip_ok))) {
         if (have_lims) {
             // c_apply_outlier_thresh, _c_helper.pyx:73-87
             block_map2<2>(n, x, y, [&](double xv) {
@@ -688,7 +700,7 @@ __device__ i64 peaks_bits(const double *s, unsigned char *st, i64 ns, double *de
 template <int RT>
 __global__ __launch_bounds__(SEL_NT, 4) void k_peaks(ReadState *rs, const DevParams *dp,
     const double *score, unsigned char *state, double *dense, i64 *valid_cpts, int ttest,
-    int only_flagged = 0)
+    int only_flagged = 0, int form = TBA_ED_FORM_SCORES_PEAKS)
 {
     __shared__ BucketSmem sm;
     __shared__ i64 s_w[SEL_NT / 64];
@@ -698,6 +710,8 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_peaks(ReadState *rs, const DevPar
     if (r.status != TBA_OK) return;
     if (only_flagged && !r.ed_flag) return; // k_detect / k_pick (k_detect.h) finished this read
     const int tid = threadIdx.x;
+    // (the long reads of any batch are scanned a workgroup each, k_long.h: the latency form)
+    if (tid == 0) r.ed_form = form == TBA_ED_FORM_SCORES_PEAKS && r.is_long && 2 * dp->p.running_stat_width <= 64 ? TBA_ED_FORM_WG_SCAN_PEAKS : form;
     const i64 w = dp->p.running_stat_width, m = dp->p.min_obs_per_base;
     const i64 ns = ttest ? r.n_raw - 2 * w : r.n_raw + 1 - 2 * w;
     const i64 num_cands = ttest ? ns : ns - 2 * w;

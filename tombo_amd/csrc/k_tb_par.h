@@ -238,6 +238,7 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     __threadfence_block(); // the lanes' read_tb entries, before lane 0 of the group reads them back
     if (!on || c != 0 || broken) return;            // (broken: k_main_tb walks this read)
     r.tb_done = 1;
+    r.tb_form = LPR; // TBA_TB_FORM_PAR16 / TBA_TB_FORM_PAR64
     if (status != TBA_OK) { r.status = status; return; }
     // _trim_traceback (resquiggle.py:754-764) and the first base's change point, as k_main_tb
     const i64 n_ev = r.n_ev - r.clip;

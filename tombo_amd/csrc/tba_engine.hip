@@ -86,11 +86,12 @@ static const char *STAGE_NAMES[N_STAGE] = {
 // the DNA / RNA parameter sets, anything else takes the generic kernel
 static void launch_peaks(i64 min_obs_per_base, unsigned n_blocks, hipStream_t s, ReadState *rs,
                          const DevParams *dp, const double *score, unsigned char *state,
-                         double *dense, i64 *valid_cpts, int ttest, int only_flagged = 0)
+                         double *dense, i64 *valid_cpts, int ttest, int only_flagged = 0,
+                         int form = TBA_ED_FORM_SCORES_PEAKS)
 {
-    if (min_obs_per_base - 1 == 2) k_peaks<2><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged);
-    else if (min_obs_per_base - 1 == 5) k_peaks<5><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged);
-    else k_peaks<0><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged);
+    if (min_obs_per_base - 1 == 2) k_peaks<2><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged, form);
+    else if (min_obs_per_base - 1 == 5) k_peaks<5><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged, form);
+    else k_peaks<0><<<n_blocks, SEL_NT, 0, s>>>(rs, dp, score, state, dense, valid_cpts, ttest, only_flagged, form);
 }
 struct tba_engine {
     int device = 0;
@@ -107,6 +108,9 @@ struct tba_engine {
     double algo_bytes = 0, dp_cells = 0;
     int n_sharing = 1;            // engines fed concurrently on this device (tba_engine_set_sharing)
     i64 dp_wg_batch = TBA_WG_BATCH; // batches up to this many reads: main forward pass by workgroup (k_dp_wgm.h)
+    // latency / throughput forms of event detection and traceback (tba_engine_set_dispatch)
+    i64 small_batch = TBA_SMALL_BATCH, tb_wave_below = TBP_WAVE_BELOW;
+    int last_c_ed_form = 0;       // tba_c_last_ed_form
     int raw_dtype = TBA_RAW_F64;
     PinBuf h_rs, h_dp;            // ReadState[n] / DevParams as uploaded (pinned)
     DevBuf d_res, d_segs32;       // packed results of tba_batch_download_async
@@ -159,6 +163,8 @@ extern "C" int tba_engine_create(int device, tba_engine **out)
     e->device = device;
     // (A/B runs and the test suite in both forms of the main forward pass: tba_engine_set_dp_workgroup_batch)
     if (const char *v = getenv("TBA_DP_WG_BATCH")) e->dp_wg_batch = atoll(v);
+    if (const char *v = getenv("TBA_SMALL_BATCH_READS")) e->small_batch = std::max<i64>(atoll(v), 0);
+    if (const char *v = getenv("TBA_TB_WAVE_BELOW")) e->tb_wave_below = std::max<i64>(atoll(v), 0);
     HIP_TRY(hipStreamCreate(&e->stream));
     for (int i = 0; i <= N_STAGE; i++) HIP_TRY(hipEventCreate(&e->ev[i]));
     *out = e;
@@ -643,7 +649,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     // k_cumsum_scores pay a pipeline step (barrier, memory round trip, greedy: ~7 us) per 128 samples
     // whatever the batch, 5 ms for a 10 kb read; a workgroup per read (k_long.h: the step is 1 856
     // dependent adds long) does the same in 0.5 ms.  (resquiggle_read, a batch of one: 20.4 -> 16 ms.)
-    const bool wg_scan = !rna && fused_scores && n <= TBA_SMALL_BATCH && (size_t)n * 4 <= e->d_order.cap;
+    const bool wg_scan = !rna && fused_scores && n <= e->small_batch && (size_t)n * 4 <= e->d_order.cap;
 #ifdef TBA_NO_FUSED_DETECT
     const bool fused_tt = false;
 #else
@@ -683,7 +689,8 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 3 peaks
     if (ON(TBA_STAGE_SEGMENT)) {
-        launch_peaks(P.min_obs_per_base, nb, s, rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0, only_flagged);
+        launch_peaks(P.min_obs_per_base, nb, s, rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0, only_flagged,
+                     rna ? TBA_ED_FORM_TTEST_PEAKS : wg_scan ? TBA_ED_FORM_WG_SCAN_PEAKS : TBA_ED_FORM_SCORES_PEAKS);
         if (e->any_stall) k_remove_stalls<<<nb, SEL_NT, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>(), e->d_csum.as<double>());
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
             RAW_DISPATCH(rdt, (k_event_means<RT, 1280><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 1)));
@@ -743,9 +750,9 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         // rows of a read over several lanes (k_tb_par.h): 16 lanes per read when the reads fill the
         // machine, a wavefront per read for small batches and for the long reads; what it leaves
         // (static bands, failed verification) is walked by the lane-per-read kernels below
-        if (n > TBP_WAVE_BELOW) k_main_tb_par<16><<<(unsigned)((n + 3) / 4), 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        if (n > e->tb_wave_below) k_main_tb_par<16><<<(unsigned)((n + 3) / 4), 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         else k_main_tb_par<64><<<nb, 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
-        if (e->n_long > 0 && n > TBP_WAVE_BELOW) k_main_tb_par<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        if (e->n_long > 0 && n > e->tb_wave_below) k_main_tb_par<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
 #endif
         k_main_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         if (e->n_long > 0) k_main_tb_long<<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
@@ -1038,14 +1045,20 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
         for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].status;
         return 0;
     }
-    if (what == TBA_GET_ED_FUSED) {
+    if (what == TBA_GET_ED_FUSED) { // (by the form the kernels recorded, not by the absence of a flag)
         if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
-        for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].ed_flag ? 0 : 1;
+        for (size_t i = 0; i < N; i++)
+            ((i32 *)out)[i] = rs[i].ed_form == TBA_ED_FORM_DETECT_PICK || rs[i].ed_form == TBA_ED_FORM_DETECT_TT_PICK;
         return 0;
     }
     if (what == TBA_GET_TB_PARALLEL) {
         if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
         for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].tb_done;
+        return 0;
+    }
+    if (what == TBA_GET_ED_FORM || what == TBA_GET_TB_FORM) {
+        if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
+        for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = what == TBA_GET_ED_FORM ? rs[i].ed_form : rs[i].tb_form;
         return 0;
     }
     if (what == TBA_GET_DP_WORKGROUP) {
@@ -1389,22 +1402,49 @@ static int c_valid_cpts(tba_engine *e, const double *sig, int64_t n, int64_t min
     C_TRY(hipMemcpy(d_dp.p, &dp, sizeof(dp), hipMemcpyHostToDevice));
     hipStream_t s = e->stream;
     const unsigned g = grid_for(n) > 128 ? 128 : grid_for(n);
+    // The score-free kernels of the batch pipeline (k_detect.h) when the engine's dispatch sends a
+    // batch of one read through the throughput form (tba_engine_set_dispatch(0, ...): the parity tests
+    // of this entry in both forms) and for the t-test scores at RNA's defaults; the kernels that keep
+    // the scores then run on what those left (flagged reads) -- exactly the batch pipeline's sequence.
+    int only_flagged = 0;
+    if (!ttest && e->small_batch < 1 && 2 * width <= DT_W2MAX && min_base_obs == 3) {
+        // (shift 0, scale 1, no limits: the loader's normalised copy of the signal is the signal)
+        Tmp d_norm;
+        if (d_norm.alloc((size_t)(n + 2) * 8 + 64)) return set_err(TBA_E_NOMEM, "hipMalloc failed");
+        r.shift = 0.0; r.scale = 1.0;
+        r.is_long = n > TBA_LONG_RAW;
+        C_TRY(hipMemcpy(d_rs.p, &r, sizeof(r), hipMemcpyHostToDevice));
+        k_detect<2, double><<<1, 256, 0, s>>>(d_rs.as<ReadState>(), 1, d_dp.as<DevParams>(), d_sig.as<double>(), d_norm.as<double>(), d_csum.as<double>(), d_score.as<double>(), n);
+        k_pick<<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_csum.as<double>(), d_score.as<double>(), d_cpts.as<i64>(), 0);
+        C_TRY(hipStreamSynchronize(s)); // (d_norm is released at the end of this scope)
+        only_flagged = 1;
+    } else if (ttest && e->small_batch < 1 && min_base_obs == 6 && width <= TT_MAXW) {
+        if (width == 12) k_detect_tt<5, 12, double><<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_csum.as<double>(), d_score.as<double>());
+        else k_detect_tt<5, 0, double><<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_csum.as<double>(), d_score.as<double>());
+        k_pick<<<1, SEL_NT, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_csum.as<double>(), d_score.as<double>(), d_cpts.as<i64>(), 1);
+        only_flagged = 1;
+    }
     if (!ttest && 2 * width <= 64) { // the batch pipeline's fused form
-        k_cumsum_scores<32><<<1, 256, 0, s>>>(d_rs.as<ReadState>(), 1, d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
+        k_cumsum_scores<32><<<1, 256, 0, s>>>(d_rs.as<ReadState>(), 1, d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>(), only_flagged);
     } else if (!ttest) {
         k_cumsum<<<1, 64, 0, s>>>(d_rs.as<ReadState>(), 1, d_sig.as<double>(), d_csum.as<double>());
         k_scores_dna<<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_csum.as<double>(), d_score.as<double>());
     } else {
-        k_scores_ttest<double><<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>());
+        k_scores_ttest<double><<<dim3(g, 1), 256, 0, s>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_score.as<double>(), only_flagged);
     }
     launch_peaks(min_base_obs, 1, s, d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_score.as<double>(),
-                                 d_state.as<unsigned char>(), d_csum.as<double>(), d_cpts.as<i64>(), ttest);
+                                 d_state.as<unsigned char>(), d_csum.as<double>(), d_cpts.as<i64>(), ttest, only_flagged,
+                                 ttest ? TBA_ED_FORM_TTEST_PEAKS : TBA_ED_FORM_SCORES_PEAKS);
     C_TRY(hipGetLastError());
     C_TRY(hipStreamSynchronize(s));
     C_TRY(hipMemcpy(&r, d_rs.p, sizeof(r), hipMemcpyDeviceToHost));
     if (r.status == TBA_OK) C_TRY(hipMemcpy(cpts, d_cpts.p, (size_t)num_cpts * 8, hipMemcpyDeviceToHost));
+    e->last_c_ed_form = r.ed_form;
     return r.status;
 }
+
+// which kernels produced the result of the last tba_c_valid_cpts_w_cap[_t_test] call (TBA_ED_FORM_*)
+extern "C" int tba_c_last_ed_form(tba_engine *e) { return e ? e->last_c_ed_form : 0; }
 
 extern "C" int tba_c_valid_cpts_w_cap(tba_engine *e, const double *sig, int64_t n,
     int64_t min_base_obs, int64_t running_stat_width, int64_t num_cpts, int64_t *cpts)
@@ -2071,6 +2111,21 @@ extern "C" int tba_engine_set_dp_workgroup_batch(tba_engine *e, int64_t max_read
 {
     if (!e) return set_err(TBA_E_ARG, "engine is NULL");
     e->dp_wg_batch = max_reads;
+    return 0;
+}
+
+extern "C" int tba_engine_set_dispatch(tba_engine *e, int64_t small_batch_reads, int64_t tb_wave_below)
+{
+    if (!e) return set_err(TBA_E_ARG, "engine is NULL");
+    if (small_batch_reads >= 0) e->small_batch = small_batch_reads;
+    if (tb_wave_below >= 0) e->tb_wave_below = tb_wave_below;
+    return 0;
+}
+extern "C" int tba_engine_get_dispatch(tba_engine *e, int64_t *small_batch_reads, int64_t *tb_wave_below)
+{
+    if (!e) return set_err(TBA_E_ARG, "engine is NULL");
+    if (small_batch_reads) *small_batch_reads = e->small_batch;
+    if (tb_wave_below) *tb_wave_below = e->tb_wave_below;
     return 0;
 }
 
