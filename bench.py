@@ -364,6 +364,27 @@ def self_launch(n):
     sys.exit(rc)
 
 
+def early_store(world):
+    """A client of the launcher's rendezvous store (torchrun's agent store, or self_launch's), before
+    the process group exists: used for ONE flag -- rank 0 raises 'tba_cpu_legs_done' when its CPU
+    baseline legs are over, the other ranks wait for it before they start anything that loads the
+    host (read synthesis workers, generators, pack threads).  None when there is no such store yet
+    (a bare env:// launch whose rank 0 creates the store inside init_process_group): no wait then."""
+    try:
+        import torch.distributed as dist
+        from datetime import timedelta
+        if 'TBA_STORE_PORT' in os.environ:
+            addr, port = '127.0.0.1', int(os.environ['TBA_STORE_PORT'])
+        elif os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '').lower() in ('1', 'true'):
+            addr, port = os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ['MASTER_PORT'])
+        else:
+            return None
+        return dist.TCPStore(addr, port, world, is_master=False, timeout=timedelta(seconds=1800),
+                             wait_for_workers=False)
+    except Exception:
+        return None
+
+
 def init_control_plane(rank, world):
     """gloo process group for the barrier / reductions / per-rank report (never RCCL: ranks of a
     resquiggle job exchange no data).  Under torchrun the env:// rendezvous of the launcher is
@@ -507,7 +528,8 @@ def finish_cfg5(a, job, ctx, dist, json_fd, cpu_legs, dev_name, ndev, t_start, t
                     job_batches=job['my_batches'], job_reads=job['my_reads'],
                     first_reads_drawn=[f for _, f in job['drawn']],
                     reads_per_s=round(job['my_reads'] / job['my_dt'], 2) if job['my_dt'] > 0 else 0.0,
-                    busy_s=round(job['my_dt'], 4))
+                    busy_s=round(job['my_dt'], 4), host_threads=ctx['workers'],
+                    waited_for_cpu_legs_s=round(ctx['t_wait_cpu'], 1))
     per_rank = [rank_rec]
     if dist is not None:
         per_rank = [None] * world
@@ -648,9 +670,46 @@ def main():
     if a.bandwidth <= 100:
         params = params._replace(band_bound_thresh=10)  # the default 40 fails every read at W=100
     stall_params = th.stallParams(**STALL_PARAMS) if rna else None
-    workers = max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))
+    # host threads per rank (synthesis workers, pack threads): the ranks of a node share its cores, and
+    # every rank also runs a feeder thread, a generator helper and its own main thread beside them
+    ncpu = os.cpu_count() or 8
+    workers = max(1, min(32, (ncpu - 3 * world) // max(world, 1) if world > 1 else ncpu))
+    # ranks > 0 stay off the host's cores until rank 0's CPU baseline legs are over
+    es = early_store(world) if world > 1 else None
+    t_wait_cpu = time.perf_counter()
+    if es is not None and rank != 0 and not a.no_cpu_baseline:
+        try:
+            es.wait(['tba_cpu_legs_done'])
+        except Exception:
+            pass
+    t_wait_cpu = time.perf_counter() - t_wait_cpu
     seed0 = 1000003 * (rank + 1)    # every rank has its own, distinct reads
     bases = longtail_bases(a.reads, seed0, a.longtail_max_bases) if longtail else np.full(a.reads, a.bases, np.int64)
+    # The CPU legs run on rank 0 at every N, FIRST: before any HIP state exists, before the control
+    # plane is up and before any rank loads the host with read synthesis (the other ranks wait for
+    # the flag below; the child process makes its own copy of the first reads from their seeds)
+    cpu_legs = None
+    t_cpu = time.perf_counter()
+    if rank == 0 and not a.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        n_cpu = min(a.reads, max(a.cpu_sample, a.cpu_per_core * cores if cores > 1 else 0, 1))
+        job = json.dumps(dict(samp=samp_name, bandwidth=a.bandwidth, bases=[int(b) for b in bases[:n_cpu]],
+                              seed0=seed0, n_single=a.cpu_sample, n_per_core=a.cpu_per_core))
+        env = dict(os.environ)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'TBA_STORE_PORT'):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', job], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1200)
+        lines = [x for x in out.stdout.decode().splitlines() if x.startswith('[')]
+        cpu_legs = json.loads(lines[-1]) if out.returncode == 0 and lines else None
+    t_cpu = time.perf_counter() - t_cpu
+    if es is not None and rank == 0:
+        try:
+            es.set('tba_cpu_legs_done', '1')
+        except Exception:
+            pass
+    es = None   # (the client socket goes before the synthesis workers are forked)
+
     want_dac = a.e2e == 'compact' or a.api_reads > 0
     t_gen = time.perf_counter()
     if cfg5:   # no rank synthesises anything on the host: every batch of the job is drawn on the device
@@ -667,24 +726,6 @@ def main():
         si = None
     n_raw = np.array([len(r) for r in raws], np.int64)
     seq_len = np.array([len(s) for s in seqs], np.int64)
-
-    # the CPU legs run on rank 0 at every N, before any HIP state exists and before the control
-    # plane is up (the other ranks wait for rank 0 in its rendezvous)
-    cpu_legs = None
-    t_cpu = time.perf_counter()
-    if rank == 0 and not a.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        n_cpu = min(a.reads, max(a.cpu_sample, a.cpu_per_core * cores if cores > 1 else 0, 1))
-        job = json.dumps(dict(samp=samp_name, bandwidth=a.bandwidth, bases=[int(b) for b in bases[:n_cpu]],
-                              seed0=seed0, n_single=a.cpu_sample, n_per_core=a.cpu_per_core))
-        env = dict(os.environ)
-        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'TBA_STORE_PORT'):
-            env.pop(k, None)
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', job], env=env,
-                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1200)
-        lines = [x for x in out.stdout.decode().splitlines() if x.startswith('[')]
-        cpu_legs = json.loads(lines[-1]) if out.returncode == 0 and lines else None
-    t_cpu = time.perf_counter() - t_cpu
 
     dist = init_control_plane(rank, world) if world > 1 else None
     import torch
@@ -727,7 +768,8 @@ def main():
         job_reads = a.job_reads if (cfg5 and a.job_reads) else (125000 if cfg5 else 4 * a.reads) * world
         ctx = dict(_native=_native, streaming=streaming, sharding=sharding, model=model, params=params, samp=samp,
                    dev=dev, rank=rank, world=world, barrier=barrier, max_over_ranks=max_over_ranks,
-                   sum_over_ranks=sum_over_ranks, dev_sync=dev_sync, slots=a.slots)
+                   sum_over_ranks=sum_over_ranks, dev_sync=dev_sync, slots=a.slots, workers=workers,
+                   t_wait_cpu=t_wait_cpu)
     if cfg5:
         job = run_job(ctx, job_reads, a.reads, a.bases, a.job_seed)
         return finish_cfg5(a, job, ctx, dist, json_fd, cpu_legs, dev_name, ndev, t_start, t_cpu,
@@ -1007,6 +1049,7 @@ def main():
     if world > 1 and not longtail and not rna and a.bandwidth == 500 and a.bases == 10000:
         job = run_job(ctx, job_reads, a.reads, a.bases, a.job_seed)
         rank_rec.update(job_batches=job['my_batches'], job_reads=job['my_reads'])
+    rank_rec.update(host_threads=workers, waited_for_cpu_legs_s=round(t_wait_cpu, 1))
 
     per_rank = [rank_rec]
     if dist is not None:

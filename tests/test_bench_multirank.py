@@ -93,6 +93,26 @@ def test_cfg5_job_hands_out_every_distinct_batch_once():
     assert r['scaling'] == 'weak' and r['distinct_read_job']['job_reads'] == 125000 and r['steps'] == 5
 
 
+def test_eight_ranks_share_the_host_and_the_job():
+    """--gpus 8 --preset cfg5 (BASELINE.json's scaling configuration) with the stub engine: every batch of
+    the job is drawn once, the per-rank sums add up, the ranks split the host's cores between them, ranks
+    > 0 stay off the host until rank 0's CPU legs are over, and the set-up does not grow with N"""
+    r1 = _run(['--preset', 'cfg5', '--job-reads', '83', '--reads', '5'])
+    r8 = _run(['--gpus', '8', '--preset', 'cfg5', '--job-reads', '83', '--reads', '5'])
+    job = r8['distinct_read_job']
+    assert r8['n_gpus'] == 8 and job['job_reads'] == 83 and job['reads_done'] == 83 and job['batches'] == 17
+    firsts = sorted(f for x in r8['per_rank'] for f in x['first_reads_drawn'])
+    assert firsts == list(range(0, 83, 5))
+    assert sum(x['job_reads'] for x in r8['per_rank']) == 83 and sum(x['job_batches'] for x in r8['per_rank']) == 17
+    assert job['checksum_mod_2_40_summed'] == r1['distinct_read_job']['checksum_mod_2_40_summed']      # the sharding does not show in the results
+    ncpu = os.cpu_count() or 8
+    assert sum(x['host_threads'] for x in r8['per_rank']) <= max(ncpu, 8)
+    assert all(x['waited_for_cpu_legs_s'] >= 0 for x in r8['per_rank'])
+    assert r8['cpu_baseline']['value'] > 0
+    # one CPU-leg child on rank 0 whatever N; the ranks come up in parallel behind it
+    assert r8['config']['setup_s']['total_wall'] <= r1['config']['setup_s']['total_wall'] + 60.0
+
+
 def test_default_two_rank_run_carries_the_distinct_read_job():
     r = _run(['--gpus', '2', '--bases', '10000', '--reads', '3', '--cpu-sample', '1'])
     job = r['distinct_read_job']

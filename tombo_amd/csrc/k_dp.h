@@ -197,13 +197,18 @@ __device__ __forceinline__ void shifted_row(const double (&Q)[CPL], double left,
 // diag / skip candidates of one row for band offset D (pyx:220-231, first cell pyx:392-401):
 // A[j] is cell j's diagonal source and cell j-1's skip source.  Instantiated per offset so the
 // previous row is read straight out of its registers (no renaming moves).  tk bit j: skip taken.
+// Also runs the FIRST sweep of the stay chain (every lane from -inf: exit0 = the lane's exit value
+// with nothing coming in): in the same basic block the chain's dependent adds are scheduled between
+// the independent candidate arithmetic of the cells to their right, instead of as a bare chain of
+// 3 CPL dependent instructions behind the offset switch (-DTBA_DP_SWEEP1_APART: the old order).
 template <int CPL, int D>
 __device__ __forceinline__ void cand_row(const double (&Q)[CPL], double left,
-    const double (&z)[CPL], double skip_pen, bool first_is_skip, bool lane0, double (&cv)[CPL],
-    bool (&tk)[CPL])
+    const double (&z)[CPL], double skip_pen, double stay_pen, bool first_is_skip, bool lane0, double (&cv)[CPL],
+    bool (&tk)[CPL], double &exit0)
 {
     double A[CPL + 1];
     shifted_row<CPL, D>(Q, left, A);
+    double x = -INFINITY;
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
         const double d = A[j] + z[j];
@@ -218,7 +223,11 @@ __device__ __forceinline__ void cand_row(const double (&Q)[CPL], double left,
             cv[j] = max_f64_raw(s, d);
         }
         tk[j] = take_s;
+#ifndef TBA_DP_SWEEP1_APART
+        x = max_f64_raw(cv[j], (x - stay_pen) + z[j]);
+#endif
     }
+    exit0 = x;
 }
 // Q <- Q shifted by S cells (S <= CPL); returns the cell just left of the new Q[0]
 template <int CPL, int S>
@@ -545,6 +554,7 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
         // pp[j] is cell j's diagonal source and cell j-1's skip source
         double cv[CPL];
         bool tk[CPL];
+        double exit0 = NEG_INF;
         {
             int rem = diff_i;
             double left = NEG_INF;
@@ -552,15 +562,15 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
             const bool fs = diff_i == 0, l0 = lane == 0;
             switch (rem) {
             case 0: left = diff_i == 0 ? wave_shr1_f64(v[CPL - 1], NEG_INF) : left;
-                    cand_row<CPL, 0>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            case 1: cand_row<CPL, 1>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            case 2: if constexpr (S >= 2) cand_row<CPL, 2>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            case 3: if constexpr (S >= 3) cand_row<CPL, 3>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            case 4: if constexpr (S >= 4) cand_row<CPL, 4>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            case 5: if constexpr (S >= 5) cand_row<CPL, 5>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            case 6: if constexpr (S >= 6) cand_row<CPL, 6>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            case 7: if constexpr (S >= 7) cand_row<CPL, 7>(v, left, z, skip_pen, fs, l0, cv, tk); break;
-            default: if constexpr (S >= 8) cand_row<CPL, 8>(v, left, z, skip_pen, fs, l0, cv, tk); break;
+                    cand_row<CPL, 0>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            case 1: cand_row<CPL, 1>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            case 2: if constexpr (S >= 2) cand_row<CPL, 2>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            case 3: if constexpr (S >= 3) cand_row<CPL, 3>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            case 4: if constexpr (S >= 4) cand_row<CPL, 4>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            case 5: if constexpr (S >= 5) cand_row<CPL, 5>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            case 6: if constexpr (S >= 6) cand_row<CPL, 6>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            case 7: if constexpr (S >= 7) cand_row<CPL, 7>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
+            default: if constexpr (S >= 8) cand_row<CPL, 8>(v, left, z, skip_pen, stay_pen, fs, l0, cv, tk, exit0); break;
             }
         }
         // stay chain: monotone fixed-point sweeps, chunk exit values shifted one lane up.
@@ -572,27 +582,40 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
         // and the cells themselves are written once, in the pass that also derives the move flags.
         // The sequence of incoming values is the same as with full sweeps, so is the sweep count.
         DP_PH(1);
+#ifndef TBA_DP_SHR_FILL
+        // Band cell 0 has no stay move (pyx:392-401): nothing may come into lane 0.  Instead of
+        // handing lane 0 an incoming -inf with every lane shift (two v_mov per sweep to prepare the
+        // DPP destination), lane 0's z[0] is -inf for the chain from here on (the candidates above were
+        // the last readers of its true value): whatever comes in -- the shift's zero fill -- dies
+        // there, (x - stay_pen) + -inf = -inf, exactly the value the reference's missing move has.
+        z[0] = lane == 0 ? NEG_INF : z[0];
+        double in = lane == 0 ? 0.0 : NEG_INF;
+#define DP_SHR(x_) wave_shr1_f64_zero(x_)
+#else
         double in = NEG_INF;
+#define DP_SHR(x_) wave_shr1_f64(x_, NEG_INF)
+#endif
         bool converged = false;
-        double exit0;
+#ifdef TBA_DP_SWEEP1_APART
         {
             double x = NEG_INF;
 #pragma unroll
             for (int j = 0; j < CPL; j++) x = max_f64_raw(cv[j], (x - stay_pen) + z[j]);
             exit0 = x;
         }
+#endif
 #ifdef TBA_SWEEP_STATS
         i64 sw_row = 1;
 #endif
         {
-            double nin = wave_shr1_f64(exit0, NEG_INF);
+            double nin = DP_SHR(exit0);
             for (int it = 0; it < 66; it++) { // <= 64 sweeps by induction over lanes (NaN-proof bound)
                 if (__ballot(nin != in) == 0) { converged = true; break; }
                 in = nin;
                 double c = in;
 #pragma unroll
                 for (int j = 0; j < CPL; j++) c = (c - stay_pen) + z[j];
-                nin = wave_shr1_f64(max_f64_raw(exit0, c), NEG_INF);
+                nin = DP_SHR(max_f64_raw(exit0, c));
 #ifdef TBA_SWEEP_STATS
                 sw_row++;
 #endif
@@ -601,6 +624,7 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
 #ifdef TBA_SWEEP_STATS
         sw_total += sw_row;
 #endif
+#undef DP_SHR
         if (!converged) { // only reachable with NaNs in the signal
             if (lane == 0) { if (DIRECT) job->status = TBA_INTERNAL; else r.status = TBA_INTERNAL; }
             return true;

@@ -146,6 +146,15 @@ __device__ __forceinline__ double wave_shr1_f64(double x, double lane0_val)
     hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0_val), hi, 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// lane i <- lane i-1, lane 0 <- +0.0: bound_ctrl fills the lane without a source with zero bits, so
+// the DPP move needs no prepared destination (the form above costs two v_mov of the fill value per
+// call -- its `old` operand is tied to the destination register)
+__device__ __forceinline__ double wave_shr1_f64_zero(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_shl1_f64(double x, double lane63_val) // lane i <- lane i+1
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
