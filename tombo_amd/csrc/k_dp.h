@@ -197,10 +197,10 @@ __device__ __forceinline__ void shifted_row(const double (&Q)[CPL], double left,
 // diag / skip candidates of one row for band offset D (pyx:220-231, first cell pyx:392-401):
 // A[j] is cell j's diagonal source and cell j-1's skip source.  Instantiated per offset so the
 // previous row is read straight out of its registers (no renaming moves).  tk bit j: skip taken.
-// Also runs the FIRST sweep of the stay chain (every lane from -inf: exit0 = the lane's exit value
-// with nothing coming in): in the same basic block the chain's dependent adds are scheduled between
-// the independent candidate arithmetic of the cells to their right, instead of as a bare chain of
-// 3 CPL dependent instructions behind the offset switch (-DTBA_DP_SWEEP1_APART: the old order).
+// -DTBA_DP_SWEEP1_FUSED (A/B switch, off): the FIRST sweep of the stay chain inside this block, so that
+// its dependent adds are scheduled between the independent candidate arithmetic.  Measured round 5:
+// main_dp 59.97 against 59.63 ms -- with four wavefronts per SIMD the f64 pipe is busy whatever the
+// order inside one of them (tools/valu_rates.hip), and nine copies of the sweep cost instruction cache.
 template <int CPL, int D>
 __device__ __forceinline__ void cand_row(const double (&Q)[CPL], double left,
     const double (&z)[CPL], double skip_pen, double stay_pen, bool first_is_skip, bool lane0, double (&cv)[CPL],
@@ -223,7 +223,7 @@ __device__ __forceinline__ void cand_row(const double (&Q)[CPL], double left,
             cv[j] = max_f64_raw(s, d);
         }
         tk[j] = take_s;
-#ifndef TBA_DP_SWEEP1_APART
+#ifdef TBA_DP_SWEEP1_FUSED
         x = max_f64_raw(cv[j], (x - stay_pen) + z[j]);
 #endif
     }
@@ -596,7 +596,7 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
 #define DP_SHR(x_) wave_shr1_f64(x_, NEG_INF)
 #endif
         bool converged = false;
-#ifdef TBA_DP_SWEEP1_APART
+#ifndef TBA_DP_SWEEP1_FUSED
         {
             double x = NEG_INF;
 #pragma unroll

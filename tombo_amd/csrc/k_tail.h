@@ -629,7 +629,15 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
     auto base_mean = [&](i64 k) { // c_new_means: sequential sum, one divide
         const i64 a = sg[k], b = sg[k + 1];
         double acc = 0;
-        for (i64 j = a; j < b; j++) acc += x[j];
+        // the adds are sequential (the reference's order), the loads are not: eight in flight (a
+        // `load -> add` loop pays a memory round trip per sample of the base: 13 % of this kernel)
+        for (i64 j = a; j < b; j += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = x[j + u < b ? j + u : b - 1];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (j + u < b) acc += t[u];
+        }
         return acc / (double)(b - a);
     };
     i64 n = r.B;
@@ -734,10 +742,13 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
             for (int i = tid; i < nn; i += SEL_NT) {
                 int j = i + d; j = j >= nn ? j - nn : j;
                 // the sample only steers the window: the approximate quotient is good enough
-                const double ei = s_ev[i], ej = s_ev[j], b = ei - ej;
+                // (all four LDS reads go out together: behind a test of ei == ej the levels were a
+                // second, dependent round trip)
+                const double ei = s_ev[i], ej = s_ev[j], mi = s_md[i], mj = s_md[j], b = ei - ej;
                 double rr = __builtin_amdgcn_rcp(b);
                 rr = __builtin_fma(__builtin_fma(-b, rr, 1.0), rr, rr);
-                const double sl = (ei == ej) ? 1000.0 : (s_md[i] - s_md[j]) * rr;
+                const double q = (mi - mj) * rr;
+                const double sl = (b == 0.0) ? 1000.0 : q;
                 atomicAdd(&sm.hist[bs_bucket(sl, glo, gsc)], 1u);
             }
         }
@@ -793,21 +804,31 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
                 if (pos < cap) { double *pr = pair_at(pos); pr[0] = a; pr[1] = b; }
             };
             if (!(nn & 1)) {
-                // Even n (the 1000-point sample): the pass is bound by LDS bandwidth (two 8-byte
-                // reads per pair), so a thread keeps TWO points and walks the distances four at
-                // a time: the 8 pairs need 5 partner points instead of 8.  The circle is walked
-                // in the order slot 0, nh, 1, nh + 1, ... (any order of the point set gives every
-                // unordered pair once): thread t holds positions 2t and 2t + 1 = slots t and
-                // nh + t, the partner at position 2t + c sits in slot (c & 1) nh + (t + c / 2)
+                // Even n (the 1000-point sample): a thread keeps TWO points and walks the distances four
+                // at a time: the 8 pairs need 5 partner points instead of 8 (the pass was bound by LDS
+                // bandwidth).  The circle is walked in the order slot 0, nh, 1, nh + 1, ... (any order of
+                // the point set gives every unordered pair once): thread t holds positions 2t and 2t + 1 =
+                // slots t and nh + t, the partner at position 2t + c sits in slot (c & 1) nh + (t + c / 2)
                 // mod nh -- consecutive threads, consecutive slots.
+                // Round 5: no branch per pair.  A pair is two subtractions, the sign fold as a bit
+                // operation, two products and three compares whose lane masks are combined and counted on
+                // the scalar unit (the count below the window lives in an SGPR per wavefront); the pairs
+                // that go to the list -- 1-2 % -- are appended once per step of eight pairs, behind ONE
+                // wave-uniform branch and one LDS counter bump.  (Before: four nested exec-mask regions
+                // per pair, a per-lane 64-bit counter, a counter bump per pair instruction that had a
+                // listed lane -- ~20 instructions per pair against ~9; profiles/r05_theil_sen_phases.txt.)
                 const int nh = nn / 2;
                 const bool okr = tid < nh;
                 const int tc = okr ? tid : 0;
+                const int lane = tid & 63;
                 const double eA = s_ev[tc], mA = s_md[tc], eB = s_ev[nh + tc], mB = s_md[nh + tc];
                 // the antipodal distance nh only from the first half of the circle
                 const int dlimA = okr ? (2 * tc < nh ? nh : nh - 1) : 0;
                 const int dlimB = okr ? (2 * tc + 1 < nh ? nh : nh - 1) : 0;
-                for (int d0 = 1; d0 <= nh; d0 += 4) {
+                const u64 okm = __ballot(okr);
+                i64 wave_lo = 0;
+                auto step = [&](const int d0, auto tail_tag) __attribute__((always_inline)) {
+                    constexpr bool TAIL = decltype(tail_tag)::value;
                     double ep[5], mp[5];
 #pragma unroll
                     for (int u = 0; u < 5; u++) {
@@ -817,12 +838,51 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
                         const int slot = (c & 1) ? nh + h : h;
                         ep[u] = s_ev[slot]; mp[u] = s_md[slot];
                     }
+                    u64 cm[8];
+                    u32 n_list = 0;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (d0 + u <= dlimA) classify(mA - mp[u], eA - ep[u]);
-                        if (d0 + u <= dlimB) classify(mB - mp[u + 1], eB - ep[u + 1]);
+                    for (int q = 0; q < 8; q++) {
+                        const int u = q >> 1;
+                        const double a = (q & 1) ? mB - mp[u + 1] : mA - mp[u];
+                        const double b = (q & 1) ? eB - ep[u + 1] : eA - ep[u];
+                        // a / b against the guarded edges without dividing: the sign of b is folded
+                        // into a, then a' < A1 |b|  =>  a / b < A1 (1 + 2^-53) < t1.  b == 0: the
+                        // reference's slope is max_slope = 1000, above the window (both products are 0
+                        // then and one of the two compares holds: never listed, never counted).
+                        const double ab = fabs(b);
+                        const double as = __hiloint2double(__double2hiint(a) ^ (__double2hiint(b) & (int)0x80000000), __double2loint(a));
+                        u64 lo = __ballot(as < A1 * ab), hi = __ballot(as >= B2 * ab);
+                        const u64 zero = __ballot(ab == 0.0);
+                        u64 ok = okm;
+                        if (TAIL) ok = __ballot(d0 + u <= ((q & 1) ? dlimB : dlimA));
+                        wave_lo += __popcll(lo & ~zero & ok);          // safely below the window
+                        cm[q] = ok & ~(lo | hi);                       // inside, too close to an edge, NaN
+                        n_list += (u32)__popcll(cm[q]);
                     }
-                }
+                    if (n_list) {                                      // (wave-uniform)
+                        u32 base = 0;
+                        if (lane == 0) base = atomicAdd(&s_ncand, n_list);
+                        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            if (cm[q] == 0) continue;
+                            const int u = q >> 1;
+                            if ((cm[q] >> lane) & 1ull) {
+                                const u32 pos = base + (u32)__popcll(cm[q] & ((1ull << lane) - 1ull));
+                                if (pos < cap) {
+                                    double *pr = pair_at(pos);
+                                    pr[0] = (q & 1) ? mB - mp[u + 1] : mA - mp[u];
+                                    pr[1] = (q & 1) ? eB - ep[u + 1] : eA - ep[u];
+                                }
+                            }
+                            base += (u32)__popcll(cm[q]);
+                        }
+                    }
+                };
+                int d0 = 1;
+                for (; d0 + 3 <= nh - 1; d0 += 4) step(d0, BoolTag<false>{});   // every distance valid for every thread
+                for (; d0 <= nh; d0 += 4) step(d0, BoolTag<true>{});
+                c_lo = lane == 0 ? wave_lo : 0;
             } else
             for (int i0 = 0; i0 < nn; i0 += SEL_NT) {
                 const int i = i0 + tid;
