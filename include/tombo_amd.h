@@ -106,6 +106,9 @@ typedef struct {
                               a keyed pseudo-random permutation of [0, B) (counter based: a
                               function of subsample_seed and the read's index in the batch) */
     uint64_t subsample_seed;
+    int64_t subsample_first_read; /* index, in the caller's job, of the batch's first read: read i of the batch
+                              draws under the key of (subsample_seed, subsample_first_read + i), so the subsample
+                              of a read does not depend on how its list was cut into batches */
     /* keyword arguments of resolve_skipped_bases_with_raw (resquiggle.py:405-407): bases a window
      * around a skipped base starts with / may grow to, and the signal a window must hold relative to
      * its bases.  All three zero (a zero-initialised struct): the reference's defaults 2 / 10 / 1.1
@@ -516,7 +519,7 @@ int tba_synth_dwell_thresholds(const tba_synth_params *p, uint32_t *thr, int64_t
 /* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build, out[3]
  * (n >= 4) = TBA_ABI_VERSION: lets a binding without a C compiler (ctypes) check its struct mirrors
  * and refuse a stale build of the library */
-#define TBA_ABI_VERSION 7
+#define TBA_ABI_VERSION 8
 int tba_abi_sizes(int64_t *out, int64_t n);
 
 /* self-test: out[t] = index t of the subsample tba_opts.device_subsample draws for read

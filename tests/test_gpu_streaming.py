@@ -172,6 +172,81 @@ def test_streamed_resquiggle_batch_gives_the_one_batch_result(monkeypatch):
         assert x.sig_match_score == y.sig_match_score and x.scale_values == y.scale_values
         assert x.genome_seq == y.genome_seq and x.read_start_rel_to_raw == y.read_start_rel_to_raw
         assert z.raw_signal is None and z.segs.shape == x.segs.shape
+    # the device-side draw of a read is keyed by its index in the LIST: cut into sub-batches or not (and
+    # however), a seeded call gives the same subsamples, hence the same results bit for bit
+    monkeypatch.setenv('TBA_API_STREAM', '0')
+    one_dev = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=3)
+    monkeypatch.setenv('TBA_API_STREAM', '1')
+    for cuts in ('3', '5'):
+        monkeypatch.setenv('TBA_API_CUTS', cuts)
+        cut_dev = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=3)
+        for x, y in zip(one_dev, cut_dev):
+            assert isinstance(x, Exception) == isinstance(y, Exception)
+            if not isinstance(x, Exception):
+                np.testing.assert_array_equal(x.segs, y.segs)
+                np.testing.assert_array_equal(x.raw_signal, y.raw_signal)
+                assert x.scale_values == y.scale_values and x.sig_match_score == y.sig_match_score
+
+
+def test_results_are_views_of_pooled_page_locked_blocks(monkeypatch):
+    """resquiggle_batch hands out views into page-locked blocks of the process-wide result pool (no
+    second copy): the blocks stay leased while any result looks into them -- a later call does not
+    overwrite them -- return to the pool when the results go, and are reused by the next call; a stream
+    that dies half way leaves the engines idle and the default engine's sharing hint reset"""
+    import gc
+    from tombo_amd import resquiggle as rq, _native
+    samp, model, params, reads = _setup(n_reads=72, seed0=4100)
+    mrs = _map_results(reads)
+    pool = _native.result_pool()
+    gc.collect()
+    leased0 = pool.leased_bytes
+    monkeypatch.setenv('TBA_API_STREAM_MIN', '24')
+    monkeypatch.setenv('TBA_API_ZERO_COPY_MIN', '1')    # (default: sub-batches of 32 reads and more)
+    a = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=9)
+    ok = [r for r in a if not isinstance(r, Exception)]
+    assert len(ok) >= 60
+    assert all(r.raw_signal.base is not None and r.segs.base is not None for r in ok)   # views, not copies
+    assert pool.leased_bytes > leased0
+    snap = [(r.segs.copy(), r.raw_signal.copy()) for r in ok]
+    b = rq.resquiggle_batch(mrs[::-1], model, params, outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=10)
+    for r, (sg, sig) in zip(ok, snap):       # the first call's results are untouched by the second
+        np.testing.assert_array_equal(r.segs, sg)
+        np.testing.assert_array_equal(r.raw_signal, sig)
+    keep = ok[3].raw_signal                  # one view keeps its block leased
+    del a, b, ok, r
+    gc.collect()
+    assert pool.leased_bytes > leased0
+    idle_before = pool.idle_bytes
+    assert idle_before > 0
+    del keep
+    gc.collect()
+    assert pool.leased_bytes == leased0
+    c = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=9)
+    assert pool.idle_bytes < idle_before + (1 << 20)    # served from the idle blocks, nothing new allocated
+    for r, (sg, sig) in zip([x for x in c if not isinstance(x, Exception)], snap):
+        np.testing.assert_array_equal(r.segs, sg)
+        np.testing.assert_array_equal(r.raw_signal, sig)
+    # a stream that raises half way
+    calls = {'n': 0}
+    real = rq._submit_batch
+
+    def boom(*a_, **k_):
+        calls['n'] += 1
+        if calls['n'] == 2:
+            raise _native.EngineError('injected')
+        return real(*a_, **k_)
+    monkeypatch.setattr(rq, '_submit_batch', boom)
+    with pytest.raises(_native.EngineError, match='injected'):
+        rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=9)
+    monkeypatch.setattr(rq, '_submit_batch', real)
+    assert not rq.get_engine(0).query()                      # nothing in flight
+    d = rq.resquiggle_batch(mrs, model, params, outlier_thresh=5.0, seq_samp_type=samp, subsample_seed=9)
+    for x, y in zip(c, d):
+        assert isinstance(x, Exception) == isinstance(y, Exception)
+        if not isinstance(x, Exception):
+            np.testing.assert_array_equal(x.segs, y.segs)
+    rq.release_stream_engines()
+    assert rq._STREAM_ENGINES == {}
 
 
 def test_put_rejects_indices_outside_the_signal():

@@ -55,7 +55,7 @@ class Opts(C.Structure):
                 ('stall_window_size', i64), ('stall_n_windows', i64),
                 ('stall_mini_window_size', i64), ('stall_min_consecutive_obs', i64),
                 ('stall_edge_buffer', i64), ('stall_threshold', f64),
-                ('device_subsample', i64), ('subsample_seed', C.c_uint64),
+                ('device_subsample', i64), ('subsample_seed', C.c_uint64), ('subsample_first_read', i64),
                 ('del_fix_window', i64), ('max_del_fix_window', i64), ('extra_sig_factor', f64)]
 
 
@@ -95,7 +95,7 @@ STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, S
 PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
     PUT_START_STATE = range(1, 8)
 MAX_BAND = 3072
-ABI_VERSION = 7  # TBA_ABI_VERSION of include/tombo_amd.h
+ABI_VERSION = 8  # TBA_ABI_VERSION of include/tombo_amd.h
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
                "rescale_score", "stalls", "total"]
@@ -149,7 +149,7 @@ def make_params(rp):
 def make_opts(outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
               sig_match_thresh=None, max_raw_cpts=200, min_event_to_seq_ratio=1.1,
               skip_norm_out=False, reverse_raw=False, stall_params=None, subsample_seed=None,
-              del_fix_window=2, max_del_fix_window=10, extra_sig_factor=1.1):
+              del_fix_window=2, max_del_fix_window=10, extra_sig_factor=1.1, subsample_first_read=0):
     """tba_opts.  `reverse_raw` / `stall_params` (a th.stallParams of the running-window-mean
     method): the worker's RNA preparation on the device (resquiggle.py:1506-1530);
     `subsample_seed` (int): the Theil-Sen subsample is drawn on the device;
@@ -172,6 +172,7 @@ def make_opts(outlier_thresh=None, const_scale=None, skip_seq_scaling=False,
         o.stall_threshold = float(sp.threshold)
     if subsample_seed is not None:
         o.device_subsample, o.subsample_seed = 1, int(subsample_seed) & 0xffffffffffffffff
+        o.subsample_first_read = int(subsample_first_read)   # (the draw of a read is keyed by its index in the JOB)
     o.has_outlier_thresh = int(outlier_thresh is not None)
     o.outlier_thresh = 0.0 if outlier_thresh is None else float(outlier_thresh)
     o.has_const_scale = int(const_scale is not None)
@@ -218,6 +219,88 @@ class PinnedArray(object):
 
 class EngineError(RuntimeError):
     pass
+
+
+class PinnedPool(object):
+    """Process-wide pool of page-locked blocks that RESULTS live in.  `lease(count, dtype)` returns
+    a fresh ndarray over a block (or None when the pool's budget is spent); every per-read result array
+    is a view of it, and the block goes back to the pool when the last view is gone (the views keep the
+    lease array alive; a finalizer on it returns the block).  Blocks are reused, never freed while the
+    pool is under its idle cap: hipHostMalloc is slow and hipHostFree waits for all work on the device.
+
+    Budget (bytes leased to live results + idle): $TBA_PINNED_POOL_BYTES, default a quarter of the
+    host's memory.  Beyond it `lease` returns None and the caller copies into pageable memory, as
+    every result did before round 5."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.RLock()   # (a finalizer may run -- and give a block back -- inside lease)
+        self._idle = []          # PinnedArray blocks (uint8), by size
+        self.leased_bytes = 0
+        self.idle_bytes = 0
+        env = os.environ.get('TBA_PINNED_POOL_BYTES')
+        if env:
+            self.budget = int(env)
+        else:
+            try:
+                self.budget = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') // 4
+            except (ValueError, OSError):
+                self.budget = 8 << 30
+
+    def lease(self, count, dtype):
+        import weakref
+        dtype = np.dtype(dtype)
+        need = max(int(count) * dtype.itemsize, 1)
+        with self._lock:
+            best = None
+            for k, pa in enumerate(self._idle):     # smallest idle block that holds it without wasting half
+                if need <= pa.nbytes <= 2 * need + (1 << 20) and (best is None or pa.nbytes < self._idle[best].nbytes):
+                    best = k
+            pa = self._idle.pop(best) if best is not None else None
+            if pa is not None:
+                self.idle_bytes -= pa.nbytes
+            elif self.leased_bytes + self.idle_bytes + need > self.budget:
+                # make room out of idle blocks of the wrong size before giving up
+                while self._idle and self.leased_bytes + self.idle_bytes + need > self.budget:
+                    old = self._idle.pop()
+                    self.idle_bytes -= old.nbytes
+                    old.close()
+                if self.leased_bytes + self.idle_bytes + need > self.budget:
+                    return None
+        if pa is None:
+            try:
+                pa = PinnedArray(need + need // 16 + 4096, np.uint8)
+            except EngineError:
+                return None
+        with self._lock:
+            self.leased_bytes += pa.nbytes
+        buf = (C.c_char * pa.nbytes).from_address(pa._ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(count))
+        weakref.finalize(arr, self._give, pa)
+        return arr
+
+    def _give(self, pa):
+        with self._lock:
+            self.leased_bytes -= pa.nbytes
+            self._idle.append(pa)
+            self.idle_bytes += pa.nbytes
+
+    def trim(self):
+        """free the idle blocks (waits for the device: hipHostFree)"""
+        with self._lock:
+            idle, self._idle, self.idle_bytes = self._idle, [], 0
+        for pa in idle:
+            pa.close()
+
+
+_result_pool = None
+
+
+def result_pool():
+    global _result_pool
+    if _result_pool is None:
+        _result_pool = PinnedPool()
+    return _result_pool
 
 
 class Engine(object):

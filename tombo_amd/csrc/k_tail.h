@@ -648,7 +648,7 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
         bool bad = false;
         // tba_opts.device_subsample: the indices are drawn here (k_prep_raw.h) and left in samp_ind
         const bool draw = dp->o.device_subsample != 0;
-        const u64 key = subsample_key(dp->o.subsample_seed, blockIdx.x);
+        const u64 key = subsample_key(dp->o.subsample_seed, dp->o.subsample_first_read + (i64)blockIdx.x);
         for (i64 i = tid; i < n; i += SEL_NT) {
             i64 k;
             if (draw) { k = keyed_perm(i, r.B, key); si[i] = k; }
@@ -788,8 +788,11 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
         __syncthreads();
         TBA_PHASE(3, 1);
         if (s_win_ok) {
-            const double t1 = s_win[0], t2 = s_win[1]; // 0.5 < t1 < t2 < 1.5
-            const double A1 = t1 - t1 * TSW_REL, B2 = t2 + t2 * TSW_REL;
+            double A1, B2;
+            {
+                const double t1 = s_win[0], t2 = s_win[1]; // 0.5 < t1 < t2 < 1.5
+                A1 = t1 - t1 * TSW_REL; B2 = t2 + t2 * TSW_REL;
+            }
             i64 c_lo = 0;
             const int dtop = dmax + ((nn & 1) ? 0 : 1);
             auto classify = [&](double a, double b) {
@@ -870,9 +873,16 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
                             if ((cm[q] >> lane) & 1ull) {
                                 const u32 pos = base + (u32)__popcll(cm[q] & ((1ull << lane) - 1ull));
                                 if (pos < cap) {
+                                    // (the partner is read from LDS again: keeping the step's eight
+                                    // differences alive for this rare lane cost the kernel its 80-register
+                                    // step -- tests/test_kernel_resources.py)
+                                    const int c = d0 + u + (q & 1);
+                                    int h = tc + (c >> 1);
+                                    h = h >= nh ? h - nh : h;
+                                    const int slot = (c & 1) ? nh + h : h;
                                     double *pr = pair_at(pos);
-                                    pr[0] = (q & 1) ? mB - mp[u + 1] : mA - mp[u];
-                                    pr[1] = (q & 1) ? eB - ep[u + 1] : eA - ep[u];
+                                    pr[0] = ((q & 1) ? mB : mA) - s_md[slot];
+                                    pr[1] = ((q & 1) ? eB : eA) - s_ev[slot];
                                 }
                             }
                             base += (u32)__popcll(cm[q]);
@@ -912,6 +922,9 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
             if (n_c <= cap) {
                 // exact slopes of the listed pairs; in-window ones stay (in place of their a),
                 // the rest becomes +inf and the ones below t1 are counted
+                // (the window edges come out of LDS again: kept in registers across the pass over the
+                // pairs they were the four registers the kernel spilled)
+                const double t1 = s_win[0], t2 = s_win[1];
                 i64 lo_more = 0, inw = 0;
                 for (i64 k = tid; k < n_c; k += SEL_NT) {
                     double *pr = pair_at(k);

@@ -113,7 +113,8 @@ def resquiggle_batch(map_results, std_ref, rsqgl_params, outlier_thresh=None,
             # (what is free now plus what this engine already holds; no floor: on a device that
             # other engines share a floor would stop the planner from cutting, and the upload
             # would fail with TBA_E_NOMEM instead)
-            mem_budget = 0.6 * (eng.device_mem()[0] + eng.held_bytes())
+            held = eng.held_bytes() + sum(e.held_bytes() for e in _STREAM_ENGINES.get(eng.device, []))
+            mem_budget = 0.6 * (eng.device_mem()[0] + held)
         p_ = _native.make_params(rsqgl_params)
         o_ = _native.make_opts(min_event_to_seq_ratio=min_event_to_seq_ratio, reverse_raw=reverse_raw,
                                stall_params=stall_params, subsample_seed=subsample_seed,
@@ -166,6 +167,16 @@ _STREAM_SLOTS = 3
 _STREAM_ENGINES = {}
 
 
+def release_stream_engines(device=None):
+    """Destroy the extra engines a streamed `resquiggle_batch` keeps per device (their grow-only device
+    buffers and page-locked staging) and hand the idle result blocks back to the system.  They are
+    created again on the next call that streams."""
+    for dev in ([device] if device is not None else list(_STREAM_ENGINES)):
+        for e in _STREAM_ENGINES.pop(dev, []):
+            e.close()
+    _native.result_pool().trim()
+
+
 def _stream_engines(eng, std_ref):
     """the engines a streamed `resquiggle_batch` rotates over: the process-wide one of the device
     and two more, created on first use (each has its own stream, device buffers and staging)"""
@@ -202,7 +213,8 @@ def _stream_batches(engines, cuts, map_results, raws, pre_err, samp_inds, subsam
     chain = bool(args['return_signal'])
     if os.environ.get('TBA_API_CHAIN'):            # (measurement aid)
         chain = os.environ['TBA_API_CHAIN'] == '1'
-    with ThreadPoolExecutor(1) as ex:
+    ex = ThreadPoolExecutor(1)
+    try:
         def unpack(ctx):
             _unpack_batch(ctx)
             mark('unpacked', ctx['k'])
@@ -231,9 +243,10 @@ def _stream_batches(engines, cuts, map_results, raws, pre_err, samp_inds, subsam
             while old is not None and not ('unpack' in old and old['unpack'].done()):
                 if not pump():           # its page-locked outputs must be free again
                     time.sleep(0.0002)
-            seed = None if subsample_seed is None else subsample_seed + 7919 * k
             mark('submit', k)
-            ctx = _submit_batch(engines[e], a, b, map_results, raws, pre_err, samp_inds, seed, args,
+            # (the device-side draw of a read is keyed by its index in the whole list -- _submit_batch hands
+            # `a` to the engine -- so the result does not depend on how the list was cut)
+            ctx = _submit_batch(engines[e], a, b, map_results, raws, pre_err, samp_inds, subsample_seed, args,
                                 after=engines[(k - 1) % S] if chain and k > 0 else None)
             ctx['k'] = k
             mark('submitted', k)
@@ -243,11 +256,22 @@ def _stream_batches(engines, cuts, map_results, raws, pre_err, samp_inds, subsam
         while pending:
             if not pump():
                 time.sleep(0.0002)
+    finally:
+        # whatever happened (TBA_E_NOMEM on one slot, an interrupt): nothing of this call may still be in
+        # flight on staging the next call reuses, and the process-wide engine goes back to its defaults
+        for e in engines:
+            try:
+                e.sync()
+            except Exception:
+                pass
+            try:
+                e.set_sharing(1)
+            except Exception:
+                pass
+        ex.shutdown(wait=True)
     if trace is not None:
         import sys
         print('resquiggle_batch stream trace:', trace, file=sys.stderr)
-    for e in engines:
-        e.set_sharing(1)
     return out
 
 
@@ -297,7 +321,7 @@ def _submit_batch(eng, a, b, map_results, raws, pre_err, samp_inds, subsample_se
         sig_match_thresh=None if seq_samp_type is None else SIG_MATCH_THRESH[seq_samp_type.name],
         max_raw_cpts=args['max_raw_cpts'], min_event_to_seq_ratio=args['min_event_to_seq_ratio'],
         reverse_raw=args['reverse_raw'], stall_params=args['stall_params'], subsample_seed=subsample_seed,
-        skip_norm_out=not return_signal and not return_debug)
+        subsample_first_read=a, skip_norm_out=not return_signal and not return_debug)
     eng.upload_packed(p, o, raw, raw_off, seq, seq_off, sv_in=sv_in, sv_flags=sv_flags,
                       samp_ind=si, stall_ints=st, stall_off=sto)
     if after is not None:
@@ -307,8 +331,22 @@ def _submit_batch(eng, a, b, map_results, raws, pre_err, samp_inds, subsample_se
                map_results=mrs, pre_err=pre_err[a:b], rng_state=rng_state, args=args)
     if not return_debug:
         ctx['o_res'] = stage.get('res', n, _native.RESULT_DTYPE)
-        ctx['o_segs'] = stage.get('segs', int(eng.seg_off[-1]), np.int64)
-        ctx['o_norm'] = stage.get('norm', eng.n_raw_total, np.float64) if return_signal else None
+        # The boundaries and the normalised signal are downloaded into page-locked blocks leased from the
+        # process-wide result pool, and the per-read arrays of the results are VIEWS of those blocks (no
+        # second copy of 0.8 MB per 10 kb read; a block returns to the pool when the last result that
+        # looks into it is gone).  Without a lease (pool budget spent, TBA_API_ZERO_COPY=0): the engine's
+        # reusable staging + a native copy into pageable memory, as before.
+        # (small batches copy: a page-locked block per handful of reads is not worth holding)
+        pool = _native.result_pool() if n >= int(os.environ.get('TBA_API_ZERO_COPY_MIN', '32')) and \
+            os.environ.get('TBA_API_ZERO_COPY', '1') != '0' else None
+        n_segs, n_norm = int(eng.seg_off[-1]), int(eng.n_raw_total)
+        l_segs = pool.lease(n_segs, np.int64) if pool is not None else None
+        l_norm = pool.lease(n_norm, np.float64) if pool is not None and return_signal and l_segs is not None else None
+        ctx['views'] = l_segs is not None and (l_norm is not None or not return_signal)
+        if not ctx['views']:
+            l_segs = l_norm = None
+        ctx['o_segs'] = l_segs if ctx['views'] else stage.get('segs', n_segs, np.int64)
+        ctx['o_norm'] = (l_norm if ctx['views'] else stage.get('norm', n_norm, np.float64)) if return_signal else None
         eng.download_async(results=ctx['o_res'], segs64=ctx['o_segs'], norm=ctx['o_norm'])
     return ctx
 
@@ -340,7 +378,18 @@ def _sync_batch(ctx):
 def _unpack_batch(ctx):
     """the per-read boundary / signal arrays out of the flat downloads (native threads)"""
     out, ok, nb, args = ctx['out'], ctx['ok'], ctx['nb'], ctx['args']
-    if not args['return_debug']:
+    if not args['return_debug'] and ctx.get('views'):
+        so, ro = ctx['seg_off'].tolist(), ctx['raw_off'].tolist()
+        o_segs, o_norm = ctx['o_segs'], ctx['o_norm']
+        okl = ok.tolist()
+        ctx['segs_l'] = [o_segs[so[i]:so[i + 1]] for i in okl]
+        if args['return_signal']:
+            nl = out['norm_len'].tolist()
+            ctx['norm_l'] = [o_norm[ro[i]:ro[i] + nl[i]] for i in okl]
+        else:
+            ctx['norm_l'] = [None] * len(okl)
+        ctx['o_segs'] = ctx['o_norm'] = None     # (only the results hold the blocks now)
+    elif not args['return_debug']:
         ctx['segs_l'] = _native.unpack_reads(ctx['o_segs'], ctx['seg_off'][:-1][ok], nb[ok] + 1)
         ctx['norm_l'] = _native.unpack_reads(ctx['o_norm'], ctx['raw_off'][:-1][ok], out['norm_len'][ok]) \
             if args['return_signal'] else [None] * len(ok)
@@ -390,27 +439,41 @@ def _build_results(ctx):
 def _fill_results(results, ok, map_results, svs, rstart, score, changed, segs_l, norm_l, dev_stalls,
                   skip_seq_scaling, outlier_thresh, rsqgl_params, const_scale, cp, dn):
     """the resquiggleResults of the successful reads of one batch (resquiggle.py:1210-1214)"""
-    for k, i in enumerate(ok):
+    # Built field by field through tuple.__new__ (namedtuple._replace walks a keyword dict per call: 3 us
+    # per read, the largest item of a 5 000-read call's host time), scalars converted once per batch.
+    RR, SV, new = th.resquiggleResults, th.scaleValues, tuple.__new__
+    I_SEQ, I_RAW, I_START, I_SEGS, I_SV, I_SCORE, I_CH, I_STALL = (
+        RR._fields.index(f) for f in ('genome_seq', 'raw_signal', 'read_start_rel_to_raw', 'segs',
+                                      'scale_values', 'sig_match_score', 'norm_params_changed', 'stall_ints'))
+    okl = ok.tolist() if hasattr(ok, 'tolist') else list(ok)
+    sv_rows = np.asarray(svs)[okl].tolist() if len(okl) else []
+    rs_l, sc_l, ch_l = (np.asarray(x)[okl].tolist() if len(okl) else [] for x in (rstart, score, changed))
+    t_test = bool(rsqgl_params.use_t_test_seg)
+    for k, i in enumerate(okl):
         mr = map_results[i]
-        sv = svs[i]
-        lo = None if np.isnan(sv[2]) else float(sv[2])
-        hi = None if np.isnan(sv[3]) else float(sv[3])
+        sh, scl, lo, hi = sv_rows[k]
+        lo = None if lo != lo else lo          # NaN: no limit
+        hi = None if hi != hi else hi
         # scaleValues.outlier_thresh: the reference stores the argument after sequence
         # rescaling (resquiggle.py:1187-1188) and normalize_raw_signal's value otherwise
         if skip_seq_scaling:
             ot = None if mr.scale_values is not None else outlier_thresh
-            if rsqgl_params.use_t_test_seg and mr.scale_values is None and const_scale is None:
+            if t_test and mr.scale_values is None and const_scale is None:
                 ot = None
         else:
             ot = outlier_thresh
-        res = mr._replace(
-            read_start_rel_to_raw=int(rstart[i]), segs=segs_l[k],
-            genome_seq=mr.genome_seq[cp:len(mr.genome_seq) - dn], raw_signal=norm_l[k],
-            scale_values=th.scaleValues(float(sv[0]), float(sv[1]), lo, hi, ot),
-            sig_match_score=float(score[i]), norm_params_changed=bool(changed[i]))
+        f = list(mr)
+        gs = f[I_SEQ]
+        f[I_SEQ] = gs[cp:len(gs) - dn]
+        f[I_RAW] = norm_l[k]
+        f[I_START] = int(rs_l[k])
+        f[I_SEGS] = segs_l[k]
+        f[I_SV] = new(SV, (sh, scl, lo, hi, ot))
+        f[I_SCORE] = sc_l[k]
+        f[I_CH] = bool(ch_l[k])
         if dev_stalls is not None:
-            res = res._replace(stall_ints=[list(map(int, x)) for x in dev_stalls[i]])
-        results[i] = res
+            f[I_STALL] = [list(map(int, x)) for x in dev_stalls[i]]
+        results[i] = new(RR, f)
 
 
 def resquiggle_read(map_res, std_ref, rsqgl_params, outlier_thresh=None, all_raw_signal=None,
