@@ -432,7 +432,10 @@ class Engine(object):
         self._check(self._L.tba_batch_enqueue(self._h), 'tba_batch_enqueue')
 
     def sync(self):
+        # (the targets of the finished downloads belong to the caller alone from here on: a block of
+        # the result pool must not stay leased because this engine still points at it)
         self._check(self._L.tba_batch_sync(self._h), 'tba_batch_sync')
+        self._keep_out = None
 
     def wait_for(self, other):
         """kernels enqueued next on this engine start after `other`'s last enqueued sequence"""
