@@ -150,6 +150,32 @@ __host__ __device__ inline i64 mv_row_bytes(i64 W)
     return c ? (i64)mv_class_rowb(c) : ((W + 255) / 256) * 64;
 }
 
+// The centre strip.  An adaptive row's band is placed around the best cell of the row before
+// (pyx:342-358), and the traceback never strays far from band cell W / 2 (synthetic reads: sd 2.3
+// cells; 99.9 % within -20 .. +8).  A move row is a whole 128-byte cache line at W = 500, of which the
+// traceback needs 16 bytes: 12.8 GB of lines per 10 000 x 10 kb reads, the whole cost of k_main_tb_par
+// (2.4 TB/s of line-granular reads; rotating the row inside its line changes nothing, measured).  So
+// the forward pass stores the 64 cells [s0, s0 + 64) around the centre a second time, 16 bytes per row,
+// rows back to back behind the read's move rows (same arena: strip row rr at mv + (B + 1) rowb + 16 rr).
+// The traceback reads eight rows per line from there and falls back to the full row whenever its
+// position leaves the strip's comfortable middle (and in the static rows at the read's start, which
+// have no strip).  Classes whose lanes hold whole bytes and divide the strip: 4, 8, 16, 32 cells.
+#define MV_STRIP_CELLS 64
+#define MV_STRIP_BYTES 16
+__host__ __device__ inline int mv_strip_s0(i64 W)
+{
+#ifdef TBA_NO_MV_STRIP
+    (void)W;
+    return -1;
+#else
+    const int c = cpl_class(W);
+    if (!(c == 4 || c == 8 || c == 16 || c == 32)) return -1;
+    const int unit = c > 16 ? c : 16;                 // dword- and lane-aligned
+    const int s0 = (((int)(W / 2) - 40) / unit) * unit; // the centre (W / 2 - 1) sits ~41 cells into the strip
+    return s0 >= 0 && s0 + MV_STRIP_CELLS <= 64 * c ? s0 : -1;
+#endif
+}
+
 // wave-uniform values the compiler cannot prove uniform (they come from vector loads or
 // shuffles) are moved to scalar registers explicitly, so that control flow on them is scalar
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -362,6 +388,12 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
     const int half_bw = W / 2; // integer division, pyx:327
     const double NEG_INF = -INFINITY;
     const i64 mv_stride = mv_class_rowb(CPL);
+    // centre strip of the adaptive rows (main forward pass of the batch pipeline only)
+    constexpr bool STRIP_CLASS = !DIRECT && (CPL == 4 || CPL == 8 || CPL == 16 || CPL == 32);
+    int strip_l0 = -1;           // first lane of the strip (-1: this read keeps none)
+    if constexpr (STRIP_CLASS) {
+        if (mode == DP_MAIN) { const int s0 = uni(r.strip_s0); strip_l0 = s0 >= 0 ? s0 / CPL : -1; }
+    }
     const int b0 = lane * CPL;   // my first band cell
     int nvalid = Wi - b0;        // how many of my cells are inside the band
     nvalid = nvalid < 0 ? 0 : (nvalid > CPL ? CPL : nvalid);
@@ -675,6 +707,21 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
                 for (int q = 0; q < BPL; q++) mrow[q] = (unsigned char)(mvw[q / 4] >> (8 * (q % 4)));
             }
         }
+        if constexpr (STRIP_CLASS && ADAPT) {
+            // the strip's lanes store their bytes a second time, rows 16 bytes apart behind the move rows
+            if (strip_l0 >= 0) {
+                const unsigned rel = (unsigned)(lane - strip_l0);
+                if (rel < (unsigned)(MV_STRIP_CELLS / CPL)) {
+                    unsigned char *sp = mv + (i64)(n_rows + 1) * mv_stride + (i64)(row + 1) * MV_STRIP_BYTES + rel * BPL;
+                    if constexpr (BPL == 1) *sp = (unsigned char)mvw[0];
+                    else if constexpr (BPL == 2) *(unsigned short *)sp = (unsigned short)mvw[0];
+                    else {
+#pragma unroll
+                        for (int q = 0; q < BPL / 4; q++) ((u32 *)sp)[q] = mvw[q];
+                    }
+                }
+            }
+        }
         if (DIRECT && job->fwd_out != nullptr) {
 #pragma unroll
             for (int j = 0; j < CPL; j++) job->fwd_out[(row + 1) * (i64)(64 * CPL) + b0 + j] = v[j];
@@ -978,6 +1025,7 @@ __global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const D
     ReadState &r = rs[ri];
     r.moves_off = 0;
     r.tb_done = 0;
+    r.strip_s0 = -1;
     r.tb_form = TBA_TB_FORM_NONE;
     r.dp_wg = 0;
     if (r.status != TBA_OK) return;
@@ -1049,7 +1097,9 @@ __global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const D
         hi_a[sp] = (i32)(sml + nzs);
     }
     r.path = PATH_ADAPTIVE; r.clip = clip; r.offset = offset; r.W = bw; r.n_static = msl;
-    r.moves_off = (r.B + 1) * (i64)mv_class_rowb(cpl_class(bw));
+    // (k_dp writes the centre strip; the reads k_dp_multi / k_dp_wgm take have none)
+    r.strip_s0 = dp_multi_class(bw).cpl != 0 || dp_by_workgroup(dp, r) ? -1 : mv_strip_s0(bw);
+    r.moves_off = (r.B + 1) * ((i64)mv_class_rowb(cpl_class(bw)) + (r.strip_s0 >= 0 ? MV_STRIP_BYTES : 0));
 }
 
 // exclusive scan of per-read arena sizes (held in `field`) into arena offsets: one workgroup,

@@ -48,19 +48,27 @@
 template <bool EXT>
 __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int roww, const i64 *st,
     int Wi, int thresh, i64 r0, i64 stop, i64 &cur_ev, int &bp_guess, int &rc, i64 *tb,
-    i64 &viol_lo, i64 cmp_lo, i64 &merged_row)
+    i64 &viol_lo, i64 cmp_lo, i64 &merged_row, const unsigned char *strip, int strip_s0, i64 n_static)
 {
     i64 stv[TBR];
     uint4 win[TBR];
     i64 oldv[TBR];
     int wb = (bp_guess >> 4) - 2;                   // first dword of the window
     wb = wb < 0 ? 0 : (wb > roww - 4 ? roww - 4 : wb);
+    // The centre strip (k_dp.h) holds cells [strip_s0, strip_s0 + 64) of every adaptive row, 16 bytes
+    // per row: while the walk is in its middle -- it nearly always is -- the block's windows come from
+    // there, eight rows to a cache line instead of one.  Same bits as the window of the full row at
+    // dword strip_s0 / 16, so everything below is unchanged; a position outside takes the slow path of
+    // its row (full row) and the next block looks again.
+    const bool use_strip = strip_s0 >= 0 && r0 - (TBR - 1) > n_static && bp_guess >= strip_s0 + 24 &&
+                           bp_guess < strip_s0 + 60;
+    if (use_strip) wb = strip_s0 >> 4;
 #pragma unroll
     for (int k = 0; k < TBR; k++) {
         const i64 rr = r0 - k;
         const i64 rc_ = rr >= 1 ? rr : 1;
         stv[k] = st[rc_ - 1];
-        win[k] = *(const uint4 *)(mv + rc_ * rowb + 4 * wb);
+        win[k] = use_strip ? *(const uint4 *)(strip + rc_ * MV_STRIP_BYTES) : *(const uint4 *)(mv + rc_ * rowb + 4 * wb);
         if (EXT) oldv[k] = tb[rc_ - 1];
     }
     u64 nzl[TBR], nzh[TBR], d2l[TBR], d2h[TBR];
@@ -167,6 +175,9 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     const i64 *st = band_starts + (on ? r.ref_off : 0);
     i64 *tb = read_tb + (on ? r.seg_off : 0);
     const int thresh = (int)dp->p.band_bound_thresh;
+    const int strip_s0 = on ? r.strip_s0 : -1;
+    const unsigned char *strip = mv + (B + 1) * (i64)rowb;   // (behind the move rows; valid when strip_s0 >= 0)
+    const i64 n_stat = on ? r.n_static : 0;
 
     // chunk c: rows (lo, hi], hi = B - c L; fewer chunks than lanes for short reads.  The rows of
     // the static bands at the start of the read (masked start, resquiggle.py:607-683: the path is
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
         bool walking = mine;
         while (__any(walking)) {
             if (walking) {
-                tbp_block<false>(mv, rowb, roww, st, Wi, thresh, r0, lo, cur, guess, rcA, tb, viol_lo, 0, none);
+                tbp_block<false>(mv, rowb, roww, st, Wi, thresh, r0, lo, cur, guess, rcA, tb, viol_lo, 0, none, strip, strip_s0, n_stat);
                 r0 -= TBR;
                 if (rcA != TBA_OK || r0 <= lo) walking = false;
             }
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
         i64 r0 = lo;
         while (__any(walking)) {
             if (walking) {
-                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rcB, tb, viol_lo, nxt_wrote_lo, merged_row);
+                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rcB, tb, viol_lo, nxt_wrote_lo, merged_row, strip, strip_s0, n_stat);
                 r0 -= TBR;
                 if (rcB != TBA_OK || merged_row != TBP_NONE || r0 <= lo2) walking = false;
             }

@@ -301,7 +301,7 @@ static int plan_batch(const tba_params *p, const tba_opts *o, i64 K, i64 n, cons
         // (n_ev - mask_len cells, any width: k_dp_wide beyond the widest class)
         i64 row_bytes = mv_row_bytes(p->bandwidth);
         if (short_read) row_bytes = std::max(row_bytes, mv_row_bytes(n_ev));
-        z.moves_need += (B + 1) * row_bytes;
+        z.moves_need += (B + 1) * (row_bytes + MV_STRIP_BYTES); // (+ the centre strip of the adaptive rows, k_dp.h)
         z.max_nev = std::max(z.max_nev, n_ev);
         // algorithmic traffic: raw in + seq + norm out + segs + band starts +
         // 2-bit moves + scalars
