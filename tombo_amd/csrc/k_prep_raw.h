@@ -76,6 +76,25 @@ __global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const
                 C[i] = (k >= 0 && k <= n) ? c[k] : 0.0;
             }
             __syncthreads();
+            // A window mean is shared by the (up to n_windows) positions whose k-th window it is:
+            // moving_average[j] is computed ONCE per j of the chunk, in place of c[j] (through
+            // registers: the difference reaches mini_window_size slots ahead), and a position reads
+            // its means 50 apart.  Same subtraction, same division, a seventh of them (the kernel was
+            // bound by its 7 divisions per position: 35 of ~90 float64 instructions).
+            constexpr int PER = (SM_T + SM_MAXW + 1 + 255) / 256;
+            double mq[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * 256;
+                if (i + (int)mw < N) mq[u] = div_by_recip(C[i + (int)mw] - C[i], dmw, rmw);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = tid + u * 256;
+                if (i + (int)mw < N) C[i] = mq[u];
+            }
+            __syncthreads();
         }
         for (int wq = wave; wq < SM_T / 64; wq += 4) {
             const i64 w = (q0 >> 6) + wq;
@@ -86,13 +105,16 @@ __global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const
             bool below = false;
             if (valid) {
                 double m[NW > 0 ? NW : 16];
-                double prev = staged ? C[i] : c[p];
+                double prev = staged ? 0.0 : c[p];
 #pragma unroll
                 for (int k = 0; k < (NW > 0 ? NW : 16); k++) {
                     if (NW > 0 || k < nw) {
-                        const double nxt = staged ? C[i + (int)mw * (k + 1)] : c[p + mw * (k + 1)];
-                        m[k] = div_by_recip(nxt - prev, dmw, rmw);
-                        prev = nxt;
+                        if (staged) m[k] = C[i + (int)mw * k];
+                        else {
+                            const double nxt = c[p + mw * (k + 1)];
+                            m[k] = div_by_recip(nxt - prev, dmw, rmw);
+                            prev = nxt;
+                        }
                     }
                 }
                 double acc = fabs(m[0] - m[1]); // diffs[0].copy()
@@ -241,6 +263,7 @@ __global__ __launch_bounds__(256) void k_stall_metric_i16(const ReadState *rs, c
     const int16_t *raw, u64 *bits)
 {
     __shared__ i32 P[SI_T + SI_MAXW + 8];
+    __shared__ double M[SI_T + SI_MAXW + 8]; // moving_average of the chunk, once per window start (see k_stall_metric)
     __shared__ i32 s_wave[4];
     const ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
@@ -282,6 +305,8 @@ __global__ __launch_bounds__(256) void k_stall_metric_i16(const ReadState *rs, c
         for (int i = a; i < b; i++) { const i32 t = P[i]; P[i] = off; off += t; }
         if (tid == 0) P[N] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]; // the total
         __syncthreads();
+        for (int i = tid; i + mw <= N; i += 256) M[i] = div_by_recip((double)(P[i + mw] - P[i]), dmw, rmw);
+        __syncthreads();
         // metric of the chunk's positions, 64 per ballot word
         for (int wq = wave; wq < SI_T / 64; wq += 4) {
             const i64 w = (q0 >> 6) + wq;
@@ -292,15 +317,9 @@ __global__ __launch_bounds__(256) void k_stall_metric_i16(const ReadState *rs, c
             bool below = false;
             if (valid) {
                 double m[NW > 0 ? NW : 16];
-                i32 prev = P[i];
 #pragma unroll
-                for (int k = 0; k < (NW > 0 ? NW : 16); k++) {
-                    if (NW > 0 || k < nw) {
-                        const i32 nxt = P[i + mw * (k + 1)];
-                        m[k] = div_by_recip((double)(nxt - prev), dmw, rmw);
-                        prev = nxt;
-                    }
-                }
+                for (int k = 0; k < (NW > 0 ? NW : 16); k++)
+                    if (NW > 0 || k < nw) m[k] = M[i + mw * k];
                 double acc = fabs(m[0] - m[1]); // diffs[0].copy()
 #pragma unroll
                 for (int ii = 0; ii < (NW > 0 ? NW : 16); ii++)

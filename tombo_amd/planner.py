@@ -49,7 +49,7 @@ def estimate_bytes(n_raw, seq_len, params, opts, kmer_width, raw_dtype=np.float6
     start_w = max(int(params.start_bw), int(params.start_save_bw))
     fixed = 512 + 32 + 8000 + 3072 * 8 + int(params.start_n_bases) * 8 + \
         (int(params.start_n_bases) + 1) * _mv_row_bytes(start_w) + 32768 * 8 + 64 + 24
-    moves = (B + 1) * _mv_row_bytes(int(params.bandwidth)) * 1.125
+    moves = (B + 1) * (_mv_row_bytes(int(params.bandwidth)) + 16) * 1.125   # (+ the centre strip, k_dp.h)
     return (S * per_sample + ne * 16 + L + B * per_base + fixed + moves) * 1.13
 
 
