@@ -665,11 +665,38 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const De
         double *sb = sbuf[tile & 1];
         const double *sp = sbuf[(tile & 1) ^ 1], *rt = rawt[tile & 1];
         const int P0 = tile * TT_NEW;
-        if (tile < n_tiles)
-            for (int c = st; c < TT_NEW; c += SC_NT) {
-                const double v = P0 + c < ns ? (WS > 0 ? ttest_score<WS>(rt + c, WS) : ttest_score<0>(rt + c, w)) : 0.0;
-                sb[TT_SPAD(32 + c)] = v;
+        if (tile < n_tiles) {
+            if constexpr (WS > 0 && TT_NEW % WS == 0) {
+                // A scorer thread walks a CHAIN of positions WS apart: the right window of one is the
+                // left window of the next, so k scores cost k + 1 windows instead of 2 k (the scorers
+                // were the longer side of a step: 14 k of its 16 k cycles, -DTBA_PHASE_DEBUG=9).
+                // Residue r = thread % WS, segment = thread / WS; the TT_NEW / WS chain steps of a residue
+                // are cut into SEGS segments of CH_LO or CH_LO + 1 steps.
+                constexpr int STEPS = TT_NEW / WS, SEGS = SC_NT / WS, CH_LO = STEPS / SEGS, N_HI = STEPS - CH_LO * SEGS;
+                const int rr = st % WS, seg = st / WS;
+                if (seg < SEGS) {
+                    const int len = seg < N_HI ? CH_LO + 1 : CH_LO;
+                    const int j0 = seg < N_HI ? (CH_LO + 1) * seg : (CH_LO + 1) * N_HI + CH_LO * (seg - N_HI);
+                    double m1, v1;
+                    tt_window<WS>(rt + (WS * j0 + rr), m1, v1);
+#pragma unroll
+                    for (int k = 0; k < CH_LO + 1; k++) {
+                        if (k < len) {
+                            const int c = WS * (j0 + k) + rr;
+                            double m2, v2;
+                            tt_window<WS>(rt + (c + WS), m2, v2);
+                            sb[TT_SPAD(32 + c)] = P0 + c < ns ? tt_combine(m1, m2, v1, v2) : 0.0;
+                            m1 = m2; v1 = v2;
+                        }
+                    }
+                }
+            } else {
+                for (int c = st; c < TT_NEW; c += SC_NT) {
+                    const double v = P0 + c < ns ? (WS > 0 ? ttest_score<WS>(rt + c, WS) : ttest_score<0>(rt + c, w)) : 0.0;
+                    sb[TT_SPAD(32 + c)] = v;
+                }
             }
+        }
         if (st < 32) sb[st] = tile > 0 ? sp[TT_SPAD(32 * (TT_WORDS - 1) + st)] : 0.0; // word 0 <- last word
     };
     if (wave >= 1) {
@@ -687,9 +714,20 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const De
 #pragma unroll
     for (int d = 0; d <= R; d++) prevX[d] = 0;
     double smin = INFINITY, smax = -INFINITY;            // range of the emitted scores (k_pick's select)
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 9
+    // cycles of the greedy wavefront / of one scorer wavefront inside their sections, and of the whole loop
+    i64 tt_acc = 0;
+    const i64 tt_t0 = (i64)__builtin_readcyclecounter();
+#define TT_T0() const i64 tt_a_ = (i64)__builtin_readcyclecounter()
+#define TT_T1() tt_acc += (i64)__builtin_readcyclecounter() - tt_a_
+#else
+#define TT_T0() do { } while (0)
+#define TT_T1() do { } while (0)
+#endif
     for (int i = 0; i <= n_tiles; i++) {                 // (one more step finishes the carried word)
         const double *sb = sbuf[i & 1];
         const int P0 = i * TT_NEW;                       // first new position of the tile
+        TT_T0();
         if (wave != 0) {
             // tile i + 1: its samples sit in rawt[(i + 1) & 1]; tile i + 2's are fetched meanwhile and
             // dropped into rawt[i & 1], which nobody reads any more (tile i was scored a step ago)
@@ -700,6 +738,12 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const De
             }
         } else {
             // ---- greedy: lane h = positions P0 - 32 + 32 h .. + 31, scores at sb[33 h ..]
+            // One wavefront against seven scorers, and the step ends when BOTH are done: at equal
+            // priority the arbiter stretched this wavefront's ~3 k cycles of issue over 13 k (of a 16 k
+            // step; -DTBA_PHASE_DEBUG=9).  It goes first; the scorers fill what it leaves.
+#ifndef TBA_TT_NO_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
             const int h = lane;
             const int pos0 = P0 - 32 + 32 * h;
             const double *row = sb + 33 * h;
@@ -812,9 +856,18 @@ __global__ __launch_bounds__(SEL_NT, 4) void k_detect_tt(ReadState *rs, const De
 #pragma unroll
             for (int d = 1; d <= R; d++) prevX[d] = (u32)__shfl((int)X[d], TT_WORDS - 2, 64);
             prev_emitted = (u32)__shfl((int)T, TT_WORDS - 1, 64);
+#ifndef TBA_TT_NO_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
+        TT_T1();
         __syncthreads();
     }
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 9
+    if (lane == 0 && wave == 0) { r.dbg[0] = tt_acc; r.dbg[2] = (i64)__builtin_readcyclecounter() - tt_t0; r.dbg[3] = n_tiles; }
+    if (lane == 0 && wave == 1) r.dbg[1] = tt_acc;
+    if (lane == 0 && wave == 7) r.dbg[4] = tt_acc;
+#endif
     if (wave == 0) {
         for (int mm = 32; mm >= 1; mm >>= 1) {
             const double a = shfl_xor_f64(smin, mm), b = shfl_xor_f64(smax, mm);

@@ -427,6 +427,28 @@ __device__ __forceinline__ double ttest_score(Acc t, int w)
     if (var1 + var2 == 0) return 0.0;
     return m1 > m2 ? (m1 - m2) / sqrt(var1 + var2) : (m2 - m1) / sqrt(var1 + var2);
 }
+// The two windows of position pos are the windows STARTING at pos and at pos + w: each is the same
+// expression of its own w samples (sum from the left, one division, squared deviations summed from
+// the left), so a window computed once serves as the right window of pos - w and the left one of pos.
+template <int WS, class Acc>
+__device__ __forceinline__ void tt_window(Acc t, double &m, double &var)
+{
+    double a[WS];
+#pragma unroll
+    for (int j = 0; j < WS; j++) a[j] = t[j];
+    double sm = 0, sv = 0, d;
+#pragma unroll
+    for (int j = 0; j < WS; j++) sm += a[j];
+    sm /= (double)WS;
+#pragma unroll
+    for (int j = 0; j < WS; j++) { d = a[j] - sm; sv += d * d; }
+    m = sm; var = sv;
+}
+__device__ __forceinline__ double tt_combine(double m1, double m2, double var1, double var2)
+{
+    if (var1 + var2 == 0) return 0.0;
+    return m1 > m2 ? (m1 - m2) / sqrt(var1 + var2) : (m2 - m1) / sqrt(var1 + var2);
+}
 #define TT_MAXW 64
 template <class RT>
 __global__ __launch_bounds__(256) void k_scores_ttest(const ReadState *rs, const DevParams *dp,
