@@ -465,6 +465,55 @@ def test_batch_properties_at_scale_on_gpu(dispatch_form):
     assert [h for _, h, *_ in part] == [full[i][1] for i in sub], 'depends on batch composition'
 
 
+def test_default_dispatch_above_and_below_its_thresholds_agree_on_gpu():
+    """2 048 reads of 4 kb at W = 500 as ONE batch (default dispatch: the throughput kernels) and as two
+    batches of 1 024 (the latency kernels): same boundaries, signal, scale values and scores read for
+    read -- the two forms against each other at the benchmark's band width, beyond what the oracle
+    finishes in seconds"""
+    import hashlib
+    from tombo_amd import _native as N, synth, tombo_stats as ts, tombo_helper as th
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    samp = th.seqSampleType('DNA', False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=500)
+    n = 2048
+    sp = N.make_synth_params(**synth.DNA_SYNTH)
+    gen = N.Synth(model, 0)
+    eng = _engine()
+    assert eng.get_dispatch() == (1024, 1024)
+    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+    p = N.make_params(params)
+
+    def run(first, count):
+        raw, raw_off, seq, seq_off = gen.generate(sp, 424243, np.full(count, 4000, np.int64), raw_dtype=np.int16,
+                                                  first_read=first)
+        o = N.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH['DNA'], subsample_seed=5,
+                        subsample_first_read=first)
+        eng.upload_packed(p, o, raw, raw_off, seq, seq_off, wait=True)
+        eng.run()
+        out = eng.download()
+        ed, tb = eng.get(N.GET_ED_FORM), eng.get(N.GET_TB_FORM)
+        per = []
+        for j in range(count):
+            segs = out['segs'][eng.seg_off[j]:eng.seg_off[j + 1]]
+            nl = int(out['norm_len'][j])
+            sig = out['norm'][eng.raw_off[j]:eng.raw_off[j] + nl]
+            per.append((int(out['status'][j]), hashlib.sha256(
+                segs.tobytes() + sig.tobytes() + out['sv'][j].tobytes() + out['score'][j:j + 1].tobytes()).hexdigest()))
+        return per, ed, tb
+    whole, ed_w, tb_w = run(0, n)
+    assert sum(st == 0 for st, _ in whole) >= n - 8
+    ok = np.array([st == 0 for st, _ in whole])
+    assert np.all(ed_w[ok] == N.ED_FORM_DETECT_PICK) and set(tb_w[ok].tolist()) <= {N.TB_FORM_PAR16, N.TB_FORM_LANE}
+    halves = []
+    for first in (0, 1024):
+        part, ed_p, tb_p = run(first, 1024)
+        okp = np.array([st == 0 for st, _ in part])
+        assert np.all(ed_p[okp] == N.ED_FORM_WG_SCAN_PEAKS) and N.TB_FORM_PAR16 not in set(tb_p.tolist())
+        halves += part
+    assert halves == whole
+
+
 def test_degenerate_inputs_on_gpu(dispatch_form):
     """too-short sequence, tiny signal, constant signal: a status, never a crash"""
     from tombo_amd import synth, tombo_stats as ts, tombo_helper as th, resquiggle as rq
