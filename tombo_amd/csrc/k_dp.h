@@ -397,6 +397,7 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
     const int b0 = lane * CPL;   // my first band cell
     int nvalid = Wi - b0;        // how many of my cells are inside the band
     nvalid = nvalid < 0 ? 0 : (nvalid > CPL ? CPL : nvalid);
+    const u64 has_cells = __ballot(nvalid > 0);         // lanes that hold band cells
     const double zcap = winsor ? max_half_z : INFINITY; // no winsorising: clamp at +inf
     double zs[CPL]; // z_shift per cell, -inf for the cells past the band (folds the band-end mask
                     // into the subtraction that forms z)
@@ -750,7 +751,8 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
             if (__popcll(cm) == 1) wm = readlane_f64(lmax, __ffsll((unsigned long long)cm) - 1);
             else wm = wave_max_f64(lmax);
         }
-        const u64 eq = __ballot(lmax == wm && nvalid > 0);
+        const u64 eq = __ballot(lmax == wm) & has_cells; // (the AND on the scalar unit: a lane predicate in the
+                                                         // ballot went through a 0/1 register and a second compare)
         const int wl = __ffsll((unsigned long long)eq) - 1; // first lane holding the maximum
         int wj = CPL - 1;
 #pragma unroll
