@@ -59,17 +59,27 @@ def stalls_awkward():
     return n_bad
 
 
-def big_fuzz(n_examples):
+def big_fuzz(n_examples, form):
     import test_gpu_param_fuzz as f
     from hypothesis import settings, HealthCheck, given
-    fn = f.test_engine_matches_oracle_over_the_parameter_box.hypothesis.inner_test
-    t = settings(max_examples=n_examples, deadline=None, derandomize=False, database=None,
-                 suppress_health_check=list(HealthCheck))(given(f.param_points())(fn))
+
+    @settings(max_examples=n_examples, deadline=None, derandomize=False, database=None,
+              suppress_health_check=list(HealthCheck))
+    @given(f.param_points())
+    def t(pt):
+        f._box_point(form, pt)
     t()
     print('fuzz: %d examples ok' % n_examples)
     return 0
 
 
 if __name__ == '__main__':
-    bad = retry_heavy() + stalls_awkward() + big_fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 600)
+    from conftest import FORMS, engine_dispatch
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+    bad = 0
+    for form in FORMS:      # the latency and the throughput kernels of event detection / traceback
+        print('--- dispatch form: %s' % form)
+        with engine_dispatch(form):
+            bad += retry_heavy() + big_fuzz(n, form)
+    bad += stalls_awkward()
     print('STRESS', 'OK' if bad == 0 else 'FAILED (%d)' % bad)
