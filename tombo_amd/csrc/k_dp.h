@@ -284,7 +284,12 @@ template <int CPL, bool DIRECT>
 #ifndef TBA_DP_WAVES
 #define TBA_DP_WAVES 4
 #endif
-#define TBA_DP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CPL <= 8 ? TBA_DP_WAVES : 1)))
+// (The 12-cell class -- start discovery at DNA's start_bw = 750 -- comes out at 196 registers = two
+// wavefronts per SIMD; held to three (168, no spills: -DTBA_DP12_WAVES=3) it measured 3.94 against 3.85 ms.)
+#ifndef TBA_DP12_WAVES
+#define TBA_DP12_WAVES 1
+#endif
+#define TBA_DP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CPL <= 8 ? TBA_DP_WAVES : (CPL == 12 ? TBA_DP12_WAVES : 1))))
 __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int mode,
     const double *event_means, const double *ref_means, const double *ref_sds,
     i64 *band_starts, const i32 *lo_arr, const i32 *hi_arr,

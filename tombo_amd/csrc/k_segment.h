@@ -1010,9 +1010,12 @@ __global__ __launch_bounds__(SEL_NT) void k_rna_event_scale(ReadState *rs, const
 
 // TomboModel.get_exp_levels_from_seq (tombo_stats.py:834-862): k-mer code -> level mean / sd.
 // grid: (blocks, reads)
+// defer != 0 (the side stream of a full run: this kernel runs beside the segmentation stage): an
+// invalid base is only noted (ReadState.bad_seq) and becomes the read's status where the stage stands in
+// the reference's order (k_seq_status) -- a read that ALSO fails in segmentation fails with that error.
 __global__ __launch_bounds__(256) void k_ref_levels(ReadState *rs, const DevParams *dp,
     const uint8_t *seq, const double *kmer_means, const double *kmer_sds, double *ref_means,
-    double *ref_sds)
+    double *ref_sds, int defer = 0)
 {
     ReadState &r = rs[blockIdx.y];
     if (r.status != TBA_OK) return;
@@ -1029,5 +1032,10 @@ __global__ __launch_bounds__(256) void k_ref_levels(ReadState *rs, const DevPara
         ref_means[r.ref_off + i] = kmer_means[code];
         ref_sds[r.ref_off + i] = kmer_sds[code];
     }
-    if (bad) r.status = TBA_INVALID_SEQ;
+    if (bad) { if (defer) r.bad_seq = 1; else r.status = TBA_INVALID_SEQ; }
+}
+__global__ __launch_bounds__(64) void k_seq_status(ReadState *rs, i64 n_reads)
+{
+    const i64 ri = (i64)blockIdx.x * 64 + threadIdx.x;
+    if (ri < n_reads && rs[ri].status == TBA_OK && rs[ri].bad_seq) rs[ri].status = TBA_INVALID_SEQ;
 }

@@ -57,7 +57,8 @@ struct ReadState {
     i32 tb_done;              // the main traceback of this read is finished (k_tb_par.h)
     i32 ed_flag, dp_wg; // dp_wg: the main forward pass was run by a workgroup (k_dp_wgm.h)        // event detection: 1 = this read needs the kernels that keep the scores (k_detect.h)
     i32 ed_form, tb_form;     // which kernels produced this read's change points / main traceback
-    i32 strip_s0, pad1;       // first band cell of the centre strip k_dp keeps beside the move rows (-1: none; k_dp.h)
+    i32 strip_s0;             // first band cell of the centre strip k_dp keeps beside the move rows (-1: none; k_dp.h)
+    i32 bad_seq;              // k_ref_levels on the side stream found a base outside ACGT (applied in stage order: k_seq_status)
                               // (TBA_ED_FORM_* / TBA_TB_FORM_*, include/tombo_amd.h: TBA_GET_ED_FORM / TBA_GET_TB_FORM)
     i64 n_taken;              // entries of the taken (score, position) list k_detect left
     double ed_min, ed_max;    // ... and the range of its scores

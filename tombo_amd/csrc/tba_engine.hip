@@ -96,6 +96,13 @@ static void launch_peaks(i64 min_obs_per_base, unsigned n_blocks, hipStream_t s,
 struct tba_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    // Side stream of a full pipeline run: what does not depend on event detection -- the worker's
+    // stall detection over the raw samples (RNA) and the expected levels of the sequence -- runs
+    // beside the normalisation / event detection kernels of the main stream and is joined before its
+    // first consumer (k_remove_stalls; start discovery).  Both groups wait on memory most of their time
+    // (SQ_WAIT_ANY 60-80 % of their wave cycles): together they fill what each leaves idle.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_stalls = nullptr, ev_levels = nullptr, ev_st0 = nullptr, ev_st1 = nullptr;
     hipEvent_t ev[N_STAGE + 1] = {};
     float stage_ms[32] = {};
     bool have_model = false, have_batch = false, ran = false;
@@ -118,7 +125,8 @@ struct tba_engine {
     DevBuf d_rs, d_dp, d_kmeans, d_ksds, d_raw, d_norm, d_norm_out, d_csum, d_score, d_state,
         d_cpts, d_evm, d_seq, d_refm, d_refs, d_bst, d_lo, d_hi, d_readtb, d_dpsegs, d_segs,
         d_win, d_absz, d_sv_in, d_samp, d_stall, d_lastrow, d_startvals, d_smoves,
-        d_moves, d_dscr, d_wide, d_stat, d_order, d_long;
+        d_moves, d_dscr, d_wide, d_stat, d_order, d_long,
+        d_stall_csum, d_stall_bits;  // the stall detector's own scratch (it runs beside event detection)
     PinBuf h_order;               // read indices by decreasing length (k_dp_multi's grouping)
     PinBuf h_long;                // indices of the long reads (k_long.h)
     i64 n_long = 0;
@@ -128,7 +136,8 @@ struct tba_engine {
                          &d_score, &d_state, &d_cpts, &d_evm, &d_seq, &d_refm, &d_refs, &d_bst,
                          &d_lo, &d_hi, &d_readtb, &d_dpsegs, &d_segs, &d_win, &d_absz,
                          &d_sv_in, &d_samp, &d_stall, &d_lastrow, &d_startvals, &d_smoves,
-                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq, &d_order, &d_long};
+                         &d_moves, &d_dscr, &d_wide, &d_stat, &d_res, &d_segs32, &d_skipq, &d_order, &d_long,
+                         &d_stall_csum, &d_stall_bits};
         for (DevBuf *b : all) b->release();
         h_order.release();
         h_long.release();
@@ -166,6 +175,8 @@ extern "C" int tba_engine_create(int device, tba_engine **out)
     if (const char *v = getenv("TBA_SMALL_BATCH_READS")) e->small_batch = std::max<i64>(atoll(v), 0);
     if (const char *v = getenv("TBA_TB_WAVE_BELOW")) e->tb_wave_below = std::max<i64>(atoll(v), 0);
     HIP_TRY(hipStreamCreate(&e->stream));
+    HIP_TRY(hipStreamCreate(&e->stream2));
+    for (hipEvent_t *x : {&e->ev_fork, &e->ev_stalls, &e->ev_levels, &e->ev_st0, &e->ev_st1}) HIP_TRY(hipEventCreate(x));
     for (int i = 0; i <= N_STAGE; i++) HIP_TRY(hipEventCreate(&e->ev[i]));
     *out = e;
     return 0;
@@ -176,8 +187,11 @@ extern "C" void tba_engine_destroy(tba_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     e->release_all();
     for (int i = 0; i <= N_STAGE; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (hipEvent_t x : {e->ev_fork, e->ev_stalls, e->ev_levels, e->ev_st0, e->ev_st1}) if (x) (void)hipEventDestroy(x);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -361,6 +375,10 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     BUF(d_dscr, (size_t)z.skip_arena * 8);
     if (z.wide_w) BUF(d_wide, (size_t)WIDE_BLOCKS * 2 * (size_t)z.wide_w * 8);
     if (z.n_stall > 0) BUF(d_stall, (size_t)z.n_stall * 16);
+    if (o->detect_stalls) { // (its scratch is its own: the detector runs beside event detection, which owns csum / state)
+        BUF(d_stall_bits, S / 8 + 8 * N + 64);
+        if (!(raw_dtype == TBA_RAW_I16 && o->stall_window_size <= SI_MAXW)) BUF(d_stall_csum, (S + N) * 8 + 64);
+    }
     BUF(d_skipq, 64 + 3 * (N * 32 + 4096) * 8);
     BUF(d_order, N * 4);
     BUF(d_long, N * 4);
@@ -616,26 +634,47 @@ static int enqueue_stages(tba_engine *e, int first, int last)
 #define ON(stage_) ((stage_) >= first && (stage_) <= last)
     const bool rna = P.use_t_test_seg != 0;
     const int rdt = e->raw_dtype;
-    // caller-side preparation: ts.identify_stalls over the raw samples (events 15 -> 16)
-    HIP_TRY(hipEventRecord(e->ev[15], s));
+    HIP_TRY(hipEventRecord(e->ev[15], s));                 // start of the sequence (the `total` bracket)
+    // A full run forks the side stream here (-DTBA_NO_SIDE_STREAM / TBA_NO_SIDE_STREAM=1: everything on
+    // the main stream, in this order); a partial run (stepwise API) stays on one stream.
+#ifdef TBA_NO_SIDE_STREAM
+    const bool side = false;
+#else
+    static const bool side_off = getenv("TBA_NO_SIDE_STREAM") != nullptr;
+    const bool side = !side_off && first == TBA_STAGE_SEGMENT && last == TBA_STAGE_RESCALE;
+#endif
+    hipStream_t s2 = side ? e->stream2 : s;
+    if (side) {
+        HIP_TRY(hipEventRecord(e->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
+    }
+    // caller-side preparation: ts.identify_stalls over the raw samples (its own scratch: it runs beside
+    // event detection)
+    HIP_TRY(hipEventRecord(e->ev_st0, s2));
     if (ON(TBA_STAGE_SEGMENT) && e->hp.o.detect_stalls) {
-        double *csum = e->d_csum.as<double>();
-        u64 *bits = e->d_state.as<u64>();
+        double *csum = e->d_stall_csum.as<double>();
+        u64 *bits = e->d_stall_bits.as<u64>();
         const unsigned gq = gx(e->max_raw / 8 + 1); // chunks of SI_T positions
         if (rdt == TBA_RAW_I16 && e->hp.o.stall_window_size <= SI_MAXW) { // exact integer sums: no cumulative sum in memory
-            if (e->hp.o.stall_n_windows == 7) k_stall_metric_i16<7><<<dim3(gq, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<int16_t>(), bits);
-            else k_stall_metric_i16<0><<<dim3(gq, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<int16_t>(), bits);
+            if (e->hp.o.stall_n_windows == 7) k_stall_metric_i16<7><<<dim3(gq, nb), 256, 0, s2>>>(rs, dp, e->d_raw.as<int16_t>(), bits);
+            else k_stall_metric_i16<0><<<dim3(gq, nb), 256, 0, s2>>>(rs, dp, e->d_raw.as<int16_t>(), bits);
         } else {
-        if (cs_reads_for(n) == 20) RAW_DISPATCH(rdt, (k_cumsum_scores<20, RT, 1><<<(unsigned)((n + 19) / 20), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
-        else RAW_DISPATCH(rdt, (k_cumsum_scores<32, RT, 1><<<(unsigned)((n + 31) / 32), 256, 0, s>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
-        if (e->n_long > 0) RAW_DISPATCH(rdt, (k_cumsum_scores_long<RT, 1><<<(unsigned)e->n_long, 256, 0, s>>>(rs, e->d_long.as<i32>(), dp, e->d_raw.as<RT>(), csum)));
-        if (e->hp.o.stall_n_windows == 7) k_stall_metric<7><<<dim3(gq, nb), 256, 0, s>>>(rs, dp, csum, bits);
-        else k_stall_metric<0><<<dim3(gq, nb), 256, 0, s>>>(rs, dp, csum, bits);
+        if (cs_reads_for(n) == 20) RAW_DISPATCH(rdt, (k_cumsum_scores<20, RT, 1><<<(unsigned)((n + 19) / 20), 256, 0, s2>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
+        else RAW_DISPATCH(rdt, (k_cumsum_scores<32, RT, 1><<<(unsigned)((n + 31) / 32), 256, 0, s2>>>(rs, n, dp, e->d_raw.as<RT>(), csum)));
+        if (e->n_long > 0) RAW_DISPATCH(rdt, (k_cumsum_scores_long<RT, 1><<<(unsigned)e->n_long, 256, 0, s2>>>(rs, e->d_long.as<i32>(), dp, e->d_raw.as<RT>(), csum)));
+        if (e->hp.o.stall_n_windows == 7) k_stall_metric<7><<<dim3(gq, nb), 256, 0, s2>>>(rs, dp, csum, bits);
+        else k_stall_metric<0><<<dim3(gq, nb), 256, 0, s2>>>(rs, dp, csum, bits);
         }
-        k_stall_runs<<<dim3(gx(e->max_raw / 64 + 1), nb), 256, 0, s>>>(rs, dp, bits, e->d_stall.as<i64>());
-        k_stall_merge<<<tpr, 64, 0, s>>>(rs, n, dp, e->d_stall.as<i64>());
+        k_stall_runs<<<dim3(gx(e->max_raw / 64 + 1), nb), 256, 0, s2>>>(rs, dp, bits, e->d_stall.as<i64>());
+        k_stall_merge<<<tpr, 64, 0, s2>>>(rs, n, dp, e->d_stall.as<i64>());
     }
-    HIP_TRY(hipEventRecord(e->ev[16], s));
+    HIP_TRY(hipEventRecord(e->ev_st1, s2));
+    if (side) {
+        HIP_TRY(hipEventRecord(e->ev_stalls, s2));
+        // the expected levels need the sequence and the model only
+        k_ref_levels<<<dim3(gB, nb), 256, 0, s2>>>(rs, dp, e->d_seq.as<uint8_t>(), e->d_kmeans.as<double>(), e->d_ksds.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), 1);
+        HIP_TRY(hipEventRecord(e->ev_levels, s2));
+    }
     MARK(); // 0 normalize
     const bool fused_scores = 2 * P.running_stat_width <= 64; // cumsum + scores in one kernel
     // DNA defaults: the scores never reach memory (k_detect.h); what that form leaves (flagged reads)
@@ -691,6 +730,7 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     if (ON(TBA_STAGE_SEGMENT)) {
         launch_peaks(P.min_obs_per_base, nb, s, rs, dp, e->d_score.as<double>(), e->d_state.as<unsigned char>(), e->d_csum.as<double>(), e->d_cpts.as<i64>(), rna ? 1 : 0, only_flagged,
                      rna ? TBA_ED_FORM_TTEST_PEAKS : wg_scan ? TBA_ED_FORM_WG_SCAN_PEAKS : TBA_ED_FORM_SCORES_PEAKS);
+        if (side) HIP_TRY(hipStreamWaitEvent(s, e->ev_stalls, 0)); // the stall intervals (and nothing else of the side stream)
         if (e->any_stall) k_remove_stalls<<<nb, SEL_NT, 0, s>>>(rs, n, e->d_stall.as<i64>(), e->d_cpts.as<i64>(), e->d_csum.as<double>());
         if (rna) { // RNA normalises after event detection (segment_signal, resquiggle.py:1073-1098)
             RAW_DISPATCH(rdt, (k_event_means<RT, 1280><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_raw.as<RT>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 1)));
@@ -705,7 +745,10 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         else k_event_means<double><<<dim3(gE, nb), 256, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_cpts.as<i64>(), e->d_evm.as<double>(), 0);
     }
     MARK(); // 5 ref levels
-    if (ON(TBA_STAGE_REF_LEVELS))
+    if (side) {                                                    // (computed on the side stream)
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_levels, 0));
+        k_seq_status<<<tpr, 64, 0, s>>>(rs, n);
+    } else if (ON(TBA_STAGE_REF_LEVELS))
         k_ref_levels<<<dim3(gB, nb), 256, 0, s>>>(rs, dp, e->d_seq.as<uint8_t>(), e->d_kmeans.as<double>(), e->d_ksds.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>());
     MARK(); // 6 start dp (+7 start tb): find_seq_start_in_events, first try then retry
     if (ON(TBA_STAGE_START)) {
@@ -892,7 +935,7 @@ extern "C" int tba_batch_sync(tba_engine *e)
     if (e->ran) {
         memset(e->stage_ms, 0, sizeof(e->stage_ms));
         for (int i = 0; i < 14; i++) (void)hipEventElapsedTime(&e->stage_ms[i], e->ev[i], e->ev[i + 1]);
-        (void)hipEventElapsedTime(&e->stage_ms[14], e->ev[15], e->ev[16]); // stall detection
+        (void)hipEventElapsedTime(&e->stage_ms[14], e->ev_st0, e->ev_st1); // stall detection (side stream: overlaps the stages above)
         (void)hipEventElapsedTime(&e->stage_ms[15], e->ev[15], e->ev[14]);
     }
     return 0;
@@ -2146,7 +2189,8 @@ extern "C" int tba_engine_held_bytes(tba_engine *e, int64_t *bytes)
                      &e->d_score, &e->d_state, &e->d_cpts, &e->d_evm, &e->d_seq, &e->d_refm, &e->d_refs, &e->d_bst,
                      &e->d_lo, &e->d_hi, &e->d_readtb, &e->d_dpsegs, &e->d_segs, &e->d_win, &e->d_absz,
                      &e->d_sv_in, &e->d_samp, &e->d_stall, &e->d_lastrow, &e->d_startvals, &e->d_smoves,
-                     &e->d_moves, &e->d_dscr, &e->d_wide, &e->d_stat, &e->d_res, &e->d_segs32, &e->d_skipq};
+                     &e->d_moves, &e->d_dscr, &e->d_wide, &e->d_stat, &e->d_res, &e->d_segs32, &e->d_skipq,
+                     &e->d_stall_csum, &e->d_stall_bits};
     for (DevBuf *b : all) tot += b->cap;
     *bytes = (int64_t)tot;
     return 0;

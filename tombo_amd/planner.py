@@ -45,6 +45,8 @@ def estimate_bytes(n_raw, seq_len, params, opts, kmer_width, raw_dtype=np.float6
     ne = _num_events(S, B, params.mean_obs_per_event, opts.min_event_to_seq_ratio)
     raw_b = np.dtype(raw_dtype).itemsize
     per_sample = raw_b + 8 + (0 if opts.skip_norm_out else 8) + 8 + 8 + 1
+    if opts.detect_stalls:   # the detector's own scratch (it runs beside event detection)
+        per_sample += 0.125 + (0 if (raw_b == 2 and opts.stall_window_size <= 1024) else 8)
     per_base = 8 * 3 + 4 + 4 + 8 * 3 + 24 + 8 + 4
     start_w = max(int(params.start_bw), int(params.start_save_bw))
     fixed = 512 + 32 + 8000 + 3072 * 8 + int(params.start_n_bases) * 8 + \
