@@ -958,7 +958,8 @@ __global__ __launch_bounds__(SEL_NT) void k_remove_stalls(ReadState *rs, i64 n_r
 template <class RT, int CAP = 448>
 // scale_events != 0: only the events ts.get_scale_values_from_events looks at are needed (the
 // first min(rna_scale_num_events, int(frac * n_cpts)) - 1, tombo_stats.py:220-224).
-__global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const DevParams *dp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, CAP > 448 ? 4 : 8)))
+void k_event_means(const ReadState *rs, const DevParams *dp,
     const RT *sig, const i64 *valid_cpts, double *event_means, int scale_events)
 {
     const ReadState &r = rs[blockIdx.y];
@@ -977,8 +978,10 @@ __global__ __launch_bounds__(256) void k_event_means(const ReadState *rs, const 
     }
     __shared__ double s_seg[4 * CAP];
     const int wave = threadIdx.x >> 6;
+    struct None {};
     wave_segment_sums<CAP>(x, c, n, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
-                      [&](i64 e, double s, i64 len) { em[e] = s / (double)len; },
+                      nullptr, [](double v) { return v; }, [](i64) { return None{}; },
+                      [&](i64 e, double s, i64 len, None) { em[e] = s / (double)len; },
                       (double)r.n_raw / (double)(r.n_cpts > 1 ? r.n_cpts - 1 : 1));
 }
 

@@ -77,12 +77,10 @@ __device__ __forceinline__ void block_map2(i64 n, Sig x, double *out, F f)
 // and access (16-byte loads and stores); all loads of a lane go out before the first value is used
 // (uniform branches: span is made an SGPR).  The pair that straddles the end of an odd span reads
 // one element past it: every signal buffer of the engine carries a few bytes of slack for that.
-template <int NP, class Sig, class F>
-__device__ __forceinline__ void wave_stage(Sig x, i64 lo, i64 span, double *lds, double *out, F f)
+template <int NP, class Sig>
+__device__ __forceinline__ void wave_stage_load(Sig x, i64 lo, int spn, double (&a)[NP], double (&b)[NP])
 {
     const int lane = threadIdx.x & 63;
-    const int spn = __builtin_amdgcn_readfirstlane((int)span);
-    double a[NP], b[NP];
 #pragma unroll
     for (int u = 0; u < NP; u++) {
         if (128 * u < spn) {
@@ -91,6 +89,12 @@ __device__ __forceinline__ void wave_stage(Sig x, i64 lo, i64 span, double *lds,
             sig_pair(x, lo + k, a[u], b[u]);
         }
     }
+}
+template <int NP, class F>
+__device__ __forceinline__ void wave_stage_store(const double (&a)[NP], const double (&b)[NP], i64 lo, int spn,
+                                                 double *lds, double *out, F f)
+{
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int u = 0; u < NP; u++) {
         if (128 * u < spn) {
@@ -106,6 +110,14 @@ __device__ __forceinline__ void wave_stage(Sig x, i64 lo, i64 span, double *lds,
             }
         }
     }
+}
+template <int NP, class Sig, class F>
+__device__ __forceinline__ void wave_stage(Sig x, i64 lo, i64 span, double *lds, double *out, F f)
+{
+    const int spn = __builtin_amdgcn_readfirstlane((int)span);
+    double a[NP], b[NP];
+    wave_stage_load<NP>(x, lo, spn, a, b);
+    wave_stage_store<NP>(a, b, lo, spn, lds, out, f);
 }
 
 #define SEL_NT 512 // threads per workgroup for every kernel that uses these helpers
@@ -813,9 +825,8 @@ __device__ bool block_int_medians(XS x, i64 n, int vmin_s, int vmax_s, BucketSme
 // sum of p[j0 .. j1) in index order (c_new_means adds sample by sample), the LDS loads issued eight
 // at a time: the adds are the only dependent chain (a plain loop waits one LDS round trip per
 // sample, which is what bounded the RNA segment kernels: 15-sample events, 43-sample bases)
-__device__ __forceinline__ double seq_sum_lds(const double *p, i64 j0, i64 j1)
+__device__ __forceinline__ double seq_sum_lds(const double *p, i64 j0, i64 j1, double s = 0)
 {
-    double s = 0;
     i64 j = j0;
     for (; j + 8 <= j1; j += 8) {
         double t[8];
@@ -828,19 +839,26 @@ __device__ __forceinline__ double seq_sum_lds(const double *p, i64 j0, i64 j1)
     return s;
 }
 
-// c_new_means-style segment means, wave-cooperative: a wavefront takes 64 consecutive segments,
-// pulls the samples they span (one contiguous range) into its LDS slice with coalesced loads, and
-// every lane then sums its own segment out of LDS -- sequentially, in sample order, like the
-// reference.  A thread-per-segment loop over global memory touches 64 different cache lines per
-// load instead.  Spans longer than SEGW_CAP samples (long dwell, RNA) take the direct loop; the
-// cap is per kernel: a smaller LDS slice lets more workgroups share a CU (these kernels are
-// bandwidth bound, occupancy is what keeps bytes in flight).
-// seg has n_segs + 1 ascending boundaries; emit(i, sum, length) per segment.
-template <int SEGW_CAP, class Sig, class Emit>
+// c_new_means-style segment sums, wave-cooperative: a wavefront takes a group of consecutive
+// segments, pulls the samples they span (one contiguous range) into its LDS slice with coalesced
+// loads -- as f(sample), written to out[] as well when out != nullptr -- and every lane then sums its
+// own segment out of LDS: sequentially, in sample order, like the reference.  (A thread-per-segment
+// loop over global memory touches 64 different cache lines per load instead.)
+// The loop over a wave's groups is software-pipelined: while the lanes add up group g out of LDS
+// the samples of group g + 1 are on their way into registers and the boundaries of group g + 2
+// (and whatever emit needs per segment: pre(i)) behind them, so a step waits one memory round trip
+// where it used to wait three in a row (boundaries -> samples -> emit's operands; RNA, 10 000
+// reads: k_rescale_absz 8.2 ms, k_event_means 4.5 ms, both bound by exactly that chain).
+// A group whose span exceeds the slice (long dwell, RNA stalls) is staged SEGW_CAP samples at a
+// time, every lane carrying its running sum from one piece to the next: the same additions in the
+// same order.
+// seg has n_segs + 1 ascending boundaries; emit(i, sum, length, pre(i)) per segment.
+template <int SEGW_CAP, class Sig, class F, class Pre, class Emit>
 __device__ __forceinline__ void wave_segment_sums(Sig x,
     const i64 *__restrict__ seg, i64 n_segs, i64 first_group, i64 group_stride, double *lds,
-    Emit emit, double mean_len)
+    double *out, F f, Pre pre, Emit emit, double mean_len)
 {
+    constexpr int NP = (SEGW_CAP + 127) / 128;
     const int lane = threadIdx.x & 63;
     // segments per wave step: 64, or fewer (a power of two) when the segments are long, so that
     // a step's samples still fit the slice (RNA: 15-sample events, 43-sample bases); the lanes
@@ -849,27 +867,80 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
     // picks the group size; reading it off seg[] would be two more dependent loads per workgroup)
     int gs = 64;
     while (gs > 4 && (double)gs * mean_len * 1.3 > (double)SEGW_CAP) gs >>= 1;
-    for (i64 g = first_group; g * gs < n_segs; g += group_stride) {
-        const i64 i = g * gs + lane;
+    i64 g = first_group;
+    if (g * gs >= n_segs) return;
+    // the boundaries of a group as loaded (one coalesced load + the group's last one, one address for
+    // the whole wavefront), resolved -- neighbour by shuffle -- only when the group comes up
+    struct Raw { i64 a, hi; };
+    auto load_raw = [&](i64 gg) {
+        const i64 i = gg * gs + lane;
         const bool ok = lane < gs && i < n_segs;
-        const i64 i_end = g * gs + gs < n_segs ? g * gs + gs : n_segs;
-        // one coalesced load of the group's boundaries, the neighbour's by DPP, the last one by lane 0
-        const i64 a = seg[ok ? i : i_end];
-        const i64 hi = seg[i_end];                      // (one address for the whole wavefront)
-        const i64 an = shfl_i64(a, lane + 1 < 64 ? lane + 1 : 63);
-        const i64 b = ok ? (i + 1 < i_end && lane + 1 < 64 ? an : hi) : a;
-        const i64 lo = shfl_i64(a, 0);
-        const i64 span = hi - lo;
+        const i64 i_end = gg * gs + gs < n_segs ? gg * gs + gs : n_segs;
+        return Raw{seg[ok ? i : i_end], seg[i_end]};
+    };
+    struct Grp { i64 a, b, lo, span; bool ok; };
+    auto resolve = [&](i64 gg, Raw w) {
+        const i64 i = gg * gs + lane;
+        const bool ok = lane < gs && i < n_segs;
+        const i64 i_end = gg * gs + gs < n_segs ? gg * gs + gs : n_segs;
+        const i64 an = shfl_i64(w.a, lane + 1 < 64 ? lane + 1 : 63);
+        const i64 b = ok ? (i + 1 < i_end && lane + 1 < 64 ? an : w.hi) : w.a;
+        const i64 lo = shfl_i64(w.a, 0);
+        return Grp{w.a, b, lo, w.hi - lo, ok};
+    };
+    double ra[NP], rb[NP];
+    Grp cur = resolve(g, load_raw(g));
+    auto pre_cur = pre(g * gs + lane < n_segs ? g * gs + lane : n_segs - 1);
+    int spn = __builtin_amdgcn_readfirstlane((int)(cur.span <= SEGW_CAP ? cur.span : 0));
+    bool staged = cur.span <= SEGW_CAP;
+    if (staged) wave_stage_load<NP>(x, cur.lo, spn, ra, rb);
+    i64 gn = g + group_stride;
+    bool has_next = gn * gs < n_segs;
+    Raw nraw = has_next ? load_raw(gn) : Raw{0, 0};
+    auto pre_nxt = pre(has_next && gn * gs + lane < n_segs ? gn * gs + lane : n_segs - 1);
+    for (;;) {
         double s = 0;
-        if (span <= SEGW_CAP) {
+        if (staged) {
             __builtin_amdgcn_wave_barrier(); // the previous group's lanes are done with the slice
-            wave_stage<(SEGW_CAP + 127) / 128>(x, lo, span, lds, nullptr, [](double v) { return v; });
+            wave_stage_store<NP>(ra, rb, cur.lo, spn, lds, out, f);
             __builtin_amdgcn_wave_barrier();
-            s = seq_sum_lds(lds, a - lo, b - lo);
         } else {
-            for (i64 j = a; j < b; j++) s += x[j];
+            for (i64 c0 = cur.lo; c0 < cur.lo + cur.span; c0 += SEGW_CAP) {
+                const i64 left = cur.lo + cur.span - c0, piece = left < SEGW_CAP ? left : SEGW_CAP;
+                __builtin_amdgcn_wave_barrier();
+                const int pc = __builtin_amdgcn_readfirstlane((int)piece);
+                wave_stage_load<NP>(x, c0, pc, ra, rb);   // (ra / rb are free: the next group is not on its way yet)
+                wave_stage_store<NP>(ra, rb, c0, pc, lds, out, f);
+                __builtin_amdgcn_wave_barrier();
+                const i64 j0 = (cur.a > c0 ? cur.a : c0) - c0, j1 = (cur.b < c0 + piece ? cur.b : c0 + piece) - c0;
+                if (j1 > j0) s = seq_sum_lds(lds, j0, j1, s);
+            }
         }
-        if (ok) emit(i, s, b - a);
+        // the next group's samples, the boundaries of the one after
+        Grp nxt = cur;
+        bool nstaged = false;
+        int nspn = 0;
+        if (has_next) {
+            nxt = resolve(gn, nraw);
+            nstaged = nxt.span <= SEGW_CAP;
+            nspn = __builtin_amdgcn_readfirstlane((int)(nstaged ? nxt.span : 0));
+        }
+        const Grp now = cur;
+        const bool was_staged = staged;
+        const auto pre_now = pre_cur;
+        const i64 g_now = g;
+        if (has_next && nstaged) wave_stage_load<NP>(x, nxt.lo, nspn, ra, rb);
+        const i64 gnn = gn + group_stride;
+        const bool has_nn = has_next && gnn * gs < n_segs;
+        pre_cur = pre_nxt;
+        if (has_nn) {
+            nraw = load_raw(gnn);
+            pre_nxt = pre(gnn * gs + lane < n_segs ? gnn * gs + lane : n_segs - 1);
+        }
+        if (was_staged) s = seq_sum_lds(lds, now.a - now.lo, now.b - now.lo);
+        if (now.ok) emit(g_now * gs + lane, s, now.b - now.a, pre_now);
+        if (!has_next) break;
+        cur = nxt; staged = nstaged; spn = nspn; g = gn; gn = gnn; has_next = has_nn;
     }
 }
 

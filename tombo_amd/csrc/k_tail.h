@@ -1062,41 +1062,21 @@ __global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const
     const double ca = r.ts[2], cb = r.ts[3];
     constexpr int CAP = 768;
     __shared__ double s_seg[4 * CAP];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *lds = s_seg + wave * CAP;
+    const int wave = threadIdx.x >> 6;
     const i64 n_segs = r.B;
-    int gs = 64; // bases per wave step (fewer when they are long, see wave_segment_sums)
-    if (n_segs > 0) {
-        const double mean_len = (double)(sg[n_segs] - sg[0]) / (double)n_segs;
-        while (gs > 4 && (double)gs * mean_len * 1.3 > (double)CAP) gs >>= 1;
-    }
-    for (i64 g = (i64)blockIdx.x * 4 + wave; g * gs < n_segs; g += (i64)gridDim.x * 4) {
-        const i64 i = g * gs + lane;
-        const bool ok = lane < gs && i < n_segs;
-        const i64 i_end = g * gs + gs < n_segs ? g * gs + gs : n_segs;
-        const i64 a = sg[ok ? i : i_end], b = sg[ok ? i + 1 : i_end];
-        const i64 lo = sg[g * gs], hi = sg[i_end];
-        const i64 span = hi - lo;
-        double s = 0;
-        if (span <= CAP) {
-            __builtin_amdgcn_wave_barrier();
-            wave_stage<CAP / 128>(x, lo, span, lds, WRITE ? y : nullptr, [&](double xv) {
-                return skip ? xv : (xv - ca) / cb; // resquiggle.py:1190
-            });
-            __builtin_amdgcn_wave_barrier();
-            s = seq_sum_lds(lds, a - lo, b - lo);
-        } else {
-            for (i64 j = a; j < b; j++) {
-                const double v = skip ? x[j] : (x[j] - ca) / cb;
-                if (WRITE) y[j] = v;
-                s += v;
-            }
-        }
-        if (ok) {
-            const double m = s / (double)(b - a);
-            absz[r.ref_off + i] = fabs((m - ref_means[r.ref_off + i]) / ref_sds[r.ref_off + i]);
-        }
-    }
+    if (n_segs <= 0) return;
+    const double *rm = ref_means + r.ref_off, *rsd = ref_sds + r.ref_off;
+    double *az = absz + r.ref_off;
+    struct Ref { double m, sd; };
+    wave_segment_sums<CAP>(x, sg, n_segs, (i64)blockIdx.x * 4 + wave, (i64)gridDim.x * 4, s_seg + wave * CAP,
+        WRITE ? y : nullptr,
+        [&](double xv) { return skip ? xv : (xv - ca) / cb; },   // resquiggle.py:1190
+        [&](i64 i) { return Ref{rm[i], rsd[i]}; },
+        [&](i64 i, double s, i64 len, Ref ref) {
+            const double m = s / (double)len;
+            az[i] = fabs((m - ref.m) / ref.sd);
+        },
+        (double)(sg[n_segs] - sg[0]) / (double)n_segs);
 }
 
 // ts.get_read_seg_score (tombo_stats.py:2327-2338): np.mean in numpy's summation order
