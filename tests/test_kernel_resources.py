@@ -21,8 +21,8 @@ BUDGET = {
     '_Z7k_peaksILi2EE': (80, False),          # 3 workgroups per CU
     '_Z7k_peaksILi5EE': (128, False),
     '_Z11k_theil_sen': (80, False),           # 3 workgroups per CU (LDS allows no more)
-    '_Z14k_rescale_abszILb1EE': (128, False),
-    '_Z13k_event_meansIdLi448E': (128, False),    # DNA: 8 wavefronts per SIMD
+    '_Z14k_rescale_abszILb1EE': (96, False),        # 5 wavefronts per SIMD (LDS allows 6)
+    '_Z13k_event_meansIdLi448E': (72, False),     # DNA: 7 wavefronts per SIMD
     '_Z13k_event_meansIdLi1280E': (128, False),   # RNA: 4 workgroups per CU (LDS), 4 per SIMD
     '_Z9k_main_tb': (256, False),
     '_Z10k_start_tb': (512, True),           # (np_sum's recursion stack lives in scratch: 250 values per read)

@@ -825,9 +825,9 @@ __device__ bool block_int_medians(XS x, i64 n, int vmin_s, int vmax_s, BucketSme
 // sum of p[j0 .. j1) in index order (c_new_means adds sample by sample), the LDS loads issued eight
 // at a time: the adds are the only dependent chain (a plain loop waits one LDS round trip per
 // sample, which is what bounded the RNA segment kernels: 15-sample events, 43-sample bases)
-__device__ __forceinline__ double seq_sum_lds(const double *p, i64 j0, i64 j1, double s = 0)
+__device__ __forceinline__ double seq_sum_lds(const double *p, int j0, int j1, double s = 0)
 {
-    i64 j = j0;
+    int j = j0;
     for (; j + 8 <= j1; j += 8) {
         double t[8];
 #pragma unroll
@@ -878,22 +878,28 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
         const i64 i_end = gg * gs + gs < n_segs ? gg * gs + gs : n_segs;
         return Raw{seg[ok ? i : i_end], seg[i_end]};
     };
-    struct Grp { i64 a, b, lo, span; bool ok; };
+    // a group resolved: lo / span are the same for the whole wavefront (scalar registers), a lane's own
+    // segment is [ja, jb) relative to lo
+    struct Grp { i64 lo; int span, ja, jb; bool ok; };
+    auto rfl64 = [](i64 v) {
+        const u32 l = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffff)), h = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+        return (i64)(((u64)h << 32) | l);
+    };
     auto resolve = [&](i64 gg, Raw w) {
         const i64 i = gg * gs + lane;
         const bool ok = lane < gs && i < n_segs;
         const i64 i_end = gg * gs + gs < n_segs ? gg * gs + gs : n_segs;
-        const i64 an = shfl_i64(w.a, lane + 1 < 64 ? lane + 1 : 63);
-        const i64 b = ok ? (i + 1 < i_end && lane + 1 < 64 ? an : w.hi) : w.a;
-        const i64 lo = shfl_i64(w.a, 0);
-        return Grp{w.a, b, lo, w.hi - lo, ok};
+        const i64 lo = rfl64(w.a), hi = rfl64(w.hi);       // (lane 0 is always inside the group)
+        const int ja = (int)(w.a - lo), hj = (int)(hi - lo);
+        const int jn = __shfl(ja, lane + 1 < 64 ? lane + 1 : 63, 64);
+        const int jb = ok ? (i + 1 < i_end && lane + 1 < 64 ? jn : hj) : ja;
+        return Grp{lo, hj, ja, jb, ok};
     };
     double ra[NP], rb[NP];
     Grp cur = resolve(g, load_raw(g));
     auto pre_cur = pre(g * gs + lane < n_segs ? g * gs + lane : n_segs - 1);
-    int spn = __builtin_amdgcn_readfirstlane((int)(cur.span <= SEGW_CAP ? cur.span : 0));
     bool staged = cur.span <= SEGW_CAP;
-    if (staged) wave_stage_load<NP>(x, cur.lo, spn, ra, rb);
+    if (staged) wave_stage_load<NP>(x, cur.lo, cur.span, ra, rb);
     i64 gn = g + group_stride;
     bool has_next = gn * gs < n_segs;
     Raw nraw = has_next ? load_raw(gn) : Raw{0, 0};
@@ -902,34 +908,29 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
         double s = 0;
         if (staged) {
             __builtin_amdgcn_wave_barrier(); // the previous group's lanes are done with the slice
-            wave_stage_store<NP>(ra, rb, cur.lo, spn, lds, out, f);
+            wave_stage_store<NP>(ra, rb, cur.lo, cur.span, lds, out, f);
             __builtin_amdgcn_wave_barrier();
         } else {
-            for (i64 c0 = cur.lo; c0 < cur.lo + cur.span; c0 += SEGW_CAP) {
-                const i64 left = cur.lo + cur.span - c0, piece = left < SEGW_CAP ? left : SEGW_CAP;
+            for (int c0 = 0; c0 < cur.span; c0 += SEGW_CAP) {
+                const int left = cur.span - c0, piece = left < SEGW_CAP ? left : SEGW_CAP;
                 __builtin_amdgcn_wave_barrier();
-                const int pc = __builtin_amdgcn_readfirstlane((int)piece);
-                wave_stage_load<NP>(x, c0, pc, ra, rb);   // (ra / rb are free: the next group is not on its way yet)
-                wave_stage_store<NP>(ra, rb, c0, pc, lds, out, f);
+                wave_stage_load<NP>(x, cur.lo + c0, piece, ra, rb);   // (ra / rb are free: the next group is not on its way yet)
+                wave_stage_store<NP>(ra, rb, cur.lo + c0, piece, lds, out, f);
                 __builtin_amdgcn_wave_barrier();
-                const i64 j0 = (cur.a > c0 ? cur.a : c0) - c0, j1 = (cur.b < c0 + piece ? cur.b : c0 + piece) - c0;
+                const int j0 = (cur.ja > c0 ? cur.ja : c0) - c0, j1 = (cur.jb < c0 + piece ? cur.jb : c0 + piece) - c0;
                 if (j1 > j0) s = seq_sum_lds(lds, j0, j1, s);
             }
         }
         // the next group's samples, the boundaries of the one after
-        Grp nxt = cur;
-        bool nstaged = false;
-        int nspn = 0;
-        if (has_next) {
-            nxt = resolve(gn, nraw);
-            nstaged = nxt.span <= SEGW_CAP;
-            nspn = __builtin_amdgcn_readfirstlane((int)(nstaged ? nxt.span : 0));
-        }
         const Grp now = cur;
         const bool was_staged = staged;
         const auto pre_now = pre_cur;
         const i64 g_now = g;
-        if (has_next && nstaged) wave_stage_load<NP>(x, nxt.lo, nspn, ra, rb);
+        if (has_next) {
+            cur = resolve(gn, nraw);
+            staged = cur.span <= SEGW_CAP;
+            if (staged) wave_stage_load<NP>(x, cur.lo, cur.span, ra, rb);
+        }
         const i64 gnn = gn + group_stride;
         const bool has_nn = has_next && gnn * gs < n_segs;
         pre_cur = pre_nxt;
@@ -937,10 +938,10 @@ __device__ __forceinline__ void wave_segment_sums(Sig x,
             nraw = load_raw(gnn);
             pre_nxt = pre(gnn * gs + lane < n_segs ? gnn * gs + lane : n_segs - 1);
         }
-        if (was_staged) s = seq_sum_lds(lds, now.a - now.lo, now.b - now.lo);
-        if (now.ok) emit(g_now * gs + lane, s, now.b - now.a, pre_now);
+        if (was_staged) s = seq_sum_lds(lds, now.ja, now.jb);
+        if (now.ok) emit(g_now * gs + lane, s, (i64)(now.jb - now.ja), pre_now);
         if (!has_next) break;
-        cur = nxt; staged = nstaged; spn = nspn; g = gn; gn = gnn; has_next = has_nn;
+        g = gn; gn = gnn; has_next = has_nn;
     }
 }
 

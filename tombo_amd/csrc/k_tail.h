@@ -1048,8 +1048,11 @@ __global__ __launch_bounds__(256) void k_base_stats(const ReadState *rs, const D
 // keeps them in its LDS slice and sums every base from there.  The bases tile the trimmed
 // signal exactly (segs[0] = 0, segs[B] = norm_len), so every sample is written once.
 // grid: (blocks, reads)
+#ifndef TBA_RSZ_WAVES
+#define TBA_RSZ_WAVES 5
+#endif
 template <bool WRITE> // WRITE = false: skip_norm_out batch, the final signal is not materialised
-__global__ __launch_bounds__(256) void k_rescale_absz(const ReadState *rs, const DevParams *dp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBA_RSZ_WAVES))) void k_rescale_absz(const ReadState *rs, const DevParams *dp,
     const double *norm, double *norm_out, const i64 *segs, const double *ref_means,
     const double *ref_sds, double *absz)
 {
