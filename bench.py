@@ -608,6 +608,8 @@ def main():
                          'cfg2, 3 slots 92.3 k -- the event-detection kernel fills a CU alone now; RNA 125 k vs 112 k)')
     ap.add_argument('--serial-compute', action='store_true',
                     help='streaming: kernel sequences of the slots back to back (tba_batch_wait_for) instead of interleaved')
+    ap.add_argument('--no-interleaved', action='store_true',
+                    help='skip the second resident figure (two batches alternating on two engines)')
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
                          'engine / stream (kernels of different sub-batches overlap)')
@@ -838,6 +840,36 @@ def main():
         print('dbg mean', ' '.join('%.1f' % x for x in d.mean(axis=0)), file=sys.stderr)
         print('dbg median', ' '.join(str(int(x)) for x in np.median(d, axis=0)), file=sys.stderr)
     stage /= max(my_steps, 1)
+    # a second figure, not `value`: TWO resident batches (the same reads uploaded twice) whose passes
+    # alternate on two engines / streams, the next pass enqueued before the previous one is waited
+    # for -- the memory-bound stages of one batch run beside the tail of the other's forward pass
+    two_batches = None
+    if world == 1 and len(plan) == 1 and not a.no_interleaved and stub is None:
+        eng2 = _native.Engine(dev)
+        eng2.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+        eng2.upload(p, o, [raws[i] for i in plan[0]], [codes[i] for i in plan[0]],
+                    samp_ind=None if si is None else si[plan[0]])
+        pair = [engines[0], eng2]
+
+        def alternate(k):
+            pair[0].enqueue()
+            for j in range(1, k):
+                pair[j % 2].enqueue()
+                pair[(j - 1) % 2].sync()
+            pair[(k - 1) % 2].sync()
+
+        alternate(max(2, a.warmup))
+        dev_sync()
+        t1 = time.perf_counter()
+        alternate(a.steps)
+        dev_sync()
+        dt2 = time.perf_counter() - t1
+        ok2 = int((eng2.download(want_norm=False)['status'] == 0).sum())
+        two_batches = {'reads_per_s': round(a.reads * a.steps / dt2, 2), 'ms_per_step': round(dt2 / a.steps * 1e3, 3),
+                       'steps': a.steps, 'ok_second_batch': ok2,
+                       'note': 'two resident batches, passes alternating on two engines (streams), at most two in flight'}
+        eng2.close()
+        del eng2, pair
     for eng in engines:
         eng.close()
     del engines, probe
@@ -1111,6 +1143,7 @@ def main():
                        'mean_bases': round(tot_bases / a.reads, 1), 'max_bases': int(bases.max()),
                        'bandwidth': a.bandwidth,
                        'resident_batches_per_gpu': len(plan),
+                       'two_resident_batches_alternating': two_batches,
                        'bases_per_s': round(tot_bases * steps_done / dt, 1),
                        'success_rate': round(n_ok / float(a.reads), 4),
                        'parallelism': 'reads sharded over %d process(es) through a shared batch '

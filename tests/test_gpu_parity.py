@@ -368,6 +368,40 @@ def test_rna_batch_on_gpu(dispatch_form):
     assert sum(o['status'] == 0 for o in oracles) >= 6
 
 
+@pytest.mark.parametrize('samp_name', ['DNA', 'RNA'])
+def test_long_dwell_stretches_vs_oracle_on_gpu(samp_name, dispatch_form):
+    """segment sums (wave_segment_sums, k_select.h): a group of segments that spans more samples than
+    a wavefront's LDS slice is staged piece by piece, every lane carrying its running sum across the
+    pieces -- flat stretches of 600-4000 samples (nothing masks them: no stall intervals are passed)
+    put single events and single bases past every slice size (448 / 768 / 1 280 samples)"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th
+    samp = th.seqSampleType(samp_name, False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    kw = synth.RNA_SYNTH if samp_name == 'RNA' else synth.DNA_SYNTH
+    rng = np.random.default_rng(77)
+    reads = []
+    for seed, nb in enumerate((1200, 2500, 700, 1800, 3000, 1500)):
+        seq, raw, starts = synth.synth_read(model, nb, 99000 + seed, **kw)
+        parts, at = [], 0
+        for k in sorted(rng.choice(np.arange(20, nb - 20), 4 if samp_name == 'RNA' else 2, replace=False)):
+            cut = int(starts[k])
+            n_flat = int(rng.integers(600, 4000))
+            parts += [raw[at:cut], raw[cut] + rng.normal(0.0, 0.02 * kw['scale'], n_flat)]
+            at = cut
+        raw = np.concatenate(parts + [raw[at:]])
+        reads.append((raw, seq, None, _si(nb, seed)))
+    eng, out, oracles = run_batch(model, params, samp_name, reads)
+    bad = compare_batch(eng, oracles, out, 'dwell')
+    assert not bad, '\n'.join(bad[:40])
+    check_forms(eng, dispatch_form, params)
+    ok = [i for i, o in enumerate(oracles) if o['status'] == 0]
+    assert len(ok) >= 4, [o['status'] for o in oracles]
+    # the case is what it claims: resolved bases longer than the widest slice
+    longest = max(int(np.diff(oracles[i]['segs']).max()) for i in ok)
+    assert longest > 1280, longest
+
+
 def test_long_read_kernels_vs_oracle_on_gpu(dispatch_form):
     """k_long.h: reads past TBA_LONG_RAW samples / TBA_LONG_BASES bases get a workgroup-per-read
     cumulative sum and a wavefront-per-read traceback -- 60 kb and 29 kb reads (long by both / by
