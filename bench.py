@@ -608,8 +608,10 @@ def main():
                          'cfg2, 3 slots 92.3 k -- the event-detection kernel fills a CU alone now; RNA 125 k vs 112 k)')
     ap.add_argument('--serial-compute', action='store_true',
                     help='streaming: kernel sequences of the slots back to back (tba_batch_wait_for) instead of interleaved')
-    ap.add_argument('--no-interleaved', action='store_true',
-                    help='skip the second resident figure (two batches alternating on two engines)')
+    ap.add_argument('--interleaved', action='store_true',
+                    help='a second resident figure after the timed region (config.two_resident_batches_alternating): '
+                         'two batches alternating on two engines; off by default -- a profile of the default '
+                         'command then holds the launches of the timed passes only')
     ap.add_argument('--resident-split', type=int, default=1,
                     help='resident phase: cut the batch into this many sub-batches, each on its own '
                          'engine / stream (kernels of different sub-batches overlap)')
@@ -844,7 +846,7 @@ def main():
     # alternate on two engines / streams, the next pass enqueued before the previous one is waited
     # for -- the memory-bound stages of one batch run beside the tail of the other's forward pass
     two_batches = None
-    if world == 1 and len(plan) == 1 and not a.no_interleaved and stub is None:
+    if world == 1 and len(plan) == 1 and a.interleaved and stub is None:
         eng2 = _native.Engine(dev)
         eng2.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
         eng2.upload(p, o, [raws[i] for i in plan[0]], [codes[i] for i in plan[0]],

@@ -160,6 +160,16 @@ int  tba_engine_set_dp_workgroup_batch(tba_engine *e, int64_t max_reads);
  * TBA_GET_ED_FORM / TBA_GET_TB_FORM report which kernels actually produced each read's result. */
 int  tba_engine_set_dispatch(tba_engine *e, int64_t small_batch_reads, int64_t tb_wave_below);
 int  tba_engine_get_dispatch(tba_engine *e, int64_t *small_batch_reads, int64_t *tb_wave_below);
+/* The side stream.  A full run (tba_batch_enqueue / tba_batch_run) puts what does not depend on the
+ * signal's normalisation -- the stall detector (ts.identify_stalls, RNA) and the expected levels of the
+ * sequences (get_exp_levels_from_seq) -- on a second stream of the engine, beside normalisation and
+ * event detection, and joins it where the reference's order needs the results; identical results (an
+ * invalid base still loses to an earlier segmentation error of the same read).  mode -1 (default):
+ * used while at most two engines are alive on the device in this process (TBA_SIDE_STREAM_MAX_ENGINES)
+ * and tba_engine_set_sharing says no more -- more streams than hardware queues serialise behind each
+ * other; 0: never; 1: always.  tba_engine_last_side_stream: whether the last full run used it. */
+int  tba_engine_set_side_stream(tba_engine *e, int mode);
+int  tba_engine_last_side_stream(tba_engine *e);
 /* TBA_ED_FORM_* of the last tba_c_valid_cpts_w_cap / tba_c_valid_cpts_w_cap_t_test call on this engine
  * (those entries follow the engine's dispatch like a batch of one read) */
 int  tba_c_last_ed_form(tba_engine *e);

@@ -566,6 +566,58 @@ def test_degenerate_inputs_on_gpu(dispatch_form):
     assert not isinstance(res[4], Exception) and res[4].segs.shape[0] == 501
 
 
+@pytest.mark.parametrize('samp_name', ['DNA', 'RNA'])
+def test_side_stream_on_and_off_agree_on_gpu(samp_name):
+    """tba_engine_set_side_stream: stall detection and expected levels beside normalisation / event
+    detection on the engine's second stream, or everything in order on one -- the same bytes and the same
+    statuses; a read with an invalid base AND too little signal for its sequence fails with the earlier
+    (segmentation) error in both, as in the reference's order of calls (resquiggle.py:1160 before
+    tombo_stats.py:858)"""
+    from tombo_amd import synth, tombo_stats as ts, tombo_helper as th, _native as N
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    samp = th.seqSampleType(samp_name, False)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)
+    kw = synth.RNA_SYNTH if samp_name == 'RNA' else synth.DNA_SYNTH
+    reads = []
+    for seed, nb in enumerate((900, 1500, 400, 1200, 700, 1000)):
+        seq, raw, _ = synth.synth_read(model, nb, 61000 + seed, **kw)
+        if seed == 1:
+            seq = seq[:300] + 'N' + seq[301:]                 # invalid base
+        if seed == 2:
+            seq, raw = seq[:100] + 'N' + seq[101:], raw[:raw.shape[0] // 30]   # ... and far too little signal
+        if seed == 3 and samp_name == 'RNA':
+            raw = np.concatenate([raw[:20000], np.full(1200, raw[20000]) +
+                                  np.random.default_rng(3).normal(0, 3.0, 1200), raw[20000:]])
+        reads.append((raw, seq))
+    stall_kw = {}
+    if samp_name == 'RNA':
+        from tombo_amd._default_parameters import MEAN_STALL_PARAMS
+        stall_kw = dict(stall_params=th.stallParams(**MEAN_STALL_PARAMS))
+    eng = N.Engine(0)
+    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+    p = N.make_params(params)
+    o = N.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name], subsample_seed=5, **stall_kw)
+    outs = []
+    for mode in (0, 1):
+        eng.set_side_stream(mode)
+        eng.upload(p, o, [r[0] for r in reads], [ts.encode_seq(r[1]) for r in reads])
+        eng.run()
+        assert eng.last_side_stream() == bool(mode)
+        out = eng.download()
+        outs.append({k: np.array(v, copy=True) for k, v in out.items() if isinstance(v, np.ndarray)})
+    eng.set_side_stream(-1)
+    a, b = outs
+    assert a['status'].tolist() == b['status'].tolist()
+    st = a['status'].tolist()
+    assert st[1] == 22, st                                    # TBA_INVALID_SEQ
+    assert st[2] not in (0, 22), st                           # the earlier error wins
+    assert sum(x == 0 for x in st) >= 3, st
+    for k in a:
+        assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+    eng.close()
+
+
 def test_degenerate_scale_vs_oracle_on_gpu(dispatch_form):
     """Scale values the throughput form's loader cannot take through its reciprocal division: a MAD of
     exactly 0 (flat or saturated signal: the reference divides by it under np.seterr(all='raise') and

@@ -471,6 +471,14 @@ class Engine(object):
         self._check(self._L.tba_engine_set_dispatch(self._h, i64(int(small_batch_reads)), i64(int(tb_wave_below))),
                     'tba_engine_set_dispatch')
 
+    def set_side_stream(self, mode=-1):
+        """stall detection and expected levels beside normalisation / event detection on a second stream
+        (tba_engine_set_side_stream): -1 while at most two engines are alive on the device, 0 never, 1 always"""
+        self._check(self._L.tba_engine_set_side_stream(self._h, int(mode)), 'tba_engine_set_side_stream')
+
+    def last_side_stream(self):
+        return bool(self._L.tba_engine_last_side_stream(self._h))
+
     def get_dispatch(self):
         a, b = i64(0), i64(0)
         self._check(self._L.tba_engine_get_dispatch(self._h, C.byref(a), C.byref(b)), 'tba_engine_get_dispatch')

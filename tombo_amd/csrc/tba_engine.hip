@@ -1,6 +1,7 @@
 // tba_engine.hip -- batch engine + C ABI (include/tombo_amd.h) of the gfx950 resquiggle path.
 // One engine == one GPU == one HIP stream; a batch is a fixed sequence of kernels over ragged
 // SoA buffers that stay resident in HBM between upload and download.
+#include <atomic>
 #include "tba_common.h"
 #include "k_select.h"
 #include "k_segment.h"
@@ -114,6 +115,8 @@ struct tba_engine {
     std::vector<i64> ne_override; // per-read num_events for the next upload (stepwise API)
     double algo_bytes = 0, dp_cells = 0;
     int n_sharing = 1;            // engines fed concurrently on this device (tba_engine_set_sharing)
+    int side_mode = -1;           // tba_engine_set_side_stream: -1 by the engines alive, 0 never, 1 always
+    bool last_side = false;       // the last full run used the side stream
     i64 dp_wg_batch = TBA_WG_BATCH; // batches up to this many reads: main forward pass by workgroup (k_dp_wgm.h)
     // latency / throughput forms of event detection and traceback (tba_engine_set_dispatch)
     i64 small_batch = TBA_SMALL_BATCH, tb_wave_below = TBP_WAVE_BELOW;
@@ -155,6 +158,18 @@ extern "C" int tba_device_count(void)
     return n;
 }
 
+// engines alive per device in this process: the side stream (enqueue_stages) is only used while the
+// process's streams fit the device's hardware queues (four by default) -- beyond that streams share
+// a queue, and a side stream queued behind ANOTHER engine's half-second forward pass holds its own
+// engine's main stream at the join (measured: eight resident long-tail batches 37.8 k -> 31.4 k reads/s)
+#define TBA_MAX_DEVICES 64
+static std::atomic<int> g_live_engines[TBA_MAX_DEVICES];
+static int side_stream_max_engines()
+{
+    static const int v = [] { const char *x = getenv("TBA_SIDE_STREAM_MAX_ENGINES"); return x ? atoi(x) : 2; }();
+    return v;
+}
+
 extern "C" int tba_engine_create(int device, tba_engine **out)
 {
     if (!out) return set_err(TBA_E_ARG, "out is NULL");
@@ -175,7 +190,7 @@ extern "C" int tba_engine_create(int device, tba_engine **out)
     if (const char *v = getenv("TBA_SMALL_BATCH_READS")) e->small_batch = std::max<i64>(atoll(v), 0);
     if (const char *v = getenv("TBA_TB_WAVE_BELOW")) e->tb_wave_below = std::max<i64>(atoll(v), 0);
     HIP_TRY(hipStreamCreate(&e->stream));
-    HIP_TRY(hipStreamCreate(&e->stream2));
+    if (device < TBA_MAX_DEVICES) g_live_engines[device]++;
     for (hipEvent_t *x : {&e->ev_fork, &e->ev_stalls, &e->ev_levels, &e->ev_st0, &e->ev_st1}) HIP_TRY(hipEventCreate(x));
     for (int i = 0; i <= N_STAGE; i++) HIP_TRY(hipEventCreate(&e->ev[i]));
     *out = e;
@@ -193,6 +208,7 @@ extern "C" void tba_engine_destroy(tba_engine *e)
     for (hipEvent_t x : {e->ev_fork, e->ev_stalls, e->ev_levels, e->ev_st0, e->ev_st1}) if (x) (void)hipEventDestroy(x);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->device < TBA_MAX_DEVICES) g_live_engines[e->device]--;
     delete e;
 }
 
@@ -639,9 +655,14 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     // the main stream, in this order); a partial run (stepwise API) stays on one stream.
 #ifdef TBA_NO_SIDE_STREAM
     const bool side = false;
+    e->last_side = false;
 #else
     static const bool side_off = getenv("TBA_NO_SIDE_STREAM") != nullptr;
-    const bool side = !side_off && first == TBA_STAGE_SEGMENT && last == TBA_STAGE_RESCALE;
+    const bool side = !side_off && first == TBA_STAGE_SEGMENT && last == TBA_STAGE_RESCALE && e->side_mode != 0 &&
+                      (e->side_mode == 1 || (e->device < TBA_MAX_DEVICES &&
+                       std::max(e->n_sharing, g_live_engines[e->device].load()) <= side_stream_max_engines()));
+    e->last_side = side;
+    if (side && !e->stream2) HIP_TRY(hipStreamCreate(&e->stream2)); // (created on first use: a stream takes a queue slot)
 #endif
     hipStream_t s2 = side ? e->stream2 : s;
     if (side) {
@@ -2170,6 +2191,17 @@ extern "C" int tba_engine_get_dispatch(tba_engine *e, int64_t *small_batch_reads
     if (small_batch_reads) *small_batch_reads = e->small_batch;
     if (tb_wave_below) *tb_wave_below = e->tb_wave_below;
     return 0;
+}
+
+extern "C" int tba_engine_set_side_stream(tba_engine *e, int mode)
+{
+    if (!e || mode < -1 || mode > 1) return set_err(TBA_E_ARG, "bad arguments");
+    e->side_mode = mode;
+    return 0;
+}
+extern "C" int tba_engine_last_side_stream(tba_engine *e)
+{
+    return e ? (e->last_side ? 1 : 0) : 0;
 }
 
 extern "C" int tba_engine_set_sharing(tba_engine *e, int n_engines)

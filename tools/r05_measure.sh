@@ -4,7 +4,7 @@ O=$R/gpurun_out/r05
 mkdir -p $O
 cd $R
 for cfg in cfg2 cfg3 cfg1 cfg4; do
-  python bench.py --preset $cfg --steps 20 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+  python bench.py --preset $cfg --steps 20 --interleaved > $O/bench_$cfg.json 2> $O/bench_$cfg.err
 done
 python bench.py --preset longtail --steps 4 --no-pmc --api-reads 0 > $O/bench_longtail.json 2> $O/bench_longtail.err
 [ "$1" = "quick" ] && exit 0
