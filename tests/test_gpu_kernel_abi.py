@@ -41,6 +41,45 @@ def test_elementwise_kernels(read):
         ch.c_new_means(sig.astype(np.float32), d['valid_cpts'])
 
 
+def test_segment_means_on_awkward_layouts():
+    """c_new_means through the batch pipeline's own kernel (k_event_means -> wave_segment_sums, k_select.h):
+    groups of 64 / 32 / ... / 4 segments per wavefront step, spans beyond the LDS slice staged piece by
+    piece with running sums carried across the pieces, the software-pipelined group loop with one, two
+    and many groups per wavefront, a first boundary past 0, odd offsets (16-byte loads that start on an
+    8-byte boundary), single-sample and zero-length segments (0 / 0 = NaN, as the reference's division)"""
+    import oracle
+    from tombo_amd import _c_helper as ch
+    rng = np.random.default_rng(20260927)
+
+    def check(lengths, start=0, label=''):
+        lengths = np.asarray(lengths, np.int64)
+        segs = start + np.concatenate([[0], np.cumsum(lengths)])
+        sig = rng.normal(0.0, 1.0, int(segs[-1]) + int(rng.integers(0, 5)))
+        sig *= np.exp(rng.normal(0.0, 3.0, sig.shape[0]))          # (magnitudes apart: the order of the adds shows)
+        got, want = ch.c_new_means(sig, segs), oracle.new_means(sig, segs)
+        assert got.shape == want.shape, label
+        with np.errstate(invalid='ignore'):
+            assert np.array_equal(got, want, equal_nan=True), (label, np.flatnonzero(~((got == want) | (np.isnan(got) & np.isnan(want))))[:8])
+
+    for n in (1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4099):
+        check(rng.integers(1, 12, n), start=int(rng.integers(0, 3)), label='short x %d' % n)
+        check(rng.integers(5, 90, n), start=int(rng.integers(0, 3)), label='rna-like x %d' % n)
+    # the widths around every slice size, alone and between short neighbours
+    for w in (447, 448, 449, 767, 768, 769, 1279, 1280, 1281, 2559, 2561, 5000, 20001):
+        check([w], label='one segment of %d' % w)
+        check(np.concatenate([rng.integers(1, 9, 70), [w], rng.integers(1, 9, 70), [w, w], rng.integers(1, 9, 5)]),
+              start=1, label='%d between short ones' % w)
+    # heavy-tailed lengths: most groups fit, some spill
+    for k in range(6):
+        ln = np.maximum(1, (rng.pareto(1.3, 3000) * 6).astype(np.int64))
+        check(ln, start=k, label='pareto %d' % k)
+    # single samples only; zero-length segments among others
+    check(np.ones(777, np.int64), label='ones')
+    ln = rng.integers(0, 4, 500)
+    ln[0] = 3
+    check(ln, label='zero lengths')
+
+
 def test_change_point_kernels(read):
     import oracle
     from tombo_amd import _c_helper as ch

@@ -16,15 +16,7 @@ __global__ void k_c_base_z_scores(const double *sig, i64 n, double mean, double 
     }
 }
 
-// c_new_means, _c_helper.pyx:59-71
-__global__ void k_c_new_means(const double *sig, const i64 *segs, i64 n_segs, double *means)
-{
-    for (i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x; s < n_segs; s += (i64)gridDim.x * blockDim.x) {
-        double acc = 0;
-        for (i64 j = segs[s]; j < segs[s + 1]; j++) acc += sig[j];
-        means[s] = acc / (double)(segs[s + 1] - segs[s]);
-    }
-}
+// (c_new_means, _c_helper.pyx:59-71: tba_c_new_means runs the batch pipeline's k_event_means, k_segment.h)
 
 // c_apply_outlier_thresh, _c_helper.pyx:73-87
 __global__ void k_c_clip(const double *sig, i64 n, double lo, double hi, double *out)

@@ -1414,12 +1414,28 @@ extern "C" int tba_c_new_means(tba_engine *e, const double *norm_signal, int64_t
         if (new_segs[i] < 0 || new_segs[i] > n_sig || (i > 0 && new_segs[i] < new_segs[i - 1]))
             return set_err(TBA_E_ARG, "segment boundaries outside the signal");
     HIP_TRY(hipSetDevice(e->device));
-    Tmp d_sig, d_segs, d_out;
-    if (d_sig.alloc((size_t)n_sig * 8) || d_segs.alloc((size_t)(n_segs + 1) * 8) || d_out.alloc((size_t)n_segs * 8))
+    // the batch pipeline's own kernel on a one-read batch (k_event_means: wave-cooperative, software-
+    // pipelined segment sums, k_select.h) -- the slice size picked as the batch pipeline picks it,
+    // by the mean segment length (+ 64 bytes: a 16-byte access may touch the element past an odd end)
+    Tmp d_sig, d_segs, d_out, d_rs, d_dp;
+    if (d_sig.alloc((size_t)n_sig * 8 + 64) || d_segs.alloc((size_t)(n_segs + 1) * 8) || d_out.alloc((size_t)n_segs * 8) ||
+        d_rs.alloc(sizeof(ReadState)) || d_dp.alloc(sizeof(DevParams)))
         return set_err(TBA_E_NOMEM, "hipMalloc failed");
+    ReadState r;
+    memset(&r, 0, sizeof(r));
+    r.n_raw = n_sig; r.n_cpts = n_segs + 1; r.status = TBA_OK;
+    DevParams dp;
+    memset(&dp, 0, sizeof(dp));
+    C_TRY(hipMemset(d_sig.p, 0, (size_t)n_sig * 8 + 64));
     C_TRY(hipMemcpy(d_sig.p, norm_signal, (size_t)n_sig * 8, hipMemcpyHostToDevice));
     C_TRY(hipMemcpy(d_segs.p, new_segs, (size_t)(n_segs + 1) * 8, hipMemcpyHostToDevice));
-    k_c_new_means<<<grid_for(n_segs), 256, 0, e->stream>>>(d_sig.as<double>(), d_segs.as<i64>(), n_segs, d_out.as<double>());
+    C_TRY(hipMemcpy(d_rs.p, &r, sizeof(r), hipMemcpyHostToDevice));
+    C_TRY(hipMemcpy(d_dp.p, &dp, sizeof(dp), hipMemcpyHostToDevice));
+    const unsigned g = (unsigned)std::min<i64>(std::max<i64>((n_segs + 255) / 256, 1), 128);
+    if (n_sig >= 10 * n_segs)
+        k_event_means<double, 1280><<<dim3(g, 1), 256, 0, e->stream>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_segs.as<i64>(), d_out.as<double>(), 0);
+    else
+        k_event_means<double><<<dim3(g, 1), 256, 0, e->stream>>>(d_rs.as<ReadState>(), d_dp.as<DevParams>(), d_sig.as<double>(), d_segs.as<i64>(), d_out.as<double>(), 0);
     C_TRY(hipGetLastError());
     C_TRY(hipStreamSynchronize(e->stream));
     C_TRY(hipMemcpy(means, d_out.p, (size_t)n_segs * 8, hipMemcpyDeviceToHost));
