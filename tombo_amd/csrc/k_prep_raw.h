@@ -67,15 +67,25 @@ __global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const
     const double thr = o.stall_threshold;
     const bool staged = ws <= SM_MAXW;
     const int N = SM_T + (int)(staged ? ws : 0) + 1;
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 11
+    // cycles of a workgroup's thread 0 by part, summed over its chunks into the read's dbg[]:
+    // 0 the chunk's sums into LDS (memory wait), 1 moving averages, 2 the metric; 3 chunks
+    i64 sm_acc[3] = {0, 0, 0}, sm_n = 0, sm_t = (i64)__builtin_readcyclecounter();
+#define SM_PH(i_) do { const i64 t_ = (i64)__builtin_readcyclecounter(); sm_acc[i_] += t_ - sm_t; sm_t = t_; } while (0)
+#else
+#define SM_PH(i_) do { } while (0)
+#endif
     for (i64 q0 = (i64)blockIdx.x * SM_T; q0 < (n_words << 6); q0 += (i64)gridDim.x * SM_T) {
         const i64 p0 = q0 - start_offset;
         if (staged) {
             __syncthreads();
+            SM_PH(2);
             for (int i = tid; i < N; i += 256) {
                 const i64 k = p0 + i;
                 C[i] = (k >= 0 && k <= n) ? c[k] : 0.0;
             }
             __syncthreads();
+            SM_PH(0);
             // A window mean is shared by the (up to n_windows) positions whose k-th window it is:
             // moving_average[j] is computed ONCE per j of the chunk, in place of c[j] (through
             // registers: the difference reaches mini_window_size slots ahead), and a position reads
@@ -95,6 +105,10 @@ __global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const
                 if (i + (int)mw < N) C[i] = mq[u];
             }
             __syncthreads();
+            SM_PH(1);
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 11
+            sm_n++;
+#endif
         }
         for (int wq = wave; wq < SM_T / 64; wq += 4) {
             const i64 w = (q0 >> 6) + wq;
@@ -129,6 +143,16 @@ __global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const
             if (lane == 0) bw[w] = word;
         }
     }
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 11
+    SM_PH(2);
+    if (tid == 0) {
+        i64 *dbg = const_cast<ReadState &>(r).dbg;
+        for (int k = 0; k < 3; k++) atomicAdd((unsigned long long *)&dbg[k], (unsigned long long)sm_acc[k]);
+        atomicAdd((unsigned long long *)&dbg[3], (unsigned long long)sm_n);
+        atomicAdd((unsigned long long *)&dbg[4], 1ull);
+    }
+#endif
+#undef SM_PH
 }
 
 // Runs of "below" longer than min_consecutive_obs (tombo_stats.py:332-340): one thread per word
