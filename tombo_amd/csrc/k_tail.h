@@ -531,6 +531,7 @@ __global__ __launch_bounds__(64) void k_skip_dp_wave(ReadState *rs, const DevPar
                                                , r.dbg
 #endif
                                                );
+            wave_mem_fence(); // (lane 0 wrote the boundaries, every lane reads them back)
             if (rc == TBA_OK)
                 for (i64 k = threadIdx.x; k < n - 1; k += 64) out[s + 1 + k] += sig_start;
         }
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
         if (lane == 0) r.status = code;
         return;
     }
+    wave_mem_fence(); // (the checks read boundaries other lanes wrote)
     int flag = 0; // 1: zero-length event
     for (i64 i = lane; i + 1 < n_segs; i += 64)
         if (out[i + 1] - out[i] < 1) flag = 1;
@@ -602,7 +604,10 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
 // intercept.  One workgroup per read; the (<= 1000) points sit in LDS, the n(n-1)/2 slopes are
 // recomputed inside every radix-select pass instead of being stored (4 MB per read otherwise).
 // Pair enumeration by circular distance: (i, (i+d) mod n); slope(i,j) == slope(j,i) bitwise.
-#define TSW_SAMPLE_DIST 128 // distances in the window sample
+#define TSW_SAMPLE_DIST 128 // distances in the window sample: at most ...
+#ifndef TSW_SAMPLE_MIN
+#define TSW_SAMPLE_MIN 96   // ... and at least (scratch permitting: see the sample size below)
+#endif
 #define TSW_MIN_POINTS 256  // below this the generic two-pass select is cheap anyway
 #define TSW_REL 1e-5        // guard band of the approximate classification (see below)
 // The per-base means the fit needs (ts.compute_base_means = c_new_means, _c_helper.pyx:59-71,
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
         {
             const double want = 4.0 * (double)ns / (0.6 * (double)cap);
             const double need = want * want / (double)nn;
-            ds = need < 96.0 ? 96 : (need > (double)TSW_SAMPLE_DIST ? TSW_SAMPLE_DIST : (int)need + 1);
+            ds = need < (double)TSW_SAMPLE_MIN ? TSW_SAMPLE_MIN : (need > (double)TSW_SAMPLE_DIST ? TSW_SAMPLE_DIST : (int)need + 1);
             ds = ds < dmax ? ds : dmax;
         }
         const double glo = 0.5, gsc = (double)BS_NB / 1.0;

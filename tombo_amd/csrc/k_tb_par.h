@@ -36,6 +36,10 @@
 #define TBP_WAVE_BELOW 1024 // batches up to this many reads: a wavefront per read (latency form)
 #define TBP_MIN_CHUNK 64    // rows; the overlap (phase B) is a block of 16 or two
 
+// (tbp_fence: lanes of ONE wavefront hand read_tb entries to each other through memory -- wave_mem_fence,
+// tba_common.h, and why __threadfence_block() is not the fence for that)
+#define tbp_fence wave_mem_fence
+
 // One block of TBR rows of one walker: rows r0, r0 - 1, ... > stop, with the reference's rules
 // (negative band positions wrap like Python indices).  The fetch / bit-mask / clz scheme is
 // k_main_tb's (k_dp.h).
@@ -48,7 +52,8 @@
 template <bool EXT>
 __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int roww, const i64 *st,
     int Wi, int thresh, i64 r0, i64 stop, i64 &cur_ev, int &bp_guess, int &rc, i64 *tb,
-    i64 &viol_lo, i64 cmp_lo, i64 &merged_row, const unsigned char *strip, int strip_s0, i64 n_static)
+    i64 &viol_lo, i64 cmp_lo, i64 &merged_row, const unsigned char *strip, int strip_s0, i64 n_static,
+    int *dbg_stores = nullptr)
 {
     i64 stv[TBR];
     uint4 win[TBR];
@@ -146,7 +151,7 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
                 cur_ev = stv[k] + bp;
                 bp_guess = bp;
                 if (EXT && rr - 1 >= cmp_lo && oldv[k] == cur_ev + 1) merged_row = rr - 1;
-                else tb[rr - 1] = cur_ev + 1;
+                else { tb[rr - 1] = cur_ev + 1; if (EXT && dbg_stores) ++*dbg_stores; }
             }
         }
     }
@@ -212,25 +217,47 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     // dies (rcA) stops writing, so without a death it is lo; after one, nothing below is known --
     // the lane above then compares nothing in this chunk (cmp_lo above every row of it)
     const i64 wrote_lo = rcA == TBA_OK ? lo : hi;
-    __threadfence_block(); // phase B reads what the lane below wrote
+    tbp_fence(); // phase B reads what the lane below wrote
     // ---- phase B: into chunk c + 1
     const bool ext = mine && c + 1 < n_chunks && rcA == TBA_OK;
     const i64 nxt_start = shfl_i64(start_ev, (lane + 1) & 63), nxt_wrote_lo = shfl_i64(wrote_lo, (lane + 1) & 63);
     const i64 lo2 = c + 1 >= n_chunks - 1 || lo - L < 0 ? 0 : lo - L; // lo of chunk c + 1
     i64 merged_row = TBP_NONE;
     int rcB = TBA_OK;
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 12
+    int dbg_st = 0;
+    int *dbg_stp = &dbg_st;
+    const bool dbg_imm = ext && cur == nxt_start;
+#else
+    int *dbg_stp = nullptr;
+#endif
     {
         bool walking = ext;
         if (ext && cur == nxt_start) { merged_row = lo; walking = false; } // (entering row lo = its hi)
         i64 r0 = lo;
         while (__any(walking)) {
             if (walking) {
-                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rcB, tb, viol_lo, nxt_wrote_lo, merged_row, strip, strip_s0, n_stat);
+                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rcB, tb, viol_lo, nxt_wrote_lo, merged_row, strip, strip_s0, n_stat, dbg_stp);
                 r0 -= TBR;
                 if (rcB != TBA_OK || merged_row != TBP_NONE || r0 <= lo2) walking = false;
             }
         }
     }
+#if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 12
+    // per read: 0 lanes that extended, 1 merged at once (state equal on entry), 2 merged later, 3 rows
+    // overwritten in phase B, 4 chunks, 5 sum of the rows merged at relative to the chunk top, 6 lanes
+    // whose phase A died, 7 sum of phase-A start states
+    if (on) {
+        auto add = [&](int k, i64 v) { atomicAdd((unsigned long long *)&r.dbg[k], (unsigned long long)v); };
+        if (ext) add(0, 1);
+        if (dbg_imm) add(1, 1);
+        if (ext && !dbg_imm && merged_row != TBP_NONE) { add(2, 1); add(5, lo - merged_row); }
+        add(3, dbg_st);
+        if (c == 0) add(4, n_chunks);
+        if (mine && rcA != TBA_OK) add(6, 1);
+        if (mine) add(7, start_ev);
+    }
+#endif
     // ---- the chain, top down (uniform over the group: every lane runs the same loop)
     int status = TBA_OK;
     bool broken = false;
@@ -246,7 +273,7 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
         if (mj == TBP_NONE) { broken = true; continue; }
         true_from = mj;
     }
-    __threadfence_block(); // the lanes' read_tb entries, before lane 0 of the group reads them back
+    tbp_fence(); // the lanes' read_tb entries, before lane 0 of the group reads them back
     if (!on || c != 0 || broken) return;            // (broken: k_main_tb walks this read)
     r.tb_done = 1;
     r.tb_form = LPR; // TBA_TB_FORM_PAR16 / TBA_TB_FORM_PAR64
@@ -263,4 +290,77 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     i64 t0 = vtb[0];
     if (t0 < 0) t0 += n_ev + 1;
     r.top_pos = t0;
+}
+
+// Phase B once more, after a kernel boundary.  tools/determinism_probe.py found a handful of wavefronts
+// per 10 000-read RNA batch (never the same ones, never in an instrumented build, with or without the
+// fences above) whose phase B had left the speculative rows under every chunk top standing -- the
+// result then depended on the run.  Phase B is idempotent: the lane of boundary c takes the state
+// entering the top row of chunk c + 1 from the entry above it (the bottom of chunk c: true, by the
+// chain k_main_tb_par checked), walks down, overwrites what differs and stops at the first agreement
+// -- on an intact read that is the first row it looks at (one block of 16 rows per boundary).  Same
+// lanes, same chunk geometry as k_main_tb_par<LPR>; reads it did not finish (tb_done == 0) are
+// k_main_tb's anyway.  Entries the trim may have clamped (at or beyond the last event, at or below 0)
+// are no state to start from: such a boundary is left alone.
+template <int LPR>
+__global__ __launch_bounds__(64) void k_tb_par_repair(ReadState *rs, i64 n_reads, const i32 *idx,
+    const DevParams *dp, const unsigned char *moves, const i64 *band_starts, i64 *read_tb)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x, g = lane / LPR, c = lane % LPR, gbase = g * LPR;
+    const i64 slot = (i64)blockIdx.x * RPW + g;
+    const bool have = slot < n_reads;
+    const i64 ri = have ? (idx ? (i64)idx[slot] : slot) : 0;
+    ReadState &r = rs[ri];
+    const bool on = have && r.status == TBA_OK && r.path == PATH_ADAPTIVE && r.tb_done == 1 && r.tb_form == LPR &&
+                    (idx != nullptr || !r.is_long) && r.B >= 2 && cpl_class(r.W) != 0;
+    const i64 B = on ? r.B : 2;
+    const int Wi = on ? (int)r.W : 64;
+    const int rowb = (int)mv_row_bytes(Wi), roww = rowb / 4;
+    const unsigned char *mv = moves + (on ? r.moves_off : 0);
+    const i64 *st = band_starts + (on ? r.ref_off : 0);
+    i64 *tb = read_tb + (on ? r.seg_off : 0);
+    const int thresh = (int)dp->p.band_bound_thresh;
+    const int strip_s0 = on ? r.strip_s0 : -1;
+    const unsigned char *strip = mv + (B + 1) * (i64)rowb;
+    const i64 n_stat = on ? r.n_static : 0;
+    const i64 n_ev = on ? r.n_ev - r.clip : 0;
+    i64 top_rows = B - ((on ? r.n_static : 0) + 16);   // (the chunk geometry of k_main_tb_par)
+    top_rows = top_rows < 1 ? 1 : top_rows;
+    i64 L = (top_rows + LPR - 1) / LPR;
+    L = L < TBP_MIN_CHUNK ? TBP_MIN_CHUNK : L;
+    const int n_chunks = (int)((top_rows + L - 1) / L);
+    const i64 hi = B - (i64)c * L, lo = c >= n_chunks - 1 || hi - L < 0 ? 0 : hi - L;
+    const i64 lo2 = c + 1 >= n_chunks - 1 || lo - L < 0 ? 0 : lo - L;
+    bool ext = on && c + 1 < n_chunks && lo >= 1;
+    i64 cur = 0;
+    if (ext) {
+        const i64 above = tb[lo];                       // recorded after row lo + 1: the state entering row lo, + 1
+        if (above <= 0 || above >= n_ev) ext = false;   // (possibly clamped by the trim)
+        cur = above - 1;
+    }
+    int guess = Wi / 2, rc = TBA_OK;
+    if (ext) {
+        const i64 g0 = cur - st[lo - 1];
+        guess = g0 < 0 ? 0 : (g0 >= Wi ? Wi - 1 : (int)g0);
+    }
+    i64 merged_row = TBP_NONE, viol = TBP_NONE;
+    {
+        bool walking = ext;
+        i64 r0 = lo;
+        while (__any(walking)) {
+            if (walking) {
+                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rc, tb, viol, 0, merged_row, strip, strip_s0, n_stat);
+                r0 -= TBR;
+                if (rc != TBA_OK || merged_row != TBP_NONE || r0 <= lo2) walking = false;
+            }
+        }
+    }
+    // the first error in walk order (the lowest chunk index) is the read's
+    int err = ext ? (rc != TBA_OK ? rc : (merged_row == TBP_NONE ? TBA_INTERNAL : 0)) : 0, first_err = 0;
+    for (int j = 0; j < LPR; j++) {
+        const int ej = __shfl(err, gbase + j, 64);
+        if (first_err == 0 && ej != 0) first_err = ej;
+    }
+    if (on && c == 0 && first_err != 0) r.status = first_err;
 }

@@ -139,6 +139,21 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
     return __builtin_fma(e, y, q);
 }
 
+// Lanes of ONE wavefront handing values to each other through GLOBAL memory (k_main_tb_par: read_tb
+// entries between the lanes of a read; k_skip_dp_wave: the boundaries lane 0 found).
+// __threadfence_block() / __syncthreads() are not the fence for that in a workgroup of a single
+// wavefront: the compiler narrows workgroup scope to wavefront scope and emits NOTHING -- no s_waitcnt
+// between the stores and the loads that follow (seen in the ISA) -- and the hardware does not order one
+// lane's load behind another lane's earlier store.  Found in round 5 by tools/determinism_probe.py: a
+// handful of wavefronts per 10 000-read RNA batch compared their traceback state with what read_tb held
+// BEFORE the lane below wrote it (the previous run's finished path: "equal", merged at once, the
+// speculative rows under every chunk top left standing), differently from run to run.
+// All stores performed, then the vector L1 dropped, whatever the scope analysis thinks:
+__device__ __forceinline__ void wave_mem_fence()
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+}
+
 // whole-wave shift by one lane on the DPP crossbar (no LDS round trip): lane i <- lane i-1 /
 // lane i <- lane i+1; the lane without a source takes the given value
 __device__ __forceinline__ double wave_shr1_f64(double x, double lane0_val)

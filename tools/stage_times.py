@@ -80,6 +80,16 @@ def main():
                 h.update(np.bitwise_xor.reduce(b).tobytes() + b.sum(dtype=np.uint64).tobytes() +
                          (b[:w.size] * w).sum(dtype=np.uint64).tobytes())
         digests.append(h.hexdigest())
+        if os.environ.get('TBA_DUMP_READS'):
+            # per-read fingerprints of this build's run (to find WHICH reads differ between two runs)
+            import zlib
+            n = a.reads
+            seg_h = np.array([zlib.crc32(out['segs'][eng.seg_off[i]:eng.seg_off[i + 1]].tobytes()) for i in range(n)], np.uint32)
+            nrm_h = np.array([zlib.crc32(out['norm'][eng.raw_off[i]:eng.raw_off[i] + int(out['norm_len'][i])].tobytes()) for i in range(n)], np.uint32) \
+                if 'norm' in out else np.zeros(n, np.uint32)
+            np.savez(os.environ['TBA_DUMP_READS'] + '_%d.npz' % (len(digests) - 1), seg=seg_h, norm=nrm_h,
+                     status=out['status'], sv=out['sv'], score=out['score'], read_start=out['read_start'],
+                     ts=eng.get(_native.GET_THEIL_SEN), stalls=eng.get(_native.GET_N_STALL) if hasattr(_native, 'GET_N_STALL') else np.zeros(n))
         print('result digest %s' % digests[-1][:16])
         if os.environ.get('TBA_DBG_PHASES'):
             d = eng.get(_native.GET_DEBUG_COUNTERS)
