@@ -6,6 +6,7 @@ boundaries, statuses); float64 outputs compared bit-exactly where the arithmetic
 operation by operation, with the contractual 1e-5 tolerance on the normalised signal asserted
 separately.
 """
+import os
 import numpy as np
 import pytest
 
@@ -615,6 +616,52 @@ def test_side_stream_on_and_off_agree_on_gpu(samp_name):
     assert sum(x == 0 for x in st) >= 3, st
     for k in a:
         assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+    eng.close()
+
+
+def test_big_rna_batch_is_the_same_every_run_and_the_oracles_on_gpu():
+    """More wavefronts than the machine holds at once, four runs of one resident batch: the same bytes
+    every time, and the oracle's on a sample of the late reads.  (Round 5: with 10 000 RNA reads a few
+    wavefronts of k_main_tb_par<16> per run -- always among those dispatched after the first 1 024 --
+    left speculative rows under their chunk tops, differently from run to run, while every 48-read
+    parity test was green; k_tb_par_repair, tools/determinism_probe.py.)"""
+    import zlib
+    import bench
+    from tombo_amd import _native as N, tombo_stats as ts, tombo_helper as th
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH, STALL_PARAMS
+    samp = th.seqSampleType('RNA', True)
+    model = ts.TomboModel(seq_samp_type=samp)
+    params = ts.load_resquiggle_parameters(samp)._replace(bandwidth=500)
+    n, nb = 4608, 1200
+    seqs, raws, _ = bench.make_reads(np.full(n, nb, np.int64), 77000, min(32, os.cpu_count() or 8), 'RNA', False)
+    rng = np.random.RandomState(3)
+    si = np.stack([rng.choice(nb, 1000, replace=False) for _ in range(n)])
+    eng = N.Engine(0)
+    eng.set_model(model.level_means, model.level_sds, model.kmer_width, model.central_pos)
+    eng.upload(N.make_params(params),
+               N.make_opts(outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH['RNA'],
+                           stall_params=th.stallParams(**STALL_PARAMS)),
+               raws, [ts.encode_seq(q) for q in seqs], samp_ind=si)
+    runs = []
+    for _ in range(4):
+        eng.run()
+        out = eng.download()
+        tb = eng.get(N.GET_READ_TB)
+        runs.append((zlib.crc32(tb.tobytes()), zlib.crc32(out['segs'].tobytes()), zlib.crc32(out['norm'].tobytes()),
+                     out['status'].tobytes()))
+    assert len(set(runs)) == 1, [r[:3] for r in runs]
+    form = eng.get(N.GET_TB_FORM)
+    assert (form == N.TB_FORM_PAR16).sum() > 3500, np.bincount(form)
+    segs = out['segs']
+    checked = 0
+    for i in list(range(4100, 4608, 23)) + [0, 1, 2047, 2048]:
+        o = _oracle_read(model, params, raws[i], seqs[i], 5.0, 'RNA', stall_ints=oracle.identify_stalls(raws[i]),
+                         samp_ind=si[i])
+        assert o['status'] == int(out['status'][i]), (i, o['status'], int(out['status'][i]))
+        if o['status'] == 0:
+            np.testing.assert_array_equal(segs[eng.seg_off[i]:eng.seg_off[i + 1]], o['segs'], err_msg='read %d' % i)
+            checked += 1
+    assert checked >= 20
     eng.close()
 
 
