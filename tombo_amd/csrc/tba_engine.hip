@@ -818,10 +818,14 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         else k_main_tb_par<64><<<nb, 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         if (e->n_long > 0 && n > e->tb_wave_below) k_main_tb_par<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
 #ifndef TBA_NO_TB_REPAIR
-        // phase B a second time, behind a kernel boundary (k_tb_par.h: what the determinism probe found)
+        // phase B again, behind a kernel boundary (k_tb_par.h: what the determinism probe found) -- twice:
+        // the failure recurs on the same few wavefronts, so one more pass squares a per-wavefront rate that
+        // is not small for those; a pass over an intact read looks at one block of rows per chunk top (70 us)
+        for (int pass = 0; pass < 2; pass++) {
         if (n > e->tb_wave_below) k_tb_par_repair<16><<<(unsigned)((n + 3) / 4), 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         else k_tb_par_repair<64><<<nb, 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         if (e->n_long > 0 && n > e->tb_wave_below) k_tb_par_repair<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        }
 #endif
 #endif
         k_main_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
