@@ -59,3 +59,31 @@ def test_chunk_parallel_walk_reports_the_first_error():
             assert rc == rc_s, (thresh, lanes)
         seen.add(rc_s)
     assert seen == {0, 2}   # both outcomes were exercised
+
+
+@pytest.mark.parametrize('n_bases,bw,seed', [(1500, 200, 0), (900, 500, 5)])
+def test_repair_pass_restores_the_serial_walk(n_bases, bw, seed):
+    """k_tb_par_repair (round 5): with the phase B of some -- or all -- lanes ending on its first
+    compare, the speculative rows under the chunk tops stay and the walk is wrong; a second phase B
+    over the finished array (state from the entry above each chunk top) overwrites exactly those rows,
+    and a pass over an intact array changes nothing"""
+    tb, st, top = M.forward(n_bases, bw, seed)
+    rc_s, want = M.serial(tb, st, top)
+    assert rc_s == 0
+    for lanes in (4, 16):
+        rc, good, info = M.chunk_parallel(tb, st, top, lanes)
+        assert rc == 0
+        rc_r, n_over = M.repair(tb, st, good, lanes)
+        assert (rc_r, n_over) == (0, 0)
+        np.testing.assert_array_equal(good, want)
+        n = info['n_chunks']
+        for failing in ({0}, {n - 2}, set(range(n - 1)), set(range(0, n - 1, 2))):
+            rc, got, _ = M.chunk_parallel(tb, st, top, lanes, fail_phase_b=failing)
+            assert rc == 0                                   # (the chain believes the false agreements)
+            speculative = int((got != want).sum())
+            assert speculative > 0 or len(failing) == 1, (lanes, failing)   # (the injected failure does show)
+            rc_r, n_over = M.repair(tb, st, got, lanes)
+            assert rc_r == 0
+            np.testing.assert_array_equal(got, want)
+            assert n_over == speculative                     # only the rows that were wrong are written
+            assert M.repair(tb, st, got, lanes) == (0, 0)    # idempotent

@@ -42,10 +42,13 @@ def serial(tb, starts, top_pos, thresh=-1):
     return OK, out
 
 
-def chunk_parallel(tb, starts, top_pos, lanes=16, thresh=-1, min_chunk=64, start_cell=None, n_static=100):
+def chunk_parallel(tb, starts, top_pos, lanes=16, thresh=-1, min_chunk=64, start_cell=None, n_static=100,
+                   fail_phase_b=()):
     """returns (rc, read_tb, info); rc None = the chain broke (the kernel leaves the read to the
     serial walk).  n_static: rows with a static band at the start of the read (the path is anywhere
-    in those bands, so they all go to the lowest chunk)"""
+    in those bands, so they all go to the lowest chunk).  fail_phase_b: chunks whose lane's phase B
+    ends on its first compare as if it had found agreement there (the failure the round-5 determinism
+    probe found on the GPU: the speculative rows under the next chunk's top stay) -- see `repair`"""
     B, bw = tb.shape[0] - 1, tb.shape[1]
     top_rows = max(B - (n_static + 16), 1)
     L = max((top_rows + lanes - 1) // lanes, min_chunk)
@@ -75,7 +78,7 @@ def chunk_parallel(tb, starts, top_pos, lanes=16, thresh=-1, min_chunk=64, start
     for c in range(n_chunks - 1):
         if rcA[c]:
             continue
-        if cur[c] == start[c + 1]:
+        if cur[c] == start[c + 1] or c in fail_phase_b:
             merged[c] = lo[c]
             merge_rows.append(0)
             continue
@@ -108,6 +111,39 @@ def chunk_parallel(tb, starts, top_pos, lanes=16, thresh=-1, min_chunk=64, start
             return None, out, dict(merge_rows=merge_rows)
         true_from = merged[j]
     return status, out, dict(merge_rows=merge_rows, chunk=L, n_chunks=n_chunks)
+
+
+def repair(tb, starts, out, lanes=16, thresh=-1, min_chunk=64, n_static=100, n_ev=None):
+    """k_tb_par_repair: phase B once more over a finished read_tb (`out`, modified in place).  The lane
+    of every chunk boundary takes the state entering the top row of the next chunk from the entry above
+    it, walks down, overwrites what differs and stops at the first agreement.  Returns (rc, rows
+    overwritten): rc INTERNAL when a lane finds no agreement inside the next chunk."""
+    B, bw = tb.shape[0] - 1, tb.shape[1]
+    top_rows = max(B - (n_static + 16), 1)
+    L = max((top_rows + lanes - 1) // lanes, min_chunk)
+    n_chunks = (top_rows + L - 1) // L
+    hi = [B - c * L for c in range(n_chunks)]
+    lo = [max(h - L, 0) for h in hi]
+    lo[-1] = 0
+    n_over, status = 0, OK
+    rec = out.copy()                               # (the lanes run side by side: each compares with what was there)
+    for c in range(n_chunks - 1):
+        above = int(rec[lo[c]])
+        if above <= 0 or (n_ev is not None and above >= n_ev):
+            continue                               # possibly clamped by the trim: no state to start from
+        cur, found = above - 1, False
+        for rr in range(lo[c], lo[c + 1], -1):
+            rc, cur, viol = _step(tb, starts, bw, rr, cur, thresh)
+            if rc or viol:
+                return (rc if rc else BEYOND), n_over
+            if rec[rr - 1] == cur + 1:
+                found = True
+                break
+            out[rr - 1] = cur + 1
+            n_over += 1
+        if not found and status == OK:
+            status = INTERNAL
+    return status, n_over
 
 
 def forward(n_bases=1500, bw=200, seed=0, static_rows=100):
