@@ -29,6 +29,7 @@ With --gpus N > 1 and no torchrun environment the script launches its own N rank
 per GPU).  Prints ONE JSON line on rank 0.
 """
 import os
+import zlib
 import gc
 import sys
 import json
@@ -817,6 +818,23 @@ def main():
 
     for _ in range(a.warmup):
         one_pass()
+
+    def batch_digest():
+        """CRC of every resident batch's boundaries + status, and the rows the traceback's verifier disagreed on
+        (TBA_GET_TB_VERIFY_FAIL): taken after the warm-up and again after the last timed pass, outside the clock --
+        the timed passes run ONE resident batch again and again, so the two must be equal and the count zero"""
+        if stub is not None:
+            return None, 0
+        crc, vf = 0, 0
+        for eng in engines:
+            d = eng.download(want_norm=False)
+            crc = zlib.crc32(d['status'].tobytes(), zlib.crc32(d['segs'].tobytes(), crc))
+            vf += int(eng.get(_native.GET_TB_VERIFY_FAIL).sum())
+        return crc, vf
+
+    if a.warmup == 0:
+        one_pass()
+    digest_first, vf_first = batch_digest()
     queue = sharding.BatchQueue(a.steps * world, key='resident')
     barrier()
     t0 = time.perf_counter()
@@ -835,6 +853,7 @@ def main():
     n_ok = 0
     for eng in engines:
         n_ok += int((eng.download(want_norm=False)['status'] == 0).sum())
+    digest_last, vf_last = batch_digest()
     if os.environ.get('TBA_DBG_PHASES'):
         # profiling aid: per-read debug counters of a -DTBA_PHASE_DEBUG / -DTBA_SWEEP_STATS build
         # (TBA_EXTRA_HIPCC_FLAGS, see tombo_amd/_native.py), to stderr
@@ -877,7 +896,9 @@ def main():
     del engines, probe
     rank_rec = dict(rank=rank, device=dev, device_name=dev_name, steps=my_steps,
                     resident_reads_per_s=round(a.reads * my_steps / my_dt, 2) if my_steps else 0.0,
-                    resident_busy_s=round(my_dt, 4))
+                    resident_busy_s=round(my_dt, 4),
+                    digest_stable=None if digest_first is None else bool(digest_first == digest_last),
+                    tb_verify_fail_rows=int(vf_first + vf_last))
 
     # ---- phase 2: end to end through the streaming pipeline ---------------------------------
     e2e = None
@@ -1148,6 +1169,10 @@ def main():
                        'two_resident_batches_alternating': two_batches,
                        'bases_per_s': round(tot_bases * steps_done / dt, 1),
                        'success_rate': round(n_ok / float(a.reads), 4),
+                       # the resident batch gave the same boundaries + status after the warm-up and after the last
+                       # timed pass (every rank), and the traceback's verifier found nothing (rows, all ranks)
+                       'digest_stable': None if any(r['digest_stable'] is None for r in per_rank) else all(r['digest_stable'] for r in per_rank),
+                       'tb_verify_fail_rows': sum(r['tb_verify_fail_rows'] for r in per_rank),
                        'parallelism': 'reads sharded over %d process(es) through a shared batch '
                                       'counter; no collective on the data path, gloo control plane' % world,
                        'devices': [r['device'] for r in per_rank], 'visible_devices': ndev,

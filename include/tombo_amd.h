@@ -300,6 +300,11 @@ enum {
     TBA_GET_ED_FORM = 29,     /* int32[n]: TBA_ED_FORM_*: the kernels that produced the read's change points
                                * (0: none did -- the read had failed before) */
     TBA_GET_TB_FORM = 30,     /* int32[n]: TBA_TB_FORM_*: the kernel that walked the read's main traceback */
+    TBA_GET_TB_VERIFY_FAIL = 31, /* int32[n]: rows of the read where the verifier of the chunk-parallel traceback
+                               * (k_tb_par_verify) found something else than its own walk; such a read was walked again
+                               * by the lane-per-read kernel, so its result is the serial walk's either way.  Zero for
+                               * every read is the expected state: a binding should treat anything else as a fault of
+                               * the machine or the build worth reporting (ABI 9) */
     TBA_GET_DEBUG_COUNTERS = 99 /* int64[n][8]: ReadState.dbg, only filled by -DTBA_PHASE_DEBUG /
                                    -DTBA_SWEEP_STATS profiling builds (zeros otherwise) */
 };
@@ -529,7 +534,7 @@ int tba_synth_dwell_thresholds(const tba_synth_params *p, uint32_t *thr, int64_t
 /* out[0..2] = sizeof(tba_params), sizeof(tba_opts), sizeof(tba_read_result) of this build, out[3]
  * (n >= 4) = TBA_ABI_VERSION: lets a binding without a C compiler (ctypes) check its struct mirrors
  * and refuse a stale build of the library */
-#define TBA_ABI_VERSION 8
+#define TBA_ABI_VERSION 9
 int tba_abi_sizes(int64_t *out, int64_t n);
 
 /* self-test: out[t] = index t of the subsample tba_opts.device_subsample draws for read

@@ -175,4 +175,7 @@ def check_forms(eng, form, params, require_all_fused=False):
     if form == 'latency':
         assert N.TB_FORM_PAR16 not in set(tb.tolist())
     assert np.all(tb[walked & (path == 2)] == N.TB_FORM_LANE)
+    # the verifier behind the chunk-parallel traceback (k_tb_par_verify) agreed with every row it looked at
+    vf = eng.get(N.GET_TB_VERIFY_FAIL)
+    assert not vf.any(), ('the traceback verifier disagreed', np.flatnonzero(vf).tolist()[:20], vf[vf != 0][:20].tolist())
     return ed, tb

@@ -624,7 +624,8 @@ def test_big_rna_batch_is_the_same_every_run_and_the_oracles_on_gpu():
     every time, and the oracle's on a sample of the late reads.  (Round 5: with 10 000 RNA reads a few
     wavefronts of k_main_tb_par<16> per run -- always among those dispatched after the first 1 024 --
     left speculative rows under their chunk tops, differently from run to run, while every 48-read
-    parity test was green; k_tb_par_repair, tools/determinism_probe.py.)"""
+    parity test was green; round 6: profiles/r06_traceback_rootcause.txt, k_tb_par_verify, and the batches of
+    tests/test_gpu_determinism.py at the sizes the fault showed at.)"""
     import zlib
     import bench
     from tombo_amd import _native as N, tombo_stats as ts, tombo_helper as th
@@ -650,6 +651,7 @@ def test_big_rna_batch_is_the_same_every_run_and_the_oracles_on_gpu():
         runs.append((zlib.crc32(tb.tobytes()), zlib.crc32(out['segs'].tobytes()), zlib.crc32(out['norm'].tobytes()),
                      out['status'].tobytes()))
     assert len(set(runs)) == 1, [r[:3] for r in runs]
+    assert not eng.get(N.GET_TB_VERIFY_FAIL).any()
     form = eng.get(N.GET_TB_FORM)
     assert (form == N.TB_FORM_PAR16).sum() > 3500, np.bincount(form)
     segs = out['segs']

@@ -62,3 +62,12 @@ def test_kernel_fits_its_occupancy_step(isa_metadata, frag):
     assert m['vgpr'] <= max_vgpr, (hits[0], m)
     if not scratch_ok:
         assert m['spill'] == 0 and m['scratch'] == 0, (hits[0], m)
+
+
+def test_no_kernel_is_allocated_224_vgprs(isa_metadata):
+    """profiles/r06_traceback_rootcause.txt: the chunk-parallel traceback computed run-dependent rows on MI355X with
+    the 224 VGPRs (28 granules of 8) the compiler had given it and never with 225-256, the instructions untouched.
+    What the allocation does is not understood, so no kernel of the library may land on it -- a kernel that reports
+    217-224 registers needs a named clobber as in k_tb_par.h (TBP_NOT_224_VGPRS) or a different register budget."""
+    bad = sorted(k for k, m in isa_metadata.items() if (m['vgpr'] + 7) // 8 == 28)
+    assert not bad, bad

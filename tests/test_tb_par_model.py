@@ -2,8 +2,8 @@
 tools/tb_par_model.py restates its phases and its chain of agreements over the move matrix the
 oracle's forward pass leaves; the stitched walk must equal c_banded_traceback's serial walk, the
 walks started in the middle of the band must merge into the true path within a few rows (else the
-kernel would be correct but no faster than the lane-per-read walk), and a failing read must get the
-serial walk's status.  The kernel itself is compared with the oracle's read_tb by the -m gpu parity
+kernel would be correct but no faster than the lane-per-read walk), a failing read must get the
+serial walk's status, and the verifier behind the kernel must catch a phase B that went wrong.  The kernel itself is compared with the oracle's read_tb by the -m gpu parity
 tests."""
 import os
 import sys
@@ -49,43 +49,53 @@ def test_any_start_cell_gives_the_serial_walk_or_a_broken_chain(start_cell):
 
 
 def test_chunk_parallel_walk_reports_the_first_error():
-    """band-edge threshold: the status is the one the serial walk stops with"""
+    """band-edge threshold: the status is the one the serial walk stops with -- from the parallel walk where the
+    error is a phase A's on the true path, from the serial walk it hands the read to where it is a phase B's"""
     tb, st, top = M.forward(1500, 100, 1)
-    seen = set()
+    seen, how_seen = set(), set()
     for thresh in (0, 1, 5, 20, 40):
-        rc_s, _ = M.serial(tb, st, top, thresh)
+        rc_s, want = M.serial(tb, st, top, thresh)
         for lanes in (4, 16, 64):
-            rc, _, _ = M.chunk_parallel(tb, st, top, lanes, thresh)
+            rc_p, _, _ = M.chunk_parallel(tb, st, top, lanes, thresh)
+            assert rc_p is None or rc_p == rc_s, (thresh, lanes)
+            rc, got, how = M.traceback(tb, st, top, lanes, thresh)
             assert rc == rc_s, (thresh, lanes)
+            if rc == 0:
+                np.testing.assert_array_equal(got, want)
+            how_seen.add(how)
         seen.add(rc_s)
     assert seen == {0, 2}   # both outcomes were exercised
+    assert 'parallel' in how_seen
 
 
 @pytest.mark.parametrize('n_bases,bw,seed', [(1500, 200, 0), (900, 500, 5)])
-def test_repair_pass_restores_the_serial_walk(n_bases, bw, seed):
-    """k_tb_par_repair (round 5): with the phase B of some -- or all -- lanes ending on its first
-    compare, the speculative rows under the chunk tops stay and the walk is wrong; a second phase B
-    over the finished array (state from the entry above each chunk top) overwrites exactly those rows,
-    and a pass over an intact array changes nothing"""
+def test_verifier_sends_a_faulty_walk_to_the_serial_kernel(n_bases, bw, seed):
+    """k_tb_par_verify (round 6).  Two faults of a phase B, each at one, at several and at all chunk tops: the walk
+    coming out of its first row one event too high (what the MI355X did at a 224-VGPR allocation), and a false
+    agreement on the first compare (what round 5 took it for).  The chain believes both; the verifier's count is
+    non-zero exactly when the result is not the serial walk's, the read then gets the serial walk, and an intact
+    read costs nothing"""
     tb, st, top = M.forward(n_bases, bw, seed)
     rc_s, want = M.serial(tb, st, top)
     assert rc_s == 0
-    shown = 0
+    caught = 0
     for lanes in (4, 16):
         rc, good, info = M.chunk_parallel(tb, st, top, lanes)
-        assert rc == 0
-        rc_r, n_over = M.repair(tb, st, good, lanes)
-        assert (rc_r, n_over) == (0, 0)
+        assert rc == 0 and M.verify(tb, st, good, lanes) == 0
         np.testing.assert_array_equal(good, want)
+        assert M.traceback(tb, st, top, lanes)[2] == 'parallel'
         n = info['n_chunks']
-        for failing in ({0}, {n - 2}, set(range(n - 1)), set(range(0, n - 1, 2))):
-            rc, got, _ = M.chunk_parallel(tb, st, top, lanes, fail_phase_b=failing)
-            assert rc == 0                                   # (the chain believes the false agreements)
-            speculative = int((got != want).sum())
-            shown += speculative
-            rc_r, n_over = M.repair(tb, st, got, lanes)
-            assert rc_r == 0
-            np.testing.assert_array_equal(got, want)
-            assert n_over == speculative                     # only the rows that were wrong are written
-            assert M.repair(tb, st, got, lanes) == (0, 0)    # idempotent
-    assert shown > 0   # (the injected failure does leave wrong rows somewhere)
+        for kind in ('first_row_plus_one', 'fail_phase_b'):
+            for failing in ({0}, {n - 2}, set(range(n - 1)), set(range(0, n - 1, 2))):
+                rc, got, _ = M.chunk_parallel(tb, st, top, lanes, **{kind: failing})
+                if rc is None:
+                    continue                                  # (the faulty walk found no agreement: serial anyway)
+                assert rc == 0                                # the chain believes it
+                wrong = bool((got != want).any())
+                n_diff = M.verify(tb, st, got, lanes)
+                assert (n_diff > 0) == wrong, (kind, failing, n_diff)
+                rc_t, out, how = M.traceback(tb, st, top, lanes, **{kind: failing})
+                assert rc_t == 0 and how == ('serial: verifier' if wrong else 'parallel')
+                np.testing.assert_array_equal(out, want)
+                caught += wrong
+    assert caught > 0   # (the injected faults do leave wrong rows somewhere)

@@ -20,17 +20,28 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off'
                '-shared']
 
 
+# a second build of the same source for ONE test (tests/test_gpu_determinism.py): the chunk-parallel traceback with a
+# deterministic fault in it, which the verifier has to catch.  Never loaded by the product (LIB_PATH is).
+INJECT_LIB_PATH = os.path.join(_HERE, 'libtombo_amd_inject.so')
+INJECT_FLAGS = ['-DTBA_TB_INJECT=5']
+
+
 def build(force=False):
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU): libtombo_amd.so and,
+    beside it, the fault-injection build one GPU test loads in a child process."""
+    tree_lib = os.path.join(_HERE, 'libtombo_amd.so')
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
         [os.path.join(_HERE, '..', 'include', 'tombo_amd.h')]
-    if (not force and os.path.exists(LIB_PATH) and
-            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
-        return LIB_PATH
+    newest = max(os.path.getmtime(s) for s in srcs)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    subprocess.check_call([hipcc] + HIPCC_FLAGS + os.environ.get('TBA_EXTRA_HIPCC_FLAGS', '').split() +
-                          ['-o', LIB_PATH,
-                                                   os.path.join(CSRC, 'tba_engine.hip')])
+    jobs = []
+    for path, extra in ((tree_lib, os.environ.get('TBA_EXTRA_HIPCC_FLAGS', '').split()), (INJECT_LIB_PATH, INJECT_FLAGS)):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
+            jobs.append((path, subprocess.Popen([hipcc] + HIPCC_FLAGS + extra +
+                                                ['-o', path, os.path.join(CSRC, 'tba_engine.hip')])))
+    for path, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, 'hipcc -> ' + path)
     return LIB_PATH
 
 
@@ -84,7 +95,7 @@ GET_VALID_CPTS, GET_N_CPTS, GET_EVENT_MEANS, GET_SEG_NORM, GET_SEG_SV, GET_START
     GET_BAND_STARTS, GET_READ_TB, GET_DP_SEGS, GET_THEIL_SEN, GET_PATH, GET_LAST_ROW, \
     GET_DP_READ_START, GET_KERNEL_MS, GET_REF_MEANS, GET_REF_SDS, GET_SEGS, GET_STATUS, GET_START_FAIL, \
     GET_STALL_INTS, GET_N_STALL, GET_STALL_OFF, GET_SAMP_IND, GET_TB_PARALLEL, GET_ED_FUSED, GET_ED_TAKEN_POS, GET_ED_N_TAKEN, \
-    GET_DP_WORKGROUP, GET_ED_FORM, GET_TB_FORM = range(1, 31)
+    GET_DP_WORKGROUP, GET_ED_FORM, GET_TB_FORM, GET_TB_VERIFY_FAIL = range(1, 32)
 # TBA_ED_FORM_* / TBA_TB_FORM_*: which kernels produced a read's change points / main traceback
 ED_FORM_NONE, ED_FORM_WG_SCAN_PEAKS, ED_FORM_DETECT_PICK, ED_FORM_SCORES_PEAKS, ED_FORM_DETECT_TT_PICK, \
     ED_FORM_TTEST_PEAKS = range(6)
@@ -95,7 +106,7 @@ STAGE_SEGMENT, STAGE_EVENT_MEANS, STAGE_REF_LEVELS, STAGE_START, STAGE_ASSIGN, S
 PUT_VALID_CPTS, PUT_EVENT_MEANS, PUT_NORM, PUT_REF_MEANS, PUT_REF_SDS, PUT_DP_SEGS, \
     PUT_START_STATE = range(1, 8)
 MAX_BAND = 3072
-ABI_VERSION = 8  # TBA_ABI_VERSION of include/tombo_amd.h
+ABI_VERSION = 9  # TBA_ABI_VERSION of include/tombo_amd.h
 STAGE_NAMES = ["normalize", "cumsum", "scores", "peaks", "event_means", "ref_levels",
                "start_dp", "start_tb", "prep", "main_dp", "main_tb", "skip_resolve", "theil_sen",
                "rescale_score", "stalls", "total"]
@@ -559,7 +570,8 @@ class Engine(object):
             GET_N_STALL: (np.int64, n), GET_STALL_OFF: (np.int64, n),
             GET_SAMP_IND: (np.int64, (n, 1000)),
             GET_TB_PARALLEL: (np.int32, n), GET_ED_FUSED: (np.int32, n), GET_DP_WORKGROUP: (np.int32, n),
-            GET_ED_FORM: (np.int32, n), GET_TB_FORM: (np.int32, n),
+            GET_ED_FORM: (np.int32, n), GET_TB_FORM: (np.int32, n), GET_TB_VERIFY_FAIL: (np.int32, n),
+            97: (np.int64, 2 * max(int(self.seg_off[-1]), 1)),  # (a -DTBA_TB_B2 experiment build: phase B's second / third array)
             GET_ED_TAKEN_POS: (np.int32, 2 * self.n_raw_total), GET_ED_N_TAKEN: (np.int64, n),
         }
         if what in (GET_VALID_CPTS, GET_EVENT_MEANS):

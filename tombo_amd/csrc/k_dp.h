@@ -1032,6 +1032,7 @@ __global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const D
     ReadState &r = rs[ri];
     r.moves_off = 0;
     r.tb_done = 0;
+    r.tb_verify_fail = 0;
     r.strip_s0 = -1;
     r.tb_form = TBA_TB_FORM_NONE;
     r.dp_wg = 0;

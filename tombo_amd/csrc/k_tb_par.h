@@ -26,9 +26,29 @@
 // phase B, and of a chunk's phase A at or below the row where the lane above merged into it; phase
 // A therefore walks on through band-edge violations and records the lowest row that had one.  The
 // first error in walk order gives the status (a violation comes before the walk's death).
-// Integer work: bit-exact by construction.  tools/tb_par_model.py restates the scheme over the
-// oracle's move matrices (tests/test_tb_par_model.py, CPU); on the GPU every parity test compares
-// read_tb with the oracle's.
+//
+// What holds the result to the serial walk's, row for row:
+//   * the scheme: tools/tb_par_model.py restates it over the oracle's move matrices
+//     (tests/test_tb_par_model.py, CPU); on the GPU every parity test compares read_tb with the oracle's;
+//   * k_tb_par_verify, behind the kernel boundary: under every chunk top it walks the first TBR rows
+//     again from the entry above (compare only) and hands any read with a disagreement to the serial
+//     kernels, counted (ReadState.tb_verify_fail, TBA_GET_TB_VERIFY_FAIL: asserted zero by the GPU tests
+//     and by bench.py).  A status that rests on a phase B (its error, or a broken chain) is never final
+//     either: such a read is the serial kernels' too.  _trim_traceback and top_pos are written by the
+//     verifier, after it has agreed -- until then the serial walk can still start from top_pos;
+//   * the register allocation.  Round 5 found a few wavefronts per 10 000-read RNA batch whose result
+//     depended on the run and "fixed" them with two repair passes; round 6 found what it was
+//     (profiles/r06_traceback_rootcause.txt).  Not the handoff through memory: with read_tb poisoned
+//     before the kernel, and with phase B's stores diverted into a second array, phase B entered with
+//     the same state every run and still computed a different FIRST ROW (path one event too high in
+//     every lane of the wavefront where the move was a diagonal) -- a computation, not a stale load.
+//     The same machine code (hand-assembled, tools/asm_variant.py) fails in 8-16 of 24 runs when the
+//     kernel descriptor allocates 224 VGPRs (28 granules: what the compiler had chosen, two wavefronts
+//     per SIMD) and in 0 of 24 with 225-256, the instructions untouched; s_nop / s_waitcnt padding
+//     anywhere in the failing binary changes nothing.  Idle and read-verify probes of a 224-register
+//     allocation (tools/vgpr_probe) see no register change, so the trigger needs this kernel's
+//     activity and is not understood further; the kernels here keep away from that allocation
+//     (TBP_NOT_224_VGPRS, and tests/test_kernel_resources.py holds every kernel of the library to it).
 #pragma once
 #include "k_dp.h"
 
@@ -40,21 +60,46 @@
 // tba_common.h, and why __threadfence_block() is not the fence for that)
 #define tbp_fence wave_mem_fence
 
+// A kernel of this file must not be allocated exactly 224 VGPRs (see above): naming v231 as clobbered
+// makes the compiler report 232.  -DTBA_TB_ALLOC224 takes it away (the build the determinism test is
+// shown failing on, profiles/r06_traceback_determinism_alloc224.txt).
+#ifdef TBA_TB_ALLOC224
+#define TBP_NOT_224_VGPRS() ((void)0)
+#else
+#define TBP_NOT_224_VGPRS() asm volatile("" ::: "v231")
+#endif
+// Experiment builds of the round-6 hunt (tools/tb_hunt.py): -DTBA_TB_B2 diverts phase B's stores into a
+// second array behind read_tb and records the state every lane enters phase B with in a third
+// (read_tb is allocated three arrays long), so that what phase B computed can be compared from run to
+// run without phase A's values in the way; -DTBA_TB_WAVES1 pads the workgroup with LDS until only one
+// wavefront fits on a SIMD (never failed).  The results of such a build are NOT the traceback.
+#ifdef TBA_TB_B2
+__device__ i64 TBA_TB_B2_OFF;
+#define TBP_B_STORE(tb_, i_, v_) ((tb_)[(i_) + TBA_TB_B2_OFF] = (v_))
+#else
+#define TBP_B_STORE(tb_, i_, v_) ((tb_)[(i_)] = (v_))
+#endif
+enum { TBP_A = 0, TBP_B = 1, TBP_V = 2 };
+
 // One block of TBR rows of one walker: rows r0, r0 - 1, ... > stop, with the reference's rules
 // (negative band positions wrap like Python indices).  The fetch / bit-mask / clz scheme is
 // k_main_tb's (k_dp.h).
-//   EXT == false (phase A): every row writes tb; a band-edge violation is recorded (viol_lo = its
+//   TBP_A (phase A): every row writes tb; a band-edge violation is recorded (viol_lo = its
 //     row; rows descend, so the last one recorded is the lowest) and the walk goes on; leaving the
 //     band ends it (rc).
-//   EXT == true (phase B): before a row's value is written it is compared with what tb holds
+//   TBP_B (phase B): before a row's value is written it is compared with what tb holds
 //     (rows >= cmp_lo only: below that the lane underneath wrote nothing); equal -> merged_row = that
 //     row, the walk ends; a violation ends it as well (rc), as in the serial walk.
-template <bool EXT>
+//   TBP_V (the verifier): nothing is written; every row is compared with what tb holds and the
+//     rows that differ are counted in *dbg_stores (a band-edge violation is not its business: phase B
+//     has seen the same row).
+template <int MODE>
 __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int roww, const i64 *st,
     int Wi, int thresh, i64 r0, i64 stop, i64 &cur_ev, int &bp_guess, int &rc, i64 *tb,
     i64 &viol_lo, i64 cmp_lo, i64 &merged_row, const unsigned char *strip, int strip_s0, i64 n_static,
     int *dbg_stores = nullptr)
 {
+    constexpr bool EXT = MODE != TBP_A, VER = MODE == TBP_V;
     i64 stv[TBR];
     uint4 win[TBR];
     i64 oldv[TBR];
@@ -91,7 +136,7 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
 #pragma unroll
     for (int k = 0; k < TBR; k++) {
         const i64 rr = r0 - k;
-        const bool act = rr > stop && rr >= 1 && rc == TBA_OK && (!EXT || merged_row == TBP_NONE);
+        const bool act = rr > stop && rr >= 1 && rc == TBA_OK && (!EXT || VER || merged_row == TBP_NONE);
         const i64 bp64 = cur_ev - stv[k];
         int bp = (int)bp64;
         const int lc = bp - 16 * wb;                // position inside the window
@@ -145,16 +190,36 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
         const int edge = bp < Wi - bp - 1 ? bp : Wi - bp - 1;
         const bool beyond = thresh >= 0 && edge < thresh;
         if (act) {
-            if (EXT && beyond) rc = TBA_BEYOND_BANDWIDTH;
+            if (EXT && !VER && beyond) rc = TBA_BEYOND_BANDWIDTH;
             else {
                 if (!EXT && beyond) viol_lo = rr;
                 cur_ev = stv[k] + bp;
                 bp_guess = bp;
-                if (EXT && rr - 1 >= cmp_lo && oldv[k] == cur_ev + 1) merged_row = rr - 1;
-                else { tb[rr - 1] = cur_ev + 1; if (EXT && dbg_stores) ++*dbg_stores; }
+                if (VER) { if (oldv[k] != cur_ev + 1) ++*dbg_stores; }
+                else if (EXT && rr - 1 >= cmp_lo && oldv[k] == cur_ev + 1) merged_row = rr - 1;
+                else {
+                    if (EXT) TBP_B_STORE(tb, rr - 1, cur_ev + 1); else tb[rr - 1] = cur_ev + 1;
+                    if (EXT && dbg_stores) ++*dbg_stores;
+                }
             }
         }
     }
+}
+
+// _trim_traceback (resquiggle.py:754-764) and the first base's change point, as k_main_tb (one lane)
+__device__ __forceinline__ void tbp_trim(ReadState &r, i64 *tb, i64 B)
+{
+    const i64 n_ev = r.n_ev - r.clip;
+    volatile i64 *vtb = tb;
+    {
+        i64 i = 0;
+        while (vtb[i] < 0) { vtb[i] = 0; i++; if (i > B) { r.status = TBA_INTERNAL; return; } }
+        i64 j = 1;
+        while (vtb[B + 1 - j] > n_ev) { vtb[B + 1 - j] = n_ev; j++; if (j > B + 1) { r.status = TBA_INTERNAL; return; } }
+    }
+    i64 t0 = vtb[0];
+    if (t0 < 0) t0 += n_ev + 1;
+    r.top_pos = t0;
 }
 
 // LPR lanes per read (a power of two <= 64), 64 / LPR reads per wavefront.  idx != nullptr: the
@@ -166,6 +231,11 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
 {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x, g = lane / LPR, c = lane % LPR, gbase = g * LPR;
+    TBP_NOT_224_VGPRS();
+#ifdef TBA_TB_WAVES1
+    __shared__ volatile int occ_pad[40 * 256];      // (40 KB per one-wavefront workgroup: four wavefronts on a CU)
+    if (n_reads < 0) occ_pad[lane] = lane;
+#endif
     const i64 slot = (i64)blockIdx.x * RPW + g;
     const bool have = slot < n_reads;
     const i64 ri = have ? (idx ? (i64)idx[slot] : slot) : 0;
@@ -207,7 +277,7 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
         bool walking = mine;
         while (__any(walking)) {
             if (walking) {
-                tbp_block<false>(mv, rowb, roww, st, Wi, thresh, r0, lo, cur, guess, rcA, tb, viol_lo, 0, none, strip, strip_s0, n_stat);
+                tbp_block<TBP_A>(mv, rowb, roww, st, Wi, thresh, r0, lo, cur, guess, rcA, tb, viol_lo, 0, none, strip, strip_s0, n_stat);
                 r0 -= TBR;
                 if (rcA != TBA_OK || r0 <= lo) walking = false;
             }
@@ -235,14 +305,23 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
         bool walking = ext;
         if (ext && cur == nxt_start) { merged_row = lo; walking = false; } // (entering row lo = its hi)
         i64 r0 = lo;
+#ifdef TBA_TB_B2
+        if (ext) tb[lo + 2 * TBA_TB_B2_OFF] = cur | ((i64)guess << 40);   // (third array: the state phase B starts from)
+#endif
         while (__any(walking)) {
             if (walking) {
-                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rcB, tb, viol_lo, nxt_wrote_lo, merged_row, strip, strip_s0, n_stat, dbg_stp);
+                tbp_block<TBP_B>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rcB, tb, viol_lo, nxt_wrote_lo, merged_row, strip, strip_s0, n_stat, dbg_stp);
                 r0 -= TBR;
                 if (rcB != TBA_OK || merged_row != TBP_NONE || r0 <= lo2) walking = false;
             }
         }
     }
+#ifdef TBA_TB_INJECT
+    // (test build, libtombo_amd_inject.so: the round-5 fault made deterministic -- the first row under the second
+    // chunk top of every TBA_TB_INJECT-th read comes out one event too high; tests/test_gpu_determinism.py
+    // expects the verifier to catch exactly those reads and the results to be the oracle's all the same)
+    if (ext && c == 1 && lo >= 1 && ri % TBA_TB_INJECT == 3) tb[lo - 1] += 1;
+#endif
 #if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 12
     // per read: 0 lanes that extended, 1 merged at once (state equal on entry), 2 merged later, 3 rows
     // overwritten in phase B, 4 chunks, 5 sum of the rows merged at relative to the chunk top, 6 lanes
@@ -260,7 +339,7 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
 #endif
     // ---- the chain, top down (uniform over the group: every lane runs the same loop)
     int status = TBA_OK;
-    bool broken = false;
+    bool broken = false, from_b = false;            // from_b: the status is a phase B's
     i64 true_from = B + 1;                          // chunk 0: all of phase A is the true walk
     for (int j = 0; j < LPR; j++) {
         const i64 vj = shfl_i64(viol_lo, gbase + j), mj = shfl_i64(merged_row, gbase + j);
@@ -269,62 +348,56 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
         if (vj != TBP_NONE && vj <= true_from) { status = TBA_BEYOND_BANDWIDTH; continue; }
         if (aj != TBA_OK) { status = aj; continue; }
         if (j == n_chunks - 1) continue;            // walked down to row 1: done
-        if (bj != TBA_OK) { status = bj; continue; }
+        if (bj != TBA_OK) { status = bj; from_b = true; continue; }
         if (mj == TBP_NONE) { broken = true; continue; }
         true_from = mj;
     }
-    tbp_fence(); // the lanes' read_tb entries, before lane 0 of the group reads them back
-    if (!on || c != 0 || broken) return;            // (broken: k_main_tb walks this read)
-    r.tb_done = 1;
+    // What rests on a phase B is not final here: an error of one, or a chain without agreement, leaves
+    // the read to the serial kernels (tb_done stays 0, top_pos untouched); a finished chain goes to
+    // k_tb_par_verify (tb_done = 2), which trims.  An error of a phase A on the true path is the
+    // serial walk's own error at that row.
+    if (!on || c != 0 || broken || (status != TBA_OK && from_b)) return;
     r.tb_form = LPR; // TBA_TB_FORM_PAR16 / TBA_TB_FORM_PAR64
-    if (status != TBA_OK) { r.status = status; return; }
-    // _trim_traceback (resquiggle.py:754-764) and the first base's change point, as k_main_tb
-    const i64 n_ev = r.n_ev - r.clip;
-    volatile i64 *vtb = tb;
-    {
-        i64 i = 0;
-        while (vtb[i] < 0) { vtb[i] = 0; i++; if (i > B) { r.status = TBA_INTERNAL; return; } }
-        i64 j = 1;
-        while (vtb[B + 1 - j] > n_ev) { vtb[B + 1 - j] = n_ev; j++; if (j > B + 1) { r.status = TBA_INTERNAL; return; } }
-    }
-    i64 t0 = vtb[0];
-    if (t0 < 0) t0 += n_ev + 1;
-    r.top_pos = t0;
+    if (status != TBA_OK) { r.tb_done = 1; r.status = status; return; }
+#ifndef TBA_NO_TB_VERIFY
+    r.tb_done = 2;
+#else
+    tbp_fence(); // the lanes' read_tb entries, before lane 0 of the group reads them back
+    r.tb_done = 1;
+    tbp_trim(r, tb, B);
+#endif
 }
 
-// Phase B once more, after a kernel boundary.  tools/determinism_probe.py found a handful of wavefronts
-// per 10 000-read RNA batch (never the same ones, never in an instrumented build, with or without the
-// fences above) whose phase B had left the speculative rows under every chunk top standing -- the
-// result then depended on the run.  Phase B is idempotent: the lane of boundary c takes the state
-// entering the top row of chunk c + 1 from the entry above it (the bottom of chunk c: true, by the
-// chain k_main_tb_par checked), walks down, overwrites what differs and stops at the first agreement
-// -- on an intact read that is the first row it looks at (one block of 16 rows per boundary).  Same
-// lanes, same chunk geometry as k_main_tb_par<LPR>; reads it did not finish (tb_done == 0) are
-// k_main_tb's anyway.  Entries the trim may have clamped (at or beyond the last event, at or below 0)
-// are no state to start from: such a boundary is left alone.
+// The verifier, behind the kernel boundary (what the result rests on: top of this file).  Same lanes,
+// same chunk geometry as k_main_tb_par<LPR>, over the reads it finished (tb_done == 2): the lane of
+// boundary c takes the state entering the top row of chunk c + 1 from the entry above it -- the bottom
+// of chunk c, true by the chain -- walks TBR rows down without writing and counts the rows where
+// read_tb holds something else.  Phase B merged within two rows at nearly every boundary and its
+// faults of round 5 sat in its first row, so this covers what phase B wrote; rows it walked beyond
+// the first block (one boundary in ~300) rest on phase B alone.  A read with any disagreement goes
+// back to the serial kernels (tb_done = 0, its count in tb_verify_fail); the others are trimmed here.
 template <int LPR>
-__global__ __launch_bounds__(64) void k_tb_par_repair(ReadState *rs, i64 n_reads, const i32 *idx,
+__global__ __launch_bounds__(64) void k_tb_par_verify(ReadState *rs, i64 n_reads, const i32 *idx,
     const DevParams *dp, const unsigned char *moves, const i64 *band_starts, i64 *read_tb)
 {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x, g = lane / LPR, c = lane % LPR, gbase = g * LPR;
+    TBP_NOT_224_VGPRS();
     const i64 slot = (i64)blockIdx.x * RPW + g;
     const bool have = slot < n_reads;
     const i64 ri = have ? (idx ? (i64)idx[slot] : slot) : 0;
     ReadState &r = rs[ri];
-    const bool on = have && r.status == TBA_OK && r.path == PATH_ADAPTIVE && r.tb_done == 1 && r.tb_form == LPR &&
-                    (idx != nullptr || !r.is_long) && r.B >= 2 && cpl_class(r.W) != 0;
+    const bool on = have && r.status == TBA_OK && r.path == PATH_ADAPTIVE && r.tb_done == 2 && r.tb_form == LPR &&
+                    (idx != nullptr || !r.is_long);
     const i64 B = on ? r.B : 2;
     const int Wi = on ? (int)r.W : 64;
     const int rowb = (int)mv_row_bytes(Wi), roww = rowb / 4;
     const unsigned char *mv = moves + (on ? r.moves_off : 0);
     const i64 *st = band_starts + (on ? r.ref_off : 0);
     i64 *tb = read_tb + (on ? r.seg_off : 0);
-    const int thresh = (int)dp->p.band_bound_thresh;
     const int strip_s0 = on ? r.strip_s0 : -1;
     const unsigned char *strip = mv + (B + 1) * (i64)rowb;
     const i64 n_stat = on ? r.n_static : 0;
-    const i64 n_ev = on ? r.n_ev - r.clip : 0;
     i64 top_rows = B - ((on ? r.n_static : 0) + 16);   // (the chunk geometry of k_main_tb_par)
     top_rows = top_rows < 1 ? 1 : top_rows;
     i64 L = (top_rows + LPR - 1) / LPR;
@@ -332,35 +405,25 @@ __global__ __launch_bounds__(64) void k_tb_par_repair(ReadState *rs, i64 n_reads
     const int n_chunks = (int)((top_rows + L - 1) / L);
     const i64 hi = B - (i64)c * L, lo = c >= n_chunks - 1 || hi - L < 0 ? 0 : hi - L;
     const i64 lo2 = c + 1 >= n_chunks - 1 || lo - L < 0 ? 0 : lo - L;
-    bool ext = on && c + 1 < n_chunks && lo >= 1;
-    i64 cur = 0;
-    if (ext) {
-        const i64 above = tb[lo];                       // recorded after row lo + 1: the state entering row lo, + 1
-        if (above <= 0 || above >= n_ev) ext = false;   // (possibly clamped by the trim)
-        cur = above - 1;
-    }
-    int guess = Wi / 2, rc = TBA_OK;
+    const bool ext = on && c + 1 < n_chunks && lo >= 1;
+    i64 cur = ext ? tb[lo] - 1 : 0;                 // recorded after row lo + 1: the state entering row lo, + 1
+    int guess = Wi / 2, rc = TBA_OK, n_diff = 0;
     if (ext) {
         const i64 g0 = cur - st[lo - 1];
         guess = g0 < 0 ? 0 : (g0 >= Wi ? Wi - 1 : (int)g0);
     }
-    i64 merged_row = TBP_NONE, viol = TBP_NONE;
-    {
-        bool walking = ext;
-        i64 r0 = lo;
-        while (__any(walking)) {
-            if (walking) {
-                tbp_block<true>(mv, rowb, roww, st, Wi, thresh, r0, lo2, cur, guess, rc, tb, viol, 0, merged_row, strip, strip_s0, n_stat);
-                r0 -= TBR;
-                if (rc != TBA_OK || merged_row != TBP_NONE || r0 <= lo2) walking = false;
-            }
-        }
+    i64 none = TBP_NONE, viol = TBP_NONE;
+    if (ext) tbp_block<TBP_V>(mv, rowb, roww, st, Wi, -1, lo, lo2, cur, guess, rc, tb, viol, 0, none, strip, strip_s0, n_stat, &n_diff);
+    if (ext && rc != TBA_OK) n_diff++;              // (a walk that died where phase B's did not)
+    int total = 0;
+    for (int j = 0; j < LPR; j++) total += __shfl(n_diff, gbase + j, 64);
+    if (!on || c != 0) return;
+    if (total != 0) {                               // the serial kernels walk this read from top_pos, untouched so far
+        r.tb_verify_fail = total;
+        r.tb_done = 0;
+        r.tb_form = TBA_TB_FORM_NONE;
+        return;
     }
-    // the first error in walk order (the lowest chunk index) is the read's
-    int err = ext ? (rc != TBA_OK ? rc : (merged_row == TBP_NONE ? TBA_INTERNAL : 0)) : 0, first_err = 0;
-    for (int j = 0; j < LPR; j++) {
-        const int ej = __shfl(err, gbase + j, 64);
-        if (first_err == 0 && ej != 0) first_err = ej;
-    }
-    if (on && c == 0 && first_err != 0) r.status = first_err;
+    r.tb_done = 1;
+    tbp_trim(r, tb, B);
 }

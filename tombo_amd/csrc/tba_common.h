@@ -54,11 +54,13 @@ struct ReadState {
     i32 is_long;              // more than TBA_LONG_RAW samples or TBA_LONG_BASES bases (k_long.h)
     double shift, scale, lower, upper; // scale values in force after segment_signal
     i32 has_lims;
-    i32 tb_done;              // the main traceback of this read is finished (k_tb_par.h)
+    i32 tb_done;              // main traceback: 0 to be walked by the serial kernels, 2 walked chunk-parallel and awaiting
+                              // k_tb_par_verify, 1 finished (k_tb_par.h)
     i32 ed_flag, dp_wg; // dp_wg: the main forward pass was run by a workgroup (k_dp_wgm.h)        // event detection: 1 = this read needs the kernels that keep the scores (k_detect.h)
     i32 ed_form, tb_form;     // which kernels produced this read's change points / main traceback
     i32 strip_s0;             // first band cell of the centre strip k_dp keeps beside the move rows (-1: none; k_dp.h)
     i32 bad_seq;              // k_ref_levels on the side stream found a base outside ACGT (applied in stage order: k_seq_status)
+    i32 tb_verify_fail, pad1; // rows where k_tb_par_verify disagreed with the chunk-parallel traceback (k_tb_par.h; 0 expected)
                               // (TBA_ED_FORM_* / TBA_TB_FORM_*, include/tombo_amd.h: TBA_GET_ED_FORM / TBA_GET_TB_FORM)
     i64 n_taken;              // entries of the taken (score, position) list k_detect left
     double ed_min, ed_max;    // ... and the range of its scores
@@ -143,15 +145,19 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
 // entries between the lanes of a read; k_skip_dp_wave: the boundaries lane 0 found).
 // __threadfence_block() / __syncthreads() are not the fence for that in a workgroup of a single
 // wavefront: the compiler narrows workgroup scope to wavefront scope and emits NOTHING -- no s_waitcnt
-// between the stores and the loads that follow (seen in the ISA) -- and the hardware does not order one
-// lane's load behind another lane's earlier store.  Found in round 5 by tools/determinism_probe.py: a
-// handful of wavefronts per 10 000-read RNA batch compared their traceback state with what read_tb held
-// BEFORE the lane below wrote it (the previous run's finished path: "equal", merged at once, the
-// speculative rows under every chunk top left standing), differently from run to run.
-// All stores performed, then the vector L1 dropped, whatever the scope analysis thinks:
+// between the stores and the loads that follow (seen in the ISA).  This one is explicit: all stores
+// performed, then the vector L1 dropped.  It is hygiene, not a cure: the run-dependent traceback of
+// round 5 was first blamed on this handoff, and round 6 showed that it was not -- the same failures with
+// this fence, with a poisoned read_tb and with system-coherent loads; the lanes entered phase B with
+// identical states and COMPUTED different rows, as a function of the kernel's VGPR allocation
+// (profiles/r06_traceback_rootcause.txt).
 __device__ __forceinline__ void wave_mem_fence()
 {
+#if defined(__gfx942__) || defined(__gfx950__)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+#else
+    __threadfence();
+#endif
 }
 
 // whole-wave shift by one lane on the DPP crossbar (no LDS round trip): lane i <- lane i-1 /

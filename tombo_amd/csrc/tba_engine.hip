@@ -377,7 +377,11 @@ static void for_each_batch_buffer(tba_engine *e, const tba_params *p, const tba_
     BUF(d_bst, Bt * 8);
     BUF(d_lo, Bt * 4);
     BUF(d_hi, Bt * 4);
+#ifdef TBA_TB_B2
+    BUF(d_readtb, (Bt + N) * 8 * 3);
+#else
     BUF(d_readtb, (Bt + N) * 8);
+#endif
     BUF(d_dpsegs, (Bt + N) * 8);
     BUF(d_segs, (Bt + N) * 8);
     BUF(d_win, (Bt + N) * 24);
@@ -814,18 +818,27 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         // rows of a read over several lanes (k_tb_par.h): 16 lanes per read when the reads fill the
         // machine, a wavefront per read for small batches and for the long reads; what it leaves
         // (static bands, failed verification) is walked by the lane-per-read kernels below
+#ifdef TBA_TB_POISON
+        // (experiment build: read_tb holds the previous run's finished paths -- take them away, so that nothing
+        // stale can compare equal; profiles/r06_traceback_rootcause.txt)
+        HIP_TRY(hipMemsetAsync(e->d_readtb.p, 0xFF, (size_t)(e->B_tot + e->n_reads) * 8, s));
+#endif
+#ifdef TBA_TB_B2
+        {   // (experiment build: d_readtb is three arrays long -- read_tb, phase B's stores, phase B's entry states)
+            const i64 off_words = (i64)(e->B_tot + e->n_reads);
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(TBA_TB_B2_OFF), &off_words, sizeof(off_words)));
+            HIP_TRY(hipMemsetAsync(e->d_readtb.as<i64>() + off_words, 0xFF, (size_t)off_words * 16, s));
+        }
+#endif
         if (n > e->tb_wave_below) k_main_tb_par<16><<<(unsigned)((n + 3) / 4), 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         else k_main_tb_par<64><<<nb, 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
         if (e->n_long > 0 && n > e->tb_wave_below) k_main_tb_par<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
-#ifndef TBA_NO_TB_REPAIR
-        // phase B again, behind a kernel boundary (k_tb_par.h: what the determinism probe found) -- twice:
-        // the failure recurs on the same few wavefronts, so one more pass squares a per-wavefront rate that
-        // is not small for those; a pass over an intact read looks at one block of rows per chunk top (70 us)
-        for (int pass = 0; pass < 2; pass++) {
-        if (n > e->tb_wave_below) k_tb_par_repair<16><<<(unsigned)((n + 3) / 4), 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
-        else k_tb_par_repair<64><<<nb, 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
-        if (e->n_long > 0 && n > e->tb_wave_below) k_tb_par_repair<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
-        }
+#ifndef TBA_NO_TB_VERIFY
+        // behind the kernel boundary: the first block of rows under every chunk top walked again, compare
+        // only; what disagrees is the serial kernels' (counted: TBA_GET_TB_VERIFY_FAIL), the rest is trimmed
+        if (n > e->tb_wave_below) k_tb_par_verify<16><<<(unsigned)((n + 3) / 4), 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        else k_tb_par_verify<64><<<nb, 64, 0, s>>>(rs, n, nullptr, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
+        if (e->n_long > 0 && n > e->tb_wave_below) k_tb_par_verify<64><<<(unsigned)e->n_long, 64, 0, s>>>(rs, e->n_long, e->d_long.as<i32>(), dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
 #endif
 #endif
         k_main_tb<<<(unsigned)((n + TB_LANES - 1) / TB_LANES), TB_LANES, 0, s>>>(rs, n, dp, e->d_moves.as<unsigned char>(), e->d_bst.as<i64>(), e->d_readtb.as<i64>());
@@ -1085,6 +1098,13 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
         HIP_TRY(hipMemcpy(rs.data(), e->d_rs.p, N * sizeof(ReadState), hipMemcpyDeviceToHost));
         return 0;
     };
+#ifdef TBA_TB_B2
+    if (what == 97) { // phase B's second and third array (experiment build)
+        const size_t words = (size_t)(e->B_tot + e->n_reads);
+        HIP_TRY(hipMemcpy(out, e->d_readtb.as<i64>() + words, std::min((size_t)out_bytes, words * 16), hipMemcpyDeviceToHost));
+        return 0;
+    }
+#endif
     switch (what) {
     case TBA_GET_VALID_CPTS: return copy(e->d_cpts, (size_t)e->E_tot * 8);
     case TBA_GET_EVENT_MEANS: return copy(e->d_evm, (size_t)e->E_tot * 8);
@@ -1130,9 +1150,10 @@ extern "C" int tba_batch_get(tba_engine *e, int what, void *out, int64_t out_byt
         for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = rs[i].tb_done;
         return 0;
     }
-    if (what == TBA_GET_ED_FORM || what == TBA_GET_TB_FORM) {
+    if (what == TBA_GET_ED_FORM || what == TBA_GET_TB_FORM || what == TBA_GET_TB_VERIFY_FAIL) {
         if ((size_t)out_bytes < N * 4) return set_err(TBA_E_ARG, "output buffer too small");
-        for (size_t i = 0; i < N; i++) ((i32 *)out)[i] = what == TBA_GET_ED_FORM ? rs[i].ed_form : rs[i].tb_form;
+        for (size_t i = 0; i < N; i++)
+            ((i32 *)out)[i] = what == TBA_GET_ED_FORM ? rs[i].ed_form : what == TBA_GET_TB_FORM ? rs[i].tb_form : rs[i].tb_verify_fail;
         return 0;
     }
     if (what == TBA_GET_DP_WORKGROUP) {

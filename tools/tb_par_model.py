@@ -43,12 +43,14 @@ def serial(tb, starts, top_pos, thresh=-1):
 
 
 def chunk_parallel(tb, starts, top_pos, lanes=16, thresh=-1, min_chunk=64, start_cell=None, n_static=100,
-                   fail_phase_b=()):
-    """returns (rc, read_tb, info); rc None = the chain broke (the kernel leaves the read to the
-    serial walk).  n_static: rows with a static band at the start of the read (the path is anywhere
-    in those bands, so they all go to the lowest chunk).  fail_phase_b: chunks whose lane's phase B
-    ends on its first compare as if it had found agreement there (the failure the round-5 determinism
-    probe found on the GPU: the speculative rows under the next chunk's top stay) -- see `repair`"""
+                   fail_phase_b=(), first_row_plus_one=()):
+    """k_main_tb_par: returns (rc, read_tb, info); rc None = the read is left to the serial walk (the chain
+    broke, or its status would rest on a phase B: an error of one).  n_static: rows with a static band at
+    the start of the read (the path is anywhere in those bands, so they all go to the lowest chunk).
+    Faults, for the verifier's test (`verify`): fail_phase_b -- chunks whose lane's phase B ends on its first
+    compare as if it had found agreement there (what round 5 took the GPU's failure for);
+    first_row_plus_one -- chunks whose lane's phase B comes out of its first row one event too high and walks
+    on from there (what the failure was: profiles/r06_traceback_rootcause.txt)"""
     B, bw = tb.shape[0] - 1, tb.shape[1]
     top_rows = max(B - (n_static + 16), 1)
     L = max((top_rows + lanes - 1) // lanes, min_chunk)
@@ -87,6 +89,8 @@ def chunk_parallel(tb, starts, top_pos, lanes=16, thresh=-1, min_chunk=64, start
             if rc or viol:
                 rcB[c] = rc if rc else BEYOND
                 break
+            if rr == lo[c] and c in first_row_plus_one:
+                nxt += 1
             cur[c] = nxt
             if rr - 1 >= wrote_lo[c + 1] and rec[rr - 1] == nxt + 1:
                 merged[c] = rr - 1
@@ -104,20 +108,16 @@ def chunk_parallel(tb, starts, top_pos, lanes=16, thresh=-1, min_chunk=64, start
             break
         if j == n_chunks - 1:
             break
-        if rcB[j]:
-            status = rcB[j]
-            break
-        if merged[j] == NONE:
+        if rcB[j] or merged[j] == NONE:
             return None, out, dict(merge_rows=merge_rows)
         true_from = merged[j]
     return status, out, dict(merge_rows=merge_rows, chunk=L, n_chunks=n_chunks)
 
 
-def repair(tb, starts, out, lanes=16, thresh=-1, min_chunk=64, n_static=100, n_ev=None):
-    """k_tb_par_repair: phase B once more over a finished read_tb (`out`, modified in place).  The lane
-    of every chunk boundary takes the state entering the top row of the next chunk from the entry above
-    it, walks down, overwrites what differs and stops at the first agreement.  Returns (rc, rows
-    overwritten): rc INTERNAL when a lane finds no agreement inside the next chunk."""
+def verify(tb, starts, out, lanes=16, min_chunk=64, n_static=100, rows=16):
+    """k_tb_par_verify: under every chunk top the first `rows` rows are walked again from the entry above the
+    top (compare only).  Returns the number of rows where `out` holds something else; the kernel sends a read
+    with a non-zero count to the serial walk."""
     B, bw = tb.shape[0] - 1, tb.shape[1]
     top_rows = max(B - (n_static + 16), 1)
     L = max((top_rows + lanes - 1) // lanes, min_chunk)
@@ -125,25 +125,31 @@ def repair(tb, starts, out, lanes=16, thresh=-1, min_chunk=64, n_static=100, n_e
     hi = [B - c * L for c in range(n_chunks)]
     lo = [max(h - L, 0) for h in hi]
     lo[-1] = 0
-    n_over, status = 0, OK
-    rec = out.copy()                               # (the lanes run side by side: each compares with what was there)
+    n_diff = 0
     for c in range(n_chunks - 1):
-        above = int(rec[lo[c]])
-        if above <= 0 or (n_ev is not None and above >= n_ev):
-            continue                               # possibly clamped by the trim: no state to start from
-        cur, found = above - 1, False
-        for rr in range(lo[c], lo[c + 1], -1):
-            rc, cur, viol = _step(tb, starts, bw, rr, cur, thresh)
-            if rc or viol:
-                return (rc if rc else BEYOND), n_over
-            if rec[rr - 1] == cur + 1:
-                found = True
+        if lo[c] < 1:
+            continue
+        cur = int(out[lo[c]]) - 1
+        for rr in range(lo[c], max(lo[c] - rows, lo[c + 1]), -1):
+            rc, cur, _ = _step(tb, starts, bw, rr, cur, -1)
+            if rc:
+                n_diff += 1
                 break
-            out[rr - 1] = cur + 1
-            n_over += 1
-        if not found and status == OK:
-            status = INTERNAL
-    return status, n_over
+            if out[rr - 1] != cur + 1:
+                n_diff += 1
+    return n_diff
+
+
+def traceback(tb, starts, top_pos, lanes=16, thresh=-1, **faults):
+    """what the engine does with a read: chunk-parallel walk, verifier, serial walk where either gives the read
+    back.  Returns (rc, read_tb, how) with how in 'parallel', 'serial: left by the parallel walk',
+    'serial: verifier'."""
+    rc, out, _ = chunk_parallel(tb, starts, top_pos, lanes, thresh, **faults)
+    if rc is None:
+        return serial(tb, starts, top_pos, thresh) + ('serial: left by the parallel walk',)
+    if rc == OK and verify(tb, starts, out, lanes):
+        return serial(tb, starts, top_pos, thresh) + ('serial: verifier',)
+    return rc, out, 'parallel'
 
 
 def forward(n_bases=1500, bw=200, seed=0, static_rows=100):
