@@ -42,7 +42,9 @@ __global__ void k_c_div_check(const double *a, const double *b, i64 n, double *o
 {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         const double y = 1.0 / b[i];
-        out[i] = div_by_recip(a[i], b[i], y);
+        const double q5 = div_by_recip(a[i], b[i], y), q4 = div_by_recip2(a[i], b[i], y, recip_low(b[i], y));
+        // (both forms: a disagreement between them comes out as a NaN, which equals no quotient)
+        out[i] = q5 == q4 || (q5 != q5 && q4 != q4) ? q4 : __longlong_as_double(0x7ff8000000000bad);
     }
 }
 

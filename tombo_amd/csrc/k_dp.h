@@ -305,6 +305,11 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
 #else
     __shared__ double ring[RING + CPL];      // + mirror of the first CPL slots: reads never wrap
 #endif
+#ifdef TBA_DP_VGPR_PAD
+    // experiment (profiles/r06_coresidency_ab.txt): a named clobber raises the kernel's VGPR allocation -- "v135": 136
+    // registers, three wavefronts on a SIMD and 104 registers left for another stream's kernels, LDS untouched
+    asm volatile("" ::: TBA_DP_VGPR_PAD);
+#endif
     ReadState &r = rs[DIRECT ? 0 : blockIdx.x];
     if (!DIRECT && r.status != TBA_OK) return;
     const tba_params &P = dp->p;
@@ -466,12 +471,19 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
 
     // expected level, sd and its reciprocal of 64 rows at a time: lane l holds row blk0 + l
     // (one coalesced load and one true division per 64 rows), a row reads its lane
+#ifndef TBA_DP_DIV4
     double mu_v = 0, sd_v = 1, y_v = 1;
+#else
+    double mu_v = 0, sd_v = 1, y_v = 1, yl_v = 0;   // (yl_v: the low word of the reciprocal, div_by_recip2)
+#endif
     auto load_levels = [&](int first) {
         int rc = first + lane;
         rc = rc < n_rows ? rc : n_rows - 1;
         mu_v = rmu[rc]; sd_v = rsd[rc];
         y_v = 1.0 / sd_v;
+#ifdef TBA_DP_DIV4
+        yl_v = recip_low(sd_v, y_v);
+#endif
         // the loads end HERE, once per 64 rows: left pending, the rows' read of these registers
         // sits behind a conditional load and the compiler guards it with s_waitcnt vmcnt(0) in
         // EVERY row (which on gfx9 also waits for the previous row's stores)
@@ -517,10 +529,16 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
     auto row_step = [&](const int row, auto adapt_tag) __attribute__((always_inline)) -> bool {
         constexpr bool ADAPT = decltype(adapt_tag)::value;
         double mu = 0, sd = 1, y = 1;
+#ifdef TBA_DP_DIV4
+        double yl = 0;
+#endif
         if (!use_z) {
             const int sel = (row - row0) & 63;
             if (sel == 0 && row != row0) load_levels(row);
             mu = readlane_f64(mu_v, sel); sd = readlane_f64(sd_v, sel); y = readlane_f64(y_v, sel);
+#ifdef TBA_DP_DIV4
+            yl = readlane_f64(yl_v, sel);
+#endif
         }
         int cur_start;
         int lo, hi;
@@ -568,7 +586,11 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
             const double *er = ring + ((cur_start + RING + b0) & (RING - 1)); // + j < RING + CPL
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
+#ifndef TBA_DP_DIV4
                 double pz = fabs(div_by_recip(er[j] - mu, sd, y));
+#else
+                double pz = fabs(div_by_recip2(er[j] - mu, sd, y, yl));
+#endif
                 pz = __builtin_fmin(pz, zcap);
                 z[j] = zs[j] - pz; // cells past the band: -inf - pz = -inf, stays -inf for good
             }

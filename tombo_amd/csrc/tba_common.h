@@ -141,6 +141,24 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
     return __builtin_fma(e, y, q);
 }
 
+// The same quotient in FOUR instructions, for a divisor whose reciprocal is kept as a pair (k_dp: per row):
+// yh = RN(1/b), yl = RN(RN(1 - b yh) yh) -- 1 - b yh is exact in an fma, so yh + yl = 1/b to 2^-105.
+// q0 = RN(a yh + RN(a yl)) is then within half an ulp + 2^-104 of a/b: faithful at once, and Markstein's
+// correction (r = a - b q0 exact, RN(q0 + r yh) = RN(a/b)) finishes it -- one correction round less than
+// div_by_recip.  Not three instructions: a quotient of two doubles can sit 2^-107 from a rounding
+// boundary, closer than q0's error bound.  100 M random and edge quotients equal a / b on the host
+// (gcc fma), and tests/test_gpu_kernel_abi.py::test_row_constant_division_is_ieee holds both forms.
+// k_dp uses it under -DTBA_DP_DIV4 only: eight float64 instructions less per row and two v_readlane
+// more came out 1.0 ms SLOWER on cfg2 (profiles/r06_k_dp_division_ab.txt).
+__device__ __forceinline__ double div_by_recip2(double a, double b, double yh, double yl)
+{
+    const double p = a * yl;
+    const double q = __builtin_fma(a, yh, p);
+    const double e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, yh, q);
+}
+__device__ __forceinline__ double recip_low(double b, double yh) { return __builtin_fma(-b, yh, 1.0) * yh; }
+
 // Lanes of ONE wavefront handing values to each other through GLOBAL memory (k_main_tb_par: read_tb
 // entries between the lanes of a read; k_skip_dp_wave: the boundaries lane 0 found).
 // __threadfence_block() / __syncthreads() are not the fence for that in a workgroup of a single
