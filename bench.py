@@ -860,6 +860,8 @@ def main():
         d = engines[0].get(_native.GET_DEBUG_COUNTERS)
         print('dbg mean', ' '.join('%.1f' % x for x in d.mean(axis=0)), file=sys.stderr)
         print('dbg median', ' '.join(str(int(x)) for x in np.median(d, axis=0)), file=sys.stderr)
+        print('dbg max', ' '.join(str(int(x)) for x in d.max(axis=0)), file=sys.stderr)
+        print('dbg p99', ' '.join(str(int(x)) for x in np.percentile(d, 99, axis=0)), file=sys.stderr)
     stage /= max(my_steps, 1)
     # a second figure, not `value`: TWO resident batches (the same reads uploaded twice) whose passes
     # alternate on two engines / streams, the next pass enqueued before the previous one is waited

@@ -79,14 +79,27 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
             const double *__restrict__ pf = fwr + (i - 1) * len;
             double *__restrict__ bf = fwr + i * len;
             double stay = 0;
-            for (i64 k = 0; k < len; k++) {
-                double zv = (x[k] - mu) / sd;
-                if (zv > 0) zv = -zv;
-                if (winsor && zv < -mh) zv = -mh;
-                const double diag = pf[k];
-                const double best = (k == 0 || diag > stay) ? diag : stay;
-                stay = zv + best;
-                bf[k] = stay;
+            // (eight positions' loads in flight together: the few windows left to this path are the longest ones, and
+            // a load -> use loop pays a memory round trip per position)
+            for (i64 k0 = 0; k0 < len; k0 += 8) {
+                double xv[8], dg[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const i64 kk = k0 + u < len ? k0 + u : len - 1;
+                    xv[u] = x[kk]; dg[u] = pf[kk];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const i64 k = k0 + u;
+                    if (k < len) {
+                        double zv = (xv[u] - mu) / sd;
+                        if (zv > 0) zv = -zv;
+                        if (winsor && zv < -mh) zv = -mh;
+                        const double best = (k == 0 || dg[u] > stay) ? dg[u] : stay;
+                        stay = zv + best;
+                        bf[k] = stay;
+                    }
+                }
             }
         }
         i64 sig_start = (n - 1) + len - 1; // raw_traceback / c_base_traceback, pyx:165-182
@@ -179,6 +192,118 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
     return TBA_OK;
 }
 
+// The DNA windows (raw_min_obs_per_base = 1) of the lane-per-window kernel out of LDS.  A window keeps ONE forward
+// row, updated in place, and one bit per (base, position) for the traceback: row i at position k needs fwd[i-1][k]
+// (what the slot holds) and its own previous position (a register), and the traceback's test
+// "fwd[b-1][j+1] > fwd[b][j]" (pyx:176-180) is the very compare that picked `diag` over `stay` at position j + 1, so
+// it is kept as bit j while the row is made.  Same arithmetic in the same order as raw_window_dp's m == 1 path
+// (the division by the base's sd through div_by_recip: IEEE, tba_common.h); what it no longer does is write every
+// forward row to global scratch and read it back (5.3 GB per cfg2 batch, three 64-line memory instructions per
+// position).  Two layouts of the same function (rp / rs: row slot k at rp[k * rs]; fp / fs / words: flag word w of
+// base i at fp[(i * words + w) * fs]):
+//   column -- the windows of at most SKL_N bases over an admissible interval of at most SKL_LEN samples, 97 % of the
+//     ~57 windows of a 10 kb read (mean 5 bases x 25 samples): all lanes at once, lane l in column l of
+//     row[k][l] (conflict-free), one flag word per base;
+//   flat -- the few larger ones, afterwards, up to SKL_FLAT_N at a time: a lane takes a quarter of the same LDS as
+//     a flat row of up to SKL_FLAT_LEN slots and a quarter of the flag words.
+// Anything larger still goes through global scratch (raw_window_dp).
+#define SKL_LEN 56   // (+ 8 slots a batch of eight positions may run past the interval's end: 32 KB, four wavefronts per CU)
+#define SKL_N 16
+#define SKL_FLAT_N 4
+#define SKL_FLAT_LEN ((SKL_LEN + 8) * 64 / SKL_FLAT_N - 8)   // 1016 samples
+#define SKL_FLAT_WORDS (SKL_N * 64 / SKL_FLAT_N)            // 256 flag words: bases x ceil(len / 64)
+struct SkipLaneSmem {
+    double row[SKL_LEN + 8][64];
+    u64 flag[SKL_N][64];
+};
+__device__ __forceinline__ int raw_window_dp_lane_lds(const double *sig, int len, const double *means,
+    const double *sds, int n, bool winsor, double mh, double *rp, int rs, u64 *fp, int fs, int words, i64 *new_segs)
+{
+    auto zscore = [&](double x, double mu, double sd, double y) { // c_base_z_scores, pyx:17-32
+        double zv = div_by_recip(x - mu, sd, y);
+        if (zv > 0) zv = -zv;
+        if (winsor && zv < -mh) zv = -mh;
+        return zv;
+    };
+    // Eight positions at a time, the samples of the NEXT eight already on their way: a lane's window lies anywhere
+    // in the read, so a sample load is a 64-line memory instruction with a round trip of a few thousand cycles at
+    // this kernel's occupancy (four wavefronts per CU) -- a step-by-step loop paid it per position (820 cycles per
+    // position measured, -DTBA_PHASE_DEBUG=13).  The z-scores of a batch follow side by side; only the max-add
+    // chain is serial.  No test of k < len inside a batch (a lone exec-mask branch per position costs more than the
+    // position): what runs past the interval's end lands in the spare slots behind it and in registers after their
+    // last use.
+    auto fetch8 = [&](const double *x, int k0, double *xv) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) xv[u] = x[k0 + u < len ? k0 + u : len - 1];
+    };
+    double xn[8];
+    fetch8(sig, 0, xn);
+    {
+        const double mu = means[0], sd = sds[0], y = 1.0 / sd;
+        double acc = 0;
+        for (int k0 = 0; k0 < len; k0 += 8) { // first row: np.cumsum (resquiggle.py:352-361)
+            double xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) xv[u] = xn[u];
+            if (k0 + 8 < len) fetch8(sig, k0 + 8, xn); else if (n > 1) fetch8(sig + 1, 0, xn);
+#pragma unroll
+            for (int u = 0; u < 8; u++) xv[u] = zscore(xv[u], mu, sd, y);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc = k0 + u == 0 ? xv[u] : acc + xv[u];
+                rp[(k0 + u) * rs] = acc;
+            }
+        }
+    }
+    for (int i = 1; i < n; i++) {
+        const double mu = means[i], sd = sds[i], y = 1.0 / sd;
+        const double *__restrict__ x = sig + i;
+        double stay = 0;
+        u64 bits = 0;
+        int w_done = -1;                              // last flag word of this base already written
+        for (int k0 = 0; k0 < len; k0 += 8) {
+            double xv[8], dg[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { xv[u] = xn[u]; dg[u] = rp[(k0 + u) * rs]; }
+            if (k0 + 8 < len) fetch8(x, k0 + 8, xn); else if (i + 1 < n) fetch8(x + 1, 0, xn);
+#pragma unroll
+            for (int u = 0; u < 8; u++) xv[u] = zscore(xv[u], mu, sd, y);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + u;
+                const bool take = k == 0 || dg[u] > stay;
+                bits |= (u64)(take && k > 0 && k < len) << ((k - 1) & 63);
+                stay = xv[u] + (take ? dg[u] : stay);
+                rp[k * rs] = stay;
+                // (position k0 carries bit k0 - 1: at a multiple of 64 that is the last bit of the finished word)
+                if (u == 0 && k0 > 0 && (k0 & 63) == 0) { w_done = (k0 >> 6) - 1; fp[(i * words + w_done) * fs] = bits; bits = 0; }
+            }
+        }
+        if (len >= 2 && ((len - 2) >> 6) > w_done) fp[(i * words + ((len - 2) >> 6)) * fs] = bits;
+    }
+    // raw_traceback / c_base_traceback (pyx:165-182) in the closed form of raw_window_dp_wave
+    i64 sig_start = (n - 1) + len - 1;
+    for (int b = n - 1; b >= 1; b--) {
+        const i64 cs = b, ne = (b - 1) + len;
+        const i64 st = sig_start < ne ? sig_start : ne;
+        i64 found;
+        if (st < 0) return TBA_INTERNAL;
+        if (st <= cs) found = st;
+        else {
+            found = cs;
+            const i64 j = st - cs - 1;                // highest candidate flag (j <= len - 2)
+            for (i64 w0 = j >> 6; w0 >= 0; w0--) {
+                u64 v = fp[(b * words + w0) * fs];
+                if (w0 == (j >> 6) && (j & 63) != 63) v &= (1ull << ((j & 63) + 1)) - 1ull;
+                if (v) { found = cs + 1 + w0 * 64 + (63 - __clzll((long long)v)); break; }
+            }
+        }
+        new_segs[b - 1] = found;
+        sig_start = found - 1;
+    }
+    return TBA_OK;
+}
+
 // get_deletion_windows (resquiggle.py:462-498) + per-window scratch sizing; one thread per read.
 // win[3*k..] = (start, end, scratch offset inside the read's slice); r.n_win, r.skip_off (need,
 // turned into an arena offset by k_scan_skip).
@@ -212,17 +337,28 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
     const i64 m = dp->p.raw_min_obs_per_base;
     const i64 n_segs = r.B + 1;
     const i64 *ds = dp_segs + r.seg_off;
-    // the resolved boundaries start as a copy; the window kernels overwrite their interiors
-    for (i64 i = lane; i < n_segs; i += 64) segs_out[r.seg_off + i] = ds[i];
-    // skipped bases (diff(segs) == 0), found by all lanes, kept in order behind the window area
+    // the resolved boundaries start as a copy; the window kernels overwrite their interiors.  The same pass finds the
+    // skipped bases (diff(segs) == 0), kept in order behind the window area.  Eight strides of loads in flight: one
+    // wavefront per read, and a load -> use loop of 157 steps pays 157 memory round trips (half of this kernel).
     i64 *dels = win_scratch + 3 * r.seg_off + 2 * n_segs;
     i64 n_del = 0;
-    for (i64 base = 0; base + 1 < n_segs; base += 64) {
-        const i64 d = base + lane;
-        const bool flag = d + 1 < n_segs && ds[d + 1] == ds[d];
-        const u64 mask = __ballot(flag);
-        if (flag) dels[n_del + __popcll(mask & ((1ull << lane) - 1ull))] = d;
-        n_del += __popcll(mask);
+    for (i64 base = 0; base < n_segs; base += 64 * 8) {
+        i64 a8[8], b8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i64 d = base + 64 * u + lane;
+            a8[u] = ds[d < n_segs ? d : n_segs - 1];
+            b8[u] = ds[d + 1 < n_segs ? d + 1 : n_segs - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i64 d = base + 64 * u + lane;
+            if (d < n_segs) segs_out[r.seg_off + d] = a8[u];
+            const bool flag = d + 1 < n_segs && b8[u] == a8[u];
+            const u64 mask = __ballot(flag);
+            if (flag) dels[n_del + __popcll(mask & ((1ull << lane) - 1ull))] = d;
+            n_del += __popcll(mask);
+        }
     }
     __syncthreads();
     if (lane != 0) return;
@@ -280,6 +416,8 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
         if (len <= 0 || n < 2) { r.status = TBA_INTERNAL; return; }
         const i64 fw = n * ((len + 63) / 64);
         int cls = -1;
+        if (m == 1 && len <= SKL_LEN && n <= SKL_N) { w3[3 * i + 2] = -2; continue; } // k_skip_dp out of LDS: column
+        if (m == 1 && len <= SKL_FLAT_LEN && n * ((len + 63) / 64) <= SKL_FLAT_WORDS) { w3[3 * i + 2] = -3; continue; } // flat
         if (m > 1 && n * len >= SKIP_WAVE_MIN) {
             // (L = len + (n - 1) m must fit the staged signal, n the staged levels)
             const bool fits = (n - 1) * m <= 512 && n <= 256;
@@ -549,6 +687,7 @@ __global__ __launch_bounds__(64) void k_skip_dp_wave(ReadState *rs, const DevPar
 
 // rq.resolve_skipped_bases_with_raw window loop + final checks (resquiggle.py:500-538).
 // One wavefront per read, one window per lane at a time (windows own disjoint boundary ranges).
+template <bool DNA_LDS> // raw_min_obs_per_base == 1: the windows k_skip_plan marked -2 run out of LDS
 __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *dp,
     const double *norm, const double *ref_means, const double *ref_sds, const i64 *dp_segs,
     i64 *segs, const i64 *win_scratch, double *arena)
@@ -569,17 +708,76 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
     // over global scratch, and the final checks)
     const i64 *w3 = win_scratch + 3 * r.seg_off;
     int rc = TBA_OK;
-    for (i64 i = lane; i < r.n_win; i += 64) {
-        if (w3[3 * i + 2] < 0) continue;
+#if TBA_PHASE_DEBUG_OR0 == 13
+    // -DTBA_PHASE_DEBUG=13: cycles of the wavefront (0 whole kernel, 1 its window loops, 2 the column phase, 3 the flat
+    // phase, 6 windows)
+    const i64 pt0 = (i64)__builtin_readcyclecounter();
+    i64 pc_lds = 0, pc_arena = 0;
+#endif
+    if constexpr (DNA_LDS) {
+        __shared__ SkipLaneSmem S_;
+        const bool winsor = P.do_winsorize_z != 0;
+        // phase 1: the small windows, every lane in its column
+        for (i64 i = lane; i < r.n_win && rc == TBA_OK; i += 64) {
+            if (w3[3 * i + 2] != -2) continue;
+            const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
+            const i64 sig_start = ds[s], sig_end = ds[e];
+            if (sig_start < 0 || sig_end > n_norm) { rc = TBA_INTERNAL; break; }
+            const int rr = raw_window_dp_lane_lds(sig + sig_start, (int)(sig_end - sig_start - (n - 1)), mu + s, sd + s, (int)n,
+                                                  winsor, P.max_half_z_score, &S_.row[0][lane], 64, &S_.flag[0][lane], 64, 1, out + s + 1);
+            if (rr != TBA_OK) { rc = rr; break; }
+            for (i64 k = 0; k < n - 1; k++) out[s + 1 + k] += sig_start;
+        }
+#if TBA_PHASE_DEBUG_OR0 == 13
+        const i64 pt_a = (i64)__builtin_readcyclecounter();
+#endif
+        // phase 2: the larger ones, SKL_FLAT_N at a time, each in its quarter of the same memory
+        for (i64 i0 = 0; i0 < r.n_win; i0 += 64) {
+            const i64 i = i0 + lane;
+            bool todo = i < r.n_win && w3[3 * i + 2] == -3 && rc == TBA_OK;
+            for (;;) {
+                const u64 mk = __ballot(todo);
+                if (mk == 0) break;
+                const int rank = __popcll(mk & ((1ull << lane) - 1ull));
+                __syncthreads();                                  // (the previous round's rows are done with)
+                if (todo && rank < SKL_FLAT_N) {
+                    todo = false;
+                    const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
+                    const i64 sig_start = ds[s], sig_end = ds[e];
+                    int rr = TBA_INTERNAL;
+                    if (sig_start >= 0 && sig_end <= n_norm) {
+                        const int len = (int)(sig_end - sig_start - (n - 1));
+                        rr = raw_window_dp_lane_lds(sig + sig_start, len, mu + s, sd + s, (int)n, winsor, P.max_half_z_score,
+                                                    &S_.row[0][0] + rank * (SKL_FLAT_LEN + 8), 1,
+                                                    &S_.flag[0][0] + rank * SKL_FLAT_WORDS, 1, (len + 63) >> 6, out + s + 1);
+                    }
+                    if (rr != TBA_OK) rc = rr;
+                    else for (i64 k = 0; k < n - 1; k++) out[s + 1 + k] += sig_start;
+                }
+            }
+        }
+#if TBA_PHASE_DEBUG_OR0 == 13
+        pc_lds = pt_a - pt0; pc_arena = (i64)__builtin_readcyclecounter() - pt_a;
+#endif
+    }
+    // what is left: windows over global scratch (raw_min_obs_per_base > 1: all the small ones; DNA: none in practice)
+    for (i64 i = lane; i < r.n_win && rc == TBA_OK; i += 64) {
+        if (w3[3 * i + 2] < 0) continue;                      // k_skip_dp_wave's, or done above
         const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
         const i64 sig_start = ds[s], sig_end = ds[e];
         if (sig_start < 0 || sig_end > n_norm) { rc = TBA_INTERNAL; break; }
-        int rr = raw_window_dp(sig + sig_start, sig_end - sig_start, mu + s, sd + s, n, m,
-                               P.do_winsorize_z != 0, P.max_half_z_score,
-                               arena + r.skip_off + w3[3 * i + 2], out + s + 1);
+        const int rr = raw_window_dp(sig + sig_start, sig_end - sig_start, mu + s, sd + s, n, m,
+                                     P.do_winsorize_z != 0, P.max_half_z_score,
+                                     arena + r.skip_off + w3[3 * i + 2], out + s + 1);
         if (rr != TBA_OK) { rc = rr; break; }
         for (i64 k = 0; k < n - 1; k++) out[s + 1 + k] += sig_start;
     }
+#if TBA_PHASE_DEBUG_OR0 == 13
+    {
+        const i64 pt1 = (i64)__builtin_readcyclecounter();
+        if (lane == 0) { r.dbg[1] = pt1 - pt0; r.dbg[2] = pc_lds; r.dbg[3] = pc_arena; r.dbg[6] = r.n_win; }
+    }
+#endif
     // first failing window in window order decides the status, as in the sequential loop
     // (all window failures here are non-Tombo errors, so any of them is "unexpected")
     if (__syncthreads_or(rc != TBA_OK)) {
@@ -590,12 +788,24 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
     }
     wave_mem_fence(); // (the checks read boundaries other lanes wrote)
     int flag = 0; // 1: zero-length event
-    for (i64 i = lane; i + 1 < n_segs; i += 64)
-        if (out[i + 1] - out[i] < 1) flag = 1;
+    // (eight strides of loads in flight: one after the other this loop was a third of the kernel -- 157 round trips)
+    for (i64 i0 = lane; i0 + 1 < n_segs; i0 += 64 * 8) {
+        i64 a8[8], b8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i64 i = i0 + 64 * u < n_segs - 1 ? i0 + 64 * u : n_segs - 2;
+            a8[u] = out[i]; b8[u] = out[i + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (i0 + 64 * u + 1 < n_segs && b8[u] - a8[u] < 1) flag = 1;
+    }
     if (__syncthreads_or(flag)) { if (lane == 0) r.status = TBA_ZERO_LEN; return; }
     if (lane == 0) {
         if (out[0] < 0) r.status = TBA_NEG_START;
         else if (out[n_segs - 1] > n_norm) r.status = TBA_PAST_END;
+#if TBA_PHASE_DEBUG_OR0 == 13
+        r.dbg[0] = (i64)__builtin_readcyclecounter() - pt0;
+#endif
     }
 }
 

@@ -861,7 +861,8 @@ static int enqueue_stages(tba_engine *e, int first, int last)
             k_skip_dp_wave<SKIP_LEN_B, SKIP_BITS_B, 2><<<512, 64, 0, s>>>(SKIP_WAVE_ARGS(2));
         }
 #undef SKIP_WAVE_ARGS
-        k_skip_dp<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
+        // (raw_min_obs_per_base == 1, DNA: the small windows out of LDS -- k_tail.h)
+        (e->hp.p.raw_min_obs_per_base == 1 ? k_skip_dp<true> : k_skip_dp<false>)<<<nb, 64, 0, s>>>(rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), e->d_dscr.as<double>());
     }
     MARK(); // 12 theil-sen
     if (ON(TBA_STAGE_RESCALE)) {
