@@ -419,3 +419,50 @@ def test_stream_pipeline_any_slot_and_feeder_staging(monkeypatch):
     assert len(feeder.stages) == 5 and not any(feeder._busy)
     feeder.close()
     pipe.close()
+
+
+def test_pinned_pool_budget_counts_what_it_allocates_and_divides_by_the_node_ranks(monkeypatch):
+    """_native.PinnedPool without a device (the page-locked allocation stubbed): the budget is checked against the bytes a
+    fresh block really takes (need + 1/16 + 4096), idle blocks of the wrong size make room, a block comes back when its
+    last view dies, and the default budget is a quarter of the host divided by the ranks of the node (page-locked memory
+    cannot be swapped: round-5 advisor finding)"""
+    import ctypes
+    import gc
+    from tombo_amd import _native
+
+    made, closed = [], []
+
+    class FakePinned(object):
+        def __init__(self, n, dtype):
+            self.nbytes = int(n)
+            self._buf = ctypes.create_string_buffer(self.nbytes)
+            self._ptr = ctypes.c_void_p(ctypes.addressof(self._buf))
+            made.append(self.nbytes)
+
+        def close(self):
+            closed.append(self.nbytes)
+
+    monkeypatch.setattr(_native, 'PinnedArray', FakePinned)
+    monkeypatch.setenv('TBA_PINNED_POOL_BYTES', str(3 << 20))
+    pool = _native.PinnedPool()
+    assert pool.budget == 3 << 20
+    a = pool.lease(1 << 18, np.float64)              # 2 MiB + 1/16 + 4096
+    assert a is not None and made == [(2 << 20) + (2 << 20) // 16 + 4096] and pool.leased_bytes == made[0]
+    assert pool.lease(1 << 17, np.float64) is None   # 1 MiB + ... would pass a check against `need` alone: 2 + 1 <= 3
+    assert pool.leased_bytes == made[0] and len(made) == 1
+    del a
+    gc.collect()
+    assert pool.leased_bytes == 0 and pool.idle_bytes == made[0]
+    b = pool.lease(1 << 18, np.float64)              # the idle block again
+    assert b is not None and len(made) == 1 and pool.idle_bytes == 0
+    del b
+    gc.collect()
+    c = pool.lease(327680, np.float64)               # 2.5 MiB: too large for the idle block, and no room beside it: it goes
+    assert c is not None and closed == [made[0]] and pool.idle_bytes == 0 and pool.leased_bytes == made[1]
+    monkeypatch.delenv('TBA_PINNED_POOL_BYTES')
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    one = _native.PinnedPool().budget
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+    assert _native.PinnedPool().budget >= one and one <= (16 << 30)
+    host = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE')
+    assert one == min(host // 4 // 8, 16 << 30)

@@ -27,7 +27,7 @@ BUDGET = {
     '_Z9k_main_tb': (256, False),
     '_Z10k_start_tb': (512, True),           # (np_sum's recursion stack lives in scratch: 250 values per read)
     '_Z13k_final_score': (128, False),
-    '_Z9k_skip_dpILb1EE': (128, False),       # DNA: small windows out of LDS (40 KB: four wavefronts per CU)
+    '_Z9k_skip_dpILb1EE': (256, False),       # DNA: windows out of LDS (40 KB: four wavefronts per CU, whatever the registers)
     '_Z9k_skip_dpILb0EE': (128, False),
 }
 

@@ -239,9 +239,17 @@ class PinnedPool(object):
     lease array alive; a finalizer on it returns the block).  Blocks are reused, never freed while the
     pool is under its idle cap: hipHostMalloc is slow and hipHostFree waits for all work on the device.
 
-    Budget (bytes leased to live results + idle): $TBA_PINNED_POOL_BYTES, default a quarter of the
-    host's memory.  Beyond it `lease` returns None and the caller copies into pageable memory, as
-    every result did before round 5."""
+    Budget (bytes of page-locked memory this PROCESS may hold in the pool, leased to live results + idle):
+    $TBA_PINNED_POOL_BYTES; default a quarter of the host's memory divided by the ranks of the node
+    ($LOCAL_WORLD_SIZE, else $WORLD_SIZE, else 1) and at most 16 GiB -- page-locked memory cannot be swapped,
+    and eight ranks with a quarter of the host each would have pinned twice the host.  Beyond the budget
+    `lease` returns None and the caller copies into pageable memory, as every result did before round 5.
+    NOTE for callers: one retained result keeps its whole batch block alive (segs + signal of every read of
+    the batch); copy what is kept for long (`np.array(r.segs)`), or run with TBA_PINNED_POOL_BYTES=0."""
+
+    @staticmethod
+    def _alloc_bytes(need):
+        return need + need // 16 + 4096         # (what a fresh block really takes: counted against the budget)
 
     def __init__(self):
         import threading
@@ -254,37 +262,51 @@ class PinnedPool(object):
             self.budget = int(env)
         else:
             try:
-                self.budget = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') // 4
+                ranks = max(int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ.get('WORLD_SIZE') or 1), 1)
+            except ValueError:
+                ranks = 1
+            try:
+                host = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE')
             except (ValueError, OSError):
-                self.budget = 8 << 30
+                host = 32 << 30
+            self.budget = min(host // 4 // ranks, 16 << 30)
 
     def lease(self, count, dtype):
         import weakref
         dtype = np.dtype(dtype)
         need = max(int(count) * dtype.itemsize, 1)
+        drop = []
         with self._lock:
             best = None
             for k, pa in enumerate(self._idle):     # smallest idle block that holds it without wasting half
                 if need <= pa.nbytes <= 2 * need + (1 << 20) and (best is None or pa.nbytes < self._idle[best].nbytes):
                     best = k
             pa = self._idle.pop(best) if best is not None else None
+            fresh = self._alloc_bytes(need)
             if pa is not None:
                 self.idle_bytes -= pa.nbytes
-            elif self.leased_bytes + self.idle_bytes + need > self.budget:
+                self.leased_bytes += pa.nbytes
+            else:
                 # make room out of idle blocks of the wrong size before giving up
-                while self._idle and self.leased_bytes + self.idle_bytes + need > self.budget:
+                while self._idle and self.leased_bytes + self.idle_bytes + fresh > self.budget:
                     old = self._idle.pop()
                     self.idle_bytes -= old.nbytes
-                    old.close()
-                if self.leased_bytes + self.idle_bytes + need > self.budget:
-                    return None
+                    drop.append(old)
+                if self.leased_bytes + self.idle_bytes + fresh > self.budget:
+                    fresh = 0
+                else:
+                    self.leased_bytes += fresh      # reserved before the lock goes: two threads cannot both take the last room
+        for old in drop:                            # hipHostFree waits for the device: never under the lock
+            old.close()
         if pa is None:
-            try:
-                pa = PinnedArray(need + need // 16 + 4096, np.uint8)
-            except EngineError:
+            if fresh == 0:
                 return None
-        with self._lock:
-            self.leased_bytes += pa.nbytes
+            try:
+                pa = PinnedArray(fresh, np.uint8)
+            except EngineError:
+                with self._lock:
+                    self.leased_bytes -= fresh
+                return None
         buf = (C.c_char * pa.nbytes).from_address(pa._ptr.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(count))
         weakref.finalize(arr, self._give, pa)

@@ -446,7 +446,7 @@ def _fill_results(results, ok, map_results, svs, rstart, score, changed, segs_l,
         RR._fields.index(f) for f in ('genome_seq', 'raw_signal', 'read_start_rel_to_raw', 'segs',
                                       'scale_values', 'sig_match_score', 'norm_params_changed', 'stall_ints'))
     okl = ok.tolist() if hasattr(ok, 'tolist') else list(ok)
-    sv_rows = np.asarray(svs)[okl].tolist() if len(okl) else []
+    sv_rows = np.asarray(svs)[okl][:, :4].tolist() if len(okl) else []
     rs_l, sc_l, ch_l = (np.asarray(x)[okl].tolist() if len(okl) else [] for x in (rstart, score, changed))
     t_test = bool(rsqgl_params.use_t_test_seg)
     for k, i in enumerate(okl):
@@ -462,13 +462,24 @@ def _fill_results(results, ok, map_results, svs, rstart, score, changed, segs_l,
                 ot = None
         else:
             ot = outlier_thresh
+        sv_new = new(SV, (sh, scl, lo, hi, ot))
+        if type(mr) is not RR:
+            # (a subclass, or another tuple with these field names: the field-by-field build below assumes RR's own
+            # layout -- such a result goes through _replace, as every result did before round 5)
+            gs = mr.genome_seq
+            kw = dict(genome_seq=gs[cp:len(gs) - dn], raw_signal=norm_l[k], read_start_rel_to_raw=int(rs_l[k]),
+                      segs=segs_l[k], scale_values=sv_new, sig_match_score=sc_l[k], norm_params_changed=bool(ch_l[k]))
+            if dev_stalls is not None:
+                kw['stall_ints'] = [list(map(int, x)) for x in dev_stalls[i]]
+            results[i] = mr._replace(**kw)
+            continue
         f = list(mr)
         gs = f[I_SEQ]
         f[I_SEQ] = gs[cp:len(gs) - dn]
         f[I_RAW] = norm_l[k]
         f[I_START] = int(rs_l[k])
         f[I_SEGS] = segs_l[k]
-        f[I_SV] = new(SV, (sh, scl, lo, hi, ot))
+        f[I_SV] = sv_new
         f[I_SCORE] = sc_l[k]
         f[I_CH] = bool(ch_l[k])
         if dev_stalls is not None:
