@@ -48,14 +48,16 @@ DAC_PER_PA, DAC_OFFSET = 1.0 / 0.1709, 10.0  # MinION-like digitisation of the s
 
 # roofline: the dominant stage GROUP of the configuration (engine event brackets) and the kernels
 # inside it
+# stage brackets (HIP events on the engine's stream) whose time is ONE kernel's, or nearly: the dominant one is the
+# line's `roofline.kernel` (rocprof's per-kernel averages of the same runs: profiles/r06_kernel_stats_*.txt)
 STAGE_GROUPS = [
     ('main_dp', ['main_dp'], 'k_dp (main adaptive banded forward pass)'),
-    ('event_detection', ['cumsum', 'scores', 'peaks'],
-     'event detection bracket: k_cumsum_scores / k_scores_ttest + k_peaks (+ RNA: stall removal, '
-     'event scaling, normalisation)'),
+    ('cumsum', ['cumsum'], 'k_detect<2> + k_pick (DNA event detection; k_detect is 82 % of the bracket)'),
+    ('scores', ['scores'], 'k_detect_tt<5, 12> (RNA t-test event detection: the bracket is this kernel)'),
+    ('peaks', ['peaks'], 'k_pick + k_remove_stalls + event scaling (RNA)'),
     ('normalize', ['normalize'], 'k_normalize'), ('stalls', ['stalls'], 'k_cumsum_scores<raw> + k_stall_metric'),
     ('event_means', ['event_means'], 'k_event_means'), ('start', ['start_dp', 'start_tb'], 'k_dp (start discovery) + k_start_tb'),
-    ('main_tb', ['main_tb'], 'k_main_tb'), ('skip_resolve', ['skip_resolve'], 'k_skip_dp'),
+    ('main_tb', ['main_tb'], 'k_main_tb_par + k_tb_par_verify + k_tb_gather'), ('skip_resolve', ['skip_resolve'], 'k_skip_plan + k_skip_dp'),
     ('theil_sen', ['theil_sen'], 'k_theil_sen'), ('rescale_score', ['rescale_score'], 'k_rescale_absz')]
 
 
@@ -622,7 +624,9 @@ def main():
                     help='longtail preset: reads longer than this form batches of their own (planner.plan_batches)')
     ap.add_argument('--api-reads', type=int, default=5000, help='reads of the resquiggle_batch API leg (0: skip)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes behind roofline.traffic')
-    ap.add_argument('--pmc-reads', type=int, default=2048, help='reads of the counter passes (they take the dispatch forms of the timed batch whatever this is)')
+    ap.add_argument('--pmc-reads', type=int, default=1 << 30,
+                    help='reads of the counter passes: the whole timed batch by default (a 2 048-read sub-batch read 5 %% low in round 5: '
+                         'per-workgroup tiles amortise differently); they take the dispatch forms of the timed batch whatever this is')
     ap.add_argument('--pmc-child', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-child', default=None, help=argparse.SUPPRESS)  # JSON job of the CPU legs
     ap.add_argument('--engine-stub', default=None, help=argparse.SUPPRESS)  # tests/: host logic without a GPU

@@ -1179,7 +1179,9 @@ __global__ __launch_bounds__(256) void k_scan_arena(ReadState *rs, i64 n_reads, 
 // current band position (one 16-byte load per row) and the band starts are fetched together,
 // then the rows are walked out of registers; a position outside its window falls back to
 // direct loads.  A run of stays is resolved with clz on the 2-bit fields.
+#ifndef TBR
 #define TBR 16
+#endif
 __device__ __forceinline__ int mv_find_le(u64 x, int top) // highest non-zero 2-bit field <= top, or -1
 {
     const u64 m = top >= 31 ? x : (x & ((1ull << (2 * top + 2)) - 1ull));
