@@ -137,14 +137,8 @@ int  tba_engine_held_bytes(tba_engine *e, int64_t *bytes);
  * default).  With n_engines > 1 a batch whose work is mostly outside the banded DP (RNA) runs the
  * register-capped build of the DP kernel so that the other engines' kernels fit beside it. */
 int  tba_engine_set_sharing(tba_engine *e, int n_engines);
-/* The main forward pass (c_adaptive_banded_forward_pass, _c_dynamic_programming.pyx:314-412) has two
- * forms with identical results: a wavefront per read (the default, always) and a workgroup per
- * read (csrc/k_dp_wgm.h: built as the latency form for small batches and long reads, measured
- * slower -- 20.3 against 12.9 ms on a 10 kb read -- and therefore off).  Batches of at most max_reads
- * reads take the second form for every read (0: batches of any size only for their long reads;
- * < 0, the default: never), applied from the next upload.  For A/B measurements and the parity
- * test of that kernel; the environment variable TBA_DP_WG_BATCH sets the same at engine creation. */
-int  tba_engine_set_dp_workgroup_batch(tba_engine *e, int64_t max_reads);
+/* (ABI 9: tba_engine_set_dp_workgroup_batch is gone with the workgroup-per-read form of the main forward pass it
+ * switched on -- measured slower in round 4, profiles/r04_dp_workgroup_form.txt; TBA_GET_DP_WORKGROUP reads zeros.) */
 /* Event detection (c_valid_cpts_w_cap, _c_helper.pyx:89-120) and the main traceback
  * (c_banded_traceback, _c_dynamic_programming.pyx:281-310) each have a LATENCY and a THROUGHPUT
  * form with identical results; which one a batch takes depends on its read count alone:
@@ -296,7 +290,7 @@ enum {
     TBA_GET_ED_TAKEN_POS = 26, /* int32, two slots per sample (CSR by 2 * raw_off): positions of the taken list k_detect
                                 * left, valid right after stage TBA_STAGE_SEGMENT only (later stages reuse the buffer) */
     TBA_GET_ED_N_TAKEN = 27,  /* int64[n]: its length per read */
-    TBA_GET_DP_WORKGROUP = 28, /* int32[n]: 1 where the workgroup-per-read form ran the main forward pass (diagnostics) */
+    TBA_GET_DP_WORKGROUP = 28, /* int32[n]: zeros since ABI 9 (was: 1 where the removed workgroup-per-read form ran the main forward pass) */
     TBA_GET_ED_FORM = 29,     /* int32[n]: TBA_ED_FORM_*: the kernels that produced the read's change points
                                * (0: none did -- the read had failed before) */
     TBA_GET_TB_FORM = 30,     /* int32[n]: TBA_TB_FORM_*: the kernel that walked the read's main traceback */

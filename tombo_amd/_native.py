@@ -490,13 +490,6 @@ class Engine(object):
         """scheduling hint: `n_engines` engines are fed concurrently on this device (tba_engine_set_sharing)"""
         self._check(self._L.tba_engine_set_sharing(self._h, int(n_engines)), 'tba_engine_set_sharing')
 
-    def set_dp_workgroup_batch(self, max_reads):
-        """batches of at most max_reads reads run the main forward pass one workgroup per read
-        (0: only the long reads of any batch, < 0 -- the default -- never); from the next upload.
-        Same results, measured slower (csrc/k_dp_wgm.h): for A/B runs and that kernel's parity test"""
-        self._check(self._L.tba_engine_set_dp_workgroup_batch(self._h, i64(int(max_reads))),
-                    'tba_engine_set_dp_workgroup_batch')
-
     def set_dispatch(self, small_batch_reads=-1, tb_wave_below=-1):
         """read-count thresholds between the latency and the throughput forms of DNA event detection
         and of the main traceback (tba_engine_set_dispatch; identical results; default 1 024 each;

@@ -29,23 +29,9 @@ __host__ __device__ inline int cpl_class(i64 W)
     return 0;
 }
 
-// The main forward pass of a read can be run by a whole workgroup (k_dp_wgm.h) instead of one
-// wavefront: every read of a batch of at most dp_wg_batch reads (DevParams.dp_wg_mode 2), the is_long
-// reads of any batch (1); bands of 129..512 cells.  k_dp and k_dp_multi leave those reads alone.
-// OFF by default (TBA_WG_BATCH -1: never): measured on a 10 kb read at W = 500 the workgroup form
-// takes 20.3 ms against k_dp's 12.9 (k_dp_wgm.h says why); tba_engine_set_dp_workgroup_batch /
-// TBA_DP_WG_BATCH switch it on for A/B runs and for the parity test that keeps it bit-exact.
-#ifndef TBA_WG_BATCH
-#define TBA_WG_BATCH -1
-#endif
-#define WGM_NT 256
-#define WGM_CPL 2
-#define WGM_MAXW (WGM_NT * WGM_CPL)
-__device__ __forceinline__ bool dp_by_workgroup(const DevParams *dp, const ReadState &r)
-{
-    const int m = dp->dp_wg_mode;
-    return (m == 2 || (m == 1 && r.is_long)) && r.W > 128 && r.W <= WGM_MAXW;
-}
+// (Rounds 4-5 kept a second form of the main forward pass in the tree, a workgroup per read (k_dp_wgm.h): built as
+// the latency form, bit-identical, 20.3 ms against this kernel's 12.9 on a 10 kb read -- profiles/r04_dp_workgroup_form.txt
+// says why.  Removed in round 6 with its switch, tba_engine_set_dp_workgroup_batch: git history has it.)
 
 
 enum { DP_START_TRY = 0, DP_START_RETRY = 1, DP_MAIN = 2, DP_DIRECT = 3 };
@@ -335,7 +321,7 @@ __device__ __forceinline__ void dp_body(ReadState *rs, const DevParams *dp, int 
     } else {
         i64 ev_base;
         if (mode == DP_MAIN) {
-            if (r.path == PATH_NONE || dp_by_workgroup(dp, r)) return;
+            if (r.path == PATH_NONE) return;
             W = (int)r.W;
             if (cpl_class(W) != CPL) return;
             // an adaptive read at a narrow batch bandwidth belongs to k_dp_multi
@@ -1127,8 +1113,8 @@ __global__ __launch_bounds__(64) void k_prep(ReadState *rs, i64 n_reads, const D
         hi_a[sp] = (i32)(sml + nzs);
     }
     r.path = PATH_ADAPTIVE; r.clip = clip; r.offset = offset; r.W = bw; r.n_static = msl;
-    // (k_dp writes the centre strip; the reads k_dp_multi / k_dp_wgm take have none)
-    r.strip_s0 = dp_multi_class(bw).cpl != 0 || dp_by_workgroup(dp, r) ? -1 : mv_strip_s0(bw);
+    // (k_dp writes the centre strip; the reads k_dp_multi takes have none)
+    r.strip_s0 = dp_multi_class(bw).cpl != 0 ? -1 : mv_strip_s0(bw);
     r.moves_off = (r.B + 1) * ((i64)mv_class_rowb(cpl_class(bw)) + (r.strip_s0 >= 0 ? MV_STRIP_BYTES : 0));
 }
 

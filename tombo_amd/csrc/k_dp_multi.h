@@ -86,8 +86,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TBA_DPM_WAVE
     const i64 ri = order[slot < n_reads ? slot : n_reads - 1];
     ReadState &r = rs[ri];
     const int Wi = (int)uni(P.bandwidth);
-    bool alive = slot < n_reads && r.status == TBA_OK && r.path == PATH_ADAPTIVE && r.W == Wi &&
-                 !dp_by_workgroup(dp, r);
+    bool alive = slot < n_reads && r.status == TBA_OK && r.path == PATH_ADAPTIVE && r.W == Wi;
     if (__ballot(alive) == 0) return;
     const double stay_pen = uni(P.stay_pen), skip_pen = uni(P.skip_pen), z_shift = uni(P.z_shift);
     const double zcap = P.do_winsorize_z ? uni(P.max_half_z_score) : INFINITY;

@@ -56,7 +56,7 @@ struct ReadState {
     i32 has_lims;
     i32 tb_done;              // main traceback: 0 to be walked by the serial kernels, 2 walked chunk-parallel and awaiting
                               // k_tb_par_verify, 1 finished (k_tb_par.h)
-    i32 ed_flag, dp_wg; // dp_wg: the main forward pass was run by a workgroup (k_dp_wgm.h)        // event detection: 1 = this read needs the kernels that keep the scores (k_detect.h)
+    i32 ed_flag, dp_wg; // ed_flag: event detection: 1 = this read needs the kernels that keep the scores (k_detect.h); dp_wg: unused since round 6 (0)
     i32 ed_form, tb_form;     // which kernels produced this read's change points / main traceback
     i32 strip_s0;             // first band cell of the centre strip k_dp keeps beside the move rows (-1: none; k_dp.h)
     i32 bad_seq;              // k_ref_levels on the side stream found a base outside ACGT (applied in stage order: k_seq_status)
@@ -80,7 +80,7 @@ struct DevParams {
     i64 kmer_width, central_pos;
     double fill_masked; // (MASK_FILL_Z_SCORE - z_shift) + z_shift, the round trip of
                         // resquiggle.py:665-668,678
-    i32 dp_wg_mode, pad; // main forward pass by workgroup (k_dp_wgm.h): 0 no read, 1 the long reads, 2 all
+    i32 dp_wg_mode, pad; // (unused since round 6: the workgroup-per-read forward pass is gone; kept for the struct's size)
 };
 
 // Two consecutive float64 as ONE 16-byte memory access at 8-byte alignment (global_load /

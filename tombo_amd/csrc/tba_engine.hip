@@ -12,7 +12,6 @@
 #include "k_dp_multi.h"
 #include "k_long.h"
 #include "k_dp_wg.h"
-#include "k_dp_wgm.h"
 #include "k_tail.h"
 #include "k_cabi.h"
 #include "k_synth.h"
@@ -117,7 +116,6 @@ struct tba_engine {
     int n_sharing = 1;            // engines fed concurrently on this device (tba_engine_set_sharing)
     int side_mode = -1;           // tba_engine_set_side_stream: -1 by the engines alive, 0 never, 1 always
     bool last_side = false;       // the last full run used the side stream
-    i64 dp_wg_batch = TBA_WG_BATCH; // batches up to this many reads: main forward pass by workgroup (k_dp_wgm.h)
     // latency / throughput forms of event detection and traceback (tba_engine_set_dispatch)
     i64 small_batch = TBA_SMALL_BATCH, tb_wave_below = TBP_WAVE_BELOW;
     int last_c_ed_form = 0;       // tba_c_last_ed_form
@@ -185,8 +183,6 @@ extern "C" int tba_engine_create(int device, tba_engine **out)
                                       ", this library carries gfx950 code only");
     tba_engine *e = new tba_engine();
     e->device = device;
-    // (A/B runs and the test suite in both forms of the main forward pass: tba_engine_set_dp_workgroup_batch)
-    if (const char *v = getenv("TBA_DP_WG_BATCH")) e->dp_wg_batch = atoll(v);
     if (const char *v = getenv("TBA_SMALL_BATCH_READS")) e->small_batch = std::max<i64>(atoll(v), 0);
     if (const char *v = getenv("TBA_TB_WAVE_BELOW")) e->tb_wave_below = std::max<i64>(atoll(v), 0);
     HIP_TRY(hipStreamCreate(&e->stream));
@@ -525,11 +521,7 @@ extern "C" int tba_batch_upload_async(tba_engine *e, const tba_params *p, const 
         for (i64 i = 0; i < n; i++) if (hrs[ord[i]].is_long) lg[e->n_long++] = ord[i];
         if (e->n_long > 0) HIP_TRY(hipMemcpyAsync(e->d_long.p, lg, (size_t)e->n_long * 4, hipMemcpyHostToDevice, s));
     }
-#ifdef TBA_NO_DP_WG
     e->hp.dp_wg_mode = 0;
-#else
-    e->hp.dp_wg_mode = e->dp_wg_batch < 0 ? 0 : n <= e->dp_wg_batch ? 2 : (e->n_long > 0 ? 1 : 0);
-#endif
     memcpy(e->h_dp.p, &e->hp, sizeof(DevParams));
     HIP_TRY(hipMemcpyAsync(e->d_rs.p, e->h_rs.p, N * sizeof(ReadState), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(e->d_dp.p, e->h_dp.p, sizeof(DevParams), hipMemcpyHostToDevice, s));
@@ -800,12 +792,6 @@ static int enqueue_stages(tba_engine *e, int first, int last)
     }
     MARK(); // 9 main dp
     if (ON(TBA_STAGE_ASSIGN)) {
-        // the reads a workgroup each takes (k_dp_wgm.h): a small batch whole, the long reads of any
-#define WGM_ARGS dp, e->d_evm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_bst.as<i64>(), \
-        e->d_lo.as<i32>(), e->d_hi.as<i32>(), e->d_moves.as<unsigned char>(), e->d_lastrow.as<double>()
-        if (e->hp.dp_wg_mode == 2) k_dp_wgm<<<nb, WGM_NT, 0, s>>>(rs, nullptr, WGM_ARGS);
-        else if (e->hp.dp_wg_mode == 1) k_dp_wgm<<<(unsigned)e->n_long, WGM_NT, 0, s>>>(rs, e->d_long.as<i32>(), WGM_ARGS);
-#undef WGM_ARGS
         const int cls[] = {4, 5, 8, 12, 16, 24, 32, 48};
         for (int c : cls) launch_dp(e, c, DP_MAIN);
         launch_dp_multi(e); // narrow adaptive bands: several reads per wavefront
@@ -2216,13 +2202,6 @@ extern "C" int tba_unpack_reads(int64_t n_reads, const void *src, int64_t elem_b
         a = b;
     }
     for (auto &x : th) x.join();
-    return 0;
-}
-
-extern "C" int tba_engine_set_dp_workgroup_batch(tba_engine *e, int64_t max_reads)
-{
-    if (!e) return set_err(TBA_E_ARG, "engine is NULL");
-    e->dp_wg_batch = max_reads;
     return 0;
 }
 
