@@ -1091,6 +1091,26 @@ def main():
             api['resquiggle_batch_' + mode] = {
                 'reads_per_s': round(n_api / dta, 1), 'seconds': round(dta, 4),
                 'ok': sum(not isinstance(r, Exception) for r in res)}
+        # the floor of the legs that hand back the float64 signal: the results cross PCIe (page-locked pool blocks,
+        # one D2H copy per sub-batch) -- measured here with a copy of the same size out of the engine's device memory
+        sig_bytes = float(sum(int(len(dacs[i])) for i in range(n_api))) * 8.0
+        try:
+            src = torch.empty(1 << 28, dtype=torch.uint8, device='cuda:%d' % dev)      # 256 MiB probe
+            dst = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()
+            dst.copy_(src)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                dst.copy_(src)
+            torch.cuda.synchronize(dev)
+            d2h = 4 * float(1 << 28) / (time.perf_counter() - t0)
+            del src, dst
+            api['d2h_GBps_page_locked'] = round(d2h / 1e9, 1)
+            api['d2h_floor_reads_per_s'] = round(n_api / (sig_bytes / d2h), 1)
+            api['d2h_floor_note'] = ('%.2f GB of float64 signal per %d reads at the measured page-locked D2H rate: what the two '
+                                     'legs that return the signal cannot exceed' % (sig_bytes / 1e9, n_api))
+        except Exception as e:   # (evidence, not the metric)
+            api['d2h_floor_note'] = 'not measured: %s' % (str(e)[:120],)
         # where the time of one call goes (second mode: no host RNG)
         t0 = time.perf_counter()
         for i in range(n_api):

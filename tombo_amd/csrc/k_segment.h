@@ -1025,7 +1025,28 @@ __global__ __launch_bounds__(256) void k_ref_levels(ReadState *rs, const DevPara
     const i64 K = dp->kmer_width;
     const uint8_t *s = seq + r.seq_off;
     bool bad = false;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < r.B; i += (i64)gridDim.x * 256) {
+    // Two bases per thread: their K + 1 <= 8 codes in one (unaligned) 8-byte load instead of 2 K byte loads, the two
+    // levels and the two sds as 16-byte stores (st2: 8-byte alignment is enough).  The generic form below takes what
+    // the pairs leave: every base when K > 7, and the last bases of the read (an 8-byte load there would run past
+    // the read's codes).
+    const i64 n_codes = r.B + K - 1;
+    i64 n_paired = 0;                                    // bases [0, n_paired) are done in pairs
+    if (K <= 7) { n_paired = n_codes - 8 + 2; n_paired = n_paired < 0 ? 0 : (n_paired > r.B ? r.B : n_paired); n_paired &= ~(i64)1; }
+    for (i64 i = 2 * ((i64)blockIdx.x * 256 + threadIdx.x); i < n_paired; i += 2 * (i64)gridDim.x * 256) {
+        u64 w;                                           // (i + 8 <= n_codes for every i < n_paired)
+        __builtin_memcpy(&w, s + i, 8);
+        if (w & 0xfcfcfcfcfcfcfcfcull) {                 // a code > 3 among the eight bytes: only the K + 1 used ones count
+            for (i64 j = 0; j <= K; j++) if (((w >> (8 * j)) & 0xff) > 3) bad = true;
+        }
+        i64 c0 = 0, c1 = 0;
+        for (i64 j = 0; j < K; j++) {
+            c0 = c0 * 4 + ((w >> (8 * j)) & 3);
+            c1 = c1 * 4 + ((w >> (8 * (j + 1))) & 3);
+        }
+        st2(ref_means + r.ref_off + i, kmer_means[c0], kmer_means[c1]);
+        st2(ref_sds + r.ref_off + i, kmer_sds[c0], kmer_sds[c1]);
+    }
+    for (i64 i = n_paired + (i64)blockIdx.x * 256 + threadIdx.x; i < r.B; i += (i64)gridDim.x * 256) {
         i64 code = 0;
         for (i64 j = 0; j < K; j++) {
             uint8_t b = s[i + j];

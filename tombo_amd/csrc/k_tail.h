@@ -326,6 +326,7 @@ __device__ __forceinline__ int raw_window_dp_lane_lds(const double *sig, int len
 #define SKIP_LEN_B 1792
 #define SKIP_BITS_B 1024 // u64 words of traceback flags (n * ceil(len / 64))
 
+#define SKP_LDS_DELS 1024
 __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp,
     const i64 *dp_segs, i64 *segs_out, i64 *win_scratch, i64 *skipq, i32 *lists, i64 list_cap)
 {
@@ -361,6 +362,123 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
         }
     }
     __syncthreads();
+    // ---- the usual case (at most SKP_LDS_DELS skipped bases): windows in LDS, per-window work on all lanes.
+    // Lane 0 alone over global memory (the form below, kept for reads with more deletions) paid a memory round
+    // trip for every window it touched -- ~350 of them, 0.5 of the kernel's 0.84 ms.  Same windows, same statuses:
+    // the first failing window in window order decides, as in the serial loops.
+    if (n_del <= SKP_LDS_DELS) {
+        __shared__ i64 s_aux[SKP_LDS_DELS];              // the deletions, later each window's scratch need / class
+        __shared__ Win s_w[SKP_LDS_DELS];
+        __shared__ i64 s_nw;
+        __shared__ int s_st;
+        const i64 dfw = dp->o.del_fix_window, mdfw = dp->o.max_del_fix_window;
+        const double esf = dp->o.extra_sig_factor;
+        for (i64 q = lane; q < n_del; q += 64) s_aux[q] = dels[q];
+        if (lane == 0) s_st = TBA_OK;
+        __syncthreads();
+        if (lane == 0) {
+            i64 nw = 0;
+            for (i64 q = 0; q < n_del; q++) {
+                const i64 d = s_aux[q];
+                if (nw > 0 && d < s_w[nw - 1].e + dfw) s_w[nw - 1].e = d + dfw + 1;
+                else { s_w[nw].s = d - dfw; s_w[nw].e = d + dfw + 1; nw++; }
+            }
+            if (nw > 0) { nw = merge_windows(s_w, nw); trim_windows(s_w, nw, n_segs); }
+            s_nw = nw;
+        }
+        __syncthreads();
+        if (s_nw == 0) return;
+        // first failing window of a parallel check (code 0: fine), in window order
+        auto first_code = [&](auto code_of) -> int {
+            int res = 0;
+            for (i64 i0 = 0; i0 < s_nw && res == 0; i0 += 64) {
+                const i64 i = i0 + lane;
+                const int c = i < s_nw ? code_of(i) : 0;
+                const u64 mk = __ballot(c != 0);
+                if (mk) res = __shfl(c, __ffsll((unsigned long long)mk) - 1, 64);
+            }
+            return res;
+        };
+        bool expanded = false;
+        for (i64 it = 0; it < mdfw - dfw; it++) {
+            bool any = false;
+            const int err = first_code([&](i64 i) {
+                const int ts = window_too_small(ds, n_segs, s_w[i], m, esf);
+                if (ts > 0) any = true;
+                return ts < 0 ? (int)TBA_INTERNAL : 0;
+            });
+            if (err) { if (lane == 0) r.status = err; return; }
+            expanded = __ballot(any) != 0;
+            if (!expanded) break;
+            __syncthreads();
+            for (i64 i = lane; i < s_nw; i += 64)       // (every lane re-derives its windows' verdicts: cheap, from cache)
+                if (window_too_small(ds, n_segs, s_w[i], m, esf) > 0) { s_w[i].s -= 1; s_w[i].e += 1; }
+            __syncthreads();
+            if (lane == 0) { const i64 nw = merge_windows(s_w, s_nw); trim_windows(s_w, nw, n_segs); s_nw = nw; }
+            __syncthreads();
+        }
+        if (expanded) {
+            const int err = first_code([&](i64 i) {
+                const int ts = window_too_small(ds, n_segs, s_w[i], m, esf);
+                return ts < 0 ? (int)TBA_INTERNAL : (ts ? (int)TBA_NOT_ENOUGH_DEL_SIGNAL : 0);
+            });
+            if (err) { if (lane == 0) r.status = err; return; }
+        }
+        if (dp->o.max_raw_cpts >= 0) {
+            const int err = first_code([&](i64 i) { return s_w[i].e - s_w[i].s > dp->o.max_raw_cpts ? (int)TBA_TOO_MANY_DELS : 0; });
+            if (err) { if (lane == 0) r.status = err; return; }
+        }
+        // per window: class / scratch need (s_aux[i]: -1 wave form, -2 LDS column, -3 LDS flat, >= 0 arena doubles)
+        i64 *w3 = win_scratch + 3 * r.seg_off;
+        {
+            const int err = first_code([&](i64 i) {
+                const i64 s = s_w[i].s, e = s_w[i].e, n = e - s;
+                if (s < 0 || e >= n_segs) return (int)TBA_INTERNAL;
+                const i64 L = ds[e] - ds[s];
+                const i64 len = L - (n - 1) * m;
+                if (len <= 0 || n < 2) return (int)TBA_INTERNAL;
+                w3[3 * i] = s; w3[3 * i + 1] = e;
+                const i64 fw = n * ((len + 63) / 64);
+                i64 code;
+                if (m == 1 && len <= SKL_LEN && n <= SKL_N) code = -2;
+                else if (m == 1 && len <= SKL_FLAT_LEN && fw <= SKL_FLAT_WORDS) code = -3;
+                else {
+                    code = raw_window_need(n, len);
+                    if (m > 1 && n * len >= SKIP_WAVE_MIN) {
+                        const bool fits = (n - 1) * m <= 512 && n <= 256;
+                        int cls = -1;
+                        if (fits && len <= SKIP_LEN_S && fw <= SKIP_BITS_S) cls = 0;
+                        else if (fits && len <= SKIP_LEN_M && fw <= SKIP_BITS_M) cls = 1;
+                        else if (fits && len <= SKIP_LEN_B && fw <= SKIP_BITS_B) cls = 2;
+                        if (cls >= 0) { // queue for k_skip_dp_wave (a full list leaves the window to the lane form)
+                            const i64 pos = (i64)atomicAdd((unsigned long long *)&skipq[cls], 1ull);
+                            if (pos < list_cap) {
+                                i32 *lst = lists + 2 * list_cap * cls;
+                                lst[2 * pos] = (i32)blockIdx.x; lst[2 * pos + 1] = (i32)i;
+                                code = -1;
+                            }
+                        }
+                    }
+                }
+                s_aux[i] = code;
+                return 0;
+            });
+            if (err) { if (lane == 0) r.status = err; return; }
+        }
+        __syncthreads();
+        if (lane == 0) { // arena offsets in window order
+            i64 acc = 0;
+            for (i64 i = 0; i < s_nw; i++) {
+                const i64 c = s_aux[i];
+                if (c >= 0) { s_aux[i] = acc; acc += c; }
+            }
+            r.n_win = s_nw;
+            r.skip_off = acc;
+        }
+        __syncthreads();
+        for (i64 i = lane; i < s_nw; i += 64) w3[3 * i + 2] = s_aux[i];
+        return;
+    }
     if (lane != 0) return;
     // windows are built in place as (s, e) pairs, then widened to (s, e, off) triples back to
     // front; capacity 3 * (B + 1) entries per read
