@@ -56,7 +56,10 @@ int main()
     report("k_main_tb", k_main_tb, 64);
     report("k_main_tb_par<16>", k_main_tb_par<16>, 64);
     report("k_main_tb_par<64>", k_main_tb_par<64>, 64);
-    report("k_skip_dp", k_skip_dp, 64);
+    report("k_tb_par_verify<16>", k_tb_par_verify<16>, 64);
+    report("k_skip_dp<true>", k_skip_dp<true>, 64);
+    report("k_skip_dp<false>", k_skip_dp<false>, 64);
+    report("k_skip_plan", k_skip_plan, 64);
     report("k_theil_sen", k_theil_sen, SEL_NT);
     report("k_rescale_absz<true>", k_rescale_absz<true>, 256);
     report("k_rescale_absz<false>", k_rescale_absz<false>, 256);
