@@ -201,17 +201,20 @@ __device__ inline int raw_window_dp(const double *sig, i64 L, const double *mean
 // forward row to global scratch and read it back (5.3 GB per cfg2 batch, three 64-line memory instructions per
 // position).  Two layouts of the same function (rp / rs: row slot k at rp[k * rs]; fp / fs / words: flag word w of
 // base i at fp[(i * words + w) * fs]):
-//   column -- the windows of at most SKL_N bases over an admissible interval of at most SKL_LEN samples, 97 % of the
+//   column -- the windows of at most SKL_N bases over an admissible interval of at most SKL_LEN samples (48 and 40
+//     measured slower: more windows in the flat phase), 97 % of the
 //     ~57 windows of a 10 kb read (mean 5 bases x 25 samples): all lanes at once, lane l in column l of
 //     row[k][l] (conflict-free), one flag word per base;
 //   flat -- the few larger ones, afterwards, up to SKL_FLAT_N at a time: a lane takes a quarter of the same LDS as
 //     a flat row of up to SKL_FLAT_LEN slots and a quarter of the flag words.
 // Anything larger still goes through global scratch (raw_window_dp).
+#ifndef SKL_LEN
 #define SKL_LEN 56   // (+ 8 slots a batch of eight positions may run past the interval's end: 32 KB, four wavefronts per CU)
-#define SKL_N 16
+#endif
+#define SKL_N 14     // (14 flag rows + 64 row slots + the kernel's own words = 40 192 bytes: four workgroups on a CU, not three)
 #define SKL_FLAT_N 4
 #define SKL_FLAT_LEN ((SKL_LEN + 8) * 64 / SKL_FLAT_N - 8)   // 1016 samples
-#define SKL_FLAT_WORDS (SKL_N * 64 / SKL_FLAT_N)            // 256 flag words: bases x ceil(len / 64)
+#define SKL_FLAT_WORDS (SKL_N * 64 / SKL_FLAT_N)            // 224 flag words: bases x ceil(len / 64)
 struct SkipLaneSmem {
     double row[SKL_LEN + 8][64];
     u64 flag[SKL_N][64];
@@ -326,7 +329,7 @@ __device__ __forceinline__ int raw_window_dp_lane_lds(const double *sig, int len
 #define SKIP_LEN_B 1792
 #define SKIP_BITS_B 1024 // u64 words of traceback flags (n * ceil(len / 64))
 
-#define SKP_LDS_DELS 1024
+#define SKP_LDS_DELS 256   // (6 KB of LDS: the scan of the boundaries wants many wavefronts per CU)
 __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, const DevParams *dp,
     const i64 *dp_segs, i64 *segs_out, i64 *win_scratch, i64 *skipq, i32 *lists, i64 list_cap)
 {
