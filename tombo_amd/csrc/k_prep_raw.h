@@ -44,8 +44,11 @@ __device__ __forceinline__ i64 stall_word_base(const ReadState &r, i64 read_inde
 // NW > 0: n_windows as a compile-time constant (7 = MEAN_STALL_PARAMS), else <= 16 at run time.
 #define SM_T 2048   // metric positions per workgroup step
 #define SM_MAXW 1024 // widest window staged in LDS (wider: straight from memory)
+#ifndef TBA_STALL_WAVES
+#define TBA_STALL_WAVES 4   // wavefronts per SIMD the register allocation leaves room for (104 VGPRs; 5 would need <= 96)
+#endif
 template <int NW>
-__global__ __launch_bounds__(256) void k_stall_metric(const ReadState *rs, const DevParams *dp,
+__global__ __launch_bounds__(256, TBA_STALL_WAVES) void k_stall_metric(const ReadState *rs, const DevParams *dp,
     const double *csum, u64 *bits)
 {
     // the SM_T + window_size sums under a chunk of positions are staged in LDS once (a position
