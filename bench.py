@@ -1099,11 +1099,13 @@ def main():
             dst = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()
             dst.copy_(src)
             torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(4):
-                dst.copy_(src)
-            torch.cuda.synchronize(dev)
-            d2h = 4 * float(1 << 28) / (time.perf_counter() - t0)
+            d2h = 0.0
+            for _ in range(3):                     # (best of three: the first timed copies sometimes run behind the legs' tails)
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    dst.copy_(src)
+                torch.cuda.synchronize(dev)
+                d2h = max(d2h, 4 * float(1 << 28) / (time.perf_counter() - t0))
             del src, dst
             api['d2h_GBps_page_locked'] = round(d2h / 1e9, 1)
             api['d2h_floor_reads_per_s'] = round(n_api / (sig_bytes / d2h), 1)
