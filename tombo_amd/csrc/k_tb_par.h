@@ -45,7 +45,9 @@
 //     The same machine code (hand-assembled, tools/asm_variant.py) fails in 8-16 of 24 runs when the
 //     kernel descriptor allocates 224 VGPRs (28 granules: what the compiler had chosen, two wavefronts
 //     per SIMD) and in 0 of 24 with 225-256, the instructions untouched; s_nop / s_waitcnt padding
-//     anywhere in the failing binary changes nothing.  Idle and read-verify probes of a 224-register
+//     anywhere in the failing binary changes nothing.  The moment is known too: in every failing
+//     wavefront the SIMD's other wavefront terminated inside the failing one's phase B (time stamps,
+//     -DTBA_TB_TIMES) -- that is what "only second residents" was.  Idle and read-verify probes of a 224-register
 //     allocation (tools/vgpr_probe) see no register change, so the trigger needs this kernel's
 //     activity and is not understood further; the kernels here keep away from that allocation
 //     (TBP_NOT_224_VGPRS, and tests/test_kernel_resources.py holds every kernel of the library to it).
@@ -236,6 +238,11 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     __shared__ volatile int occ_pad[40 * 256];      // (40 KB per one-wavefront workgroup: four wavefronts on a CU)
     if (n_reads < 0) occ_pad[lane] = lane;
 #endif
+#ifdef TBA_TB_TIMES
+    // (experiment: when and where the wavefront ran -- start / end on the 100 MHz counter and HW_ID into the read's dbg[],
+    // to see which wavefronts shared a SIMD with one that failed; profiles/r06_traceback_rootcause.txt)
+    const i64 tt0 = (i64)__builtin_amdgcn_s_memrealtime();
+#endif
     const i64 slot = (i64)blockIdx.x * RPW + g;
     const bool have = slot < n_reads;
     const i64 ri = have ? (idx ? (i64)idx[slot] : slot) : 0;
@@ -294,6 +301,9 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     const i64 lo2 = c + 1 >= n_chunks - 1 || lo - L < 0 ? 0 : lo - L; // lo of chunk c + 1
     i64 merged_row = TBP_NONE;
     int rcB = TBA_OK;
+#ifdef TBA_TB_TIMES
+    const i64 ttB0 = (i64)__builtin_amdgcn_s_memrealtime();
+#endif
 #if defined(TBA_PHASE_DEBUG) && TBA_PHASE_DEBUG == 12
     int dbg_st = 0;
     int *dbg_stp = &dbg_st;
@@ -316,6 +326,9 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
             }
         }
     }
+#ifdef TBA_TB_TIMES
+    const i64 ttB1 = (i64)__builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef TBA_TB_INJECT
     // (test build, libtombo_amd_inject.so: the round-5 fault made deterministic -- the first row under the second
     // chunk top of every TBA_TB_INJECT-th read comes out one event too high; tests/test_gpu_determinism.py
@@ -356,6 +369,14 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     // the read to the serial kernels (tb_done stays 0, top_pos untouched); a finished chain goes to
     // k_tb_par_verify (tb_done = 2), which trims.  An error of a phase A on the true path is the
     // serial walk's own error at that row.
+#ifdef TBA_TB_TIMES
+    if (have && c == 0) {
+        r.dbg[0] = tt0; r.dbg[1] = (i64)__builtin_amdgcn_s_memrealtime();
+        r.dbg[2] = (i64)(u32)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_ID
+                   ((i64)(u32)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); // XCC_ID
+        r.dbg[3] = (i64)blockIdx.x; r.dbg[4] = ttB0; r.dbg[5] = ttB1;
+    }
+#endif
     if (!on || c != 0 || broken || (status != TBA_OK && from_b)) return;
     r.tb_form = LPR; // TBA_TB_FORM_PAR16 / TBA_TB_FORM_PAR64
     if (status != TBA_OK) { r.tb_done = 1; r.status = status; return; }

@@ -9,6 +9,7 @@ for lib in "$@"; do
   if [ "$lib" = "-" ]; then unset TBA_LIB_PATH; name=tree; else export TBA_LIB_PATH=$PWD/$lib; fi
   extra=""
   case $name in *b2*) extra="$extra --aux b2";; esac
+  case $name in *times*) extra="$extra --aux times";; esac
   timeout 900 python tools/tb_hunt.py ${HUNT_KIND---rna} --runs $runs --tag $name $extra > $out/hunt_$name.txt 2>&1
   tail -1 $out/hunt_$name.txt
 done

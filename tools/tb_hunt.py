@@ -28,7 +28,8 @@ def main():
     ap.add_argument('--bandwidth', type=int, default=500)
     ap.add_argument('--rna', action='store_true')
     ap.add_argument('--runs', type=int, default=20)
-    ap.add_argument('--aux', default='', help="'b2': read the experiment build's second / third array")
+    ap.add_argument('--aux', default='', help="'b2': read the experiment build's second / third array; 'times': a -DTBA_TB_TIMES build -- "
+                    "for the wavefronts of a run that differs, who shared their SIMD and when")
     ap.add_argument('--tag', default=os.path.basename(os.environ.get('TBA_LIB_PATH', 'tree')))
     a = ap.parse_args()
     from tombo_amd import _native as N, tombo_stats as ts, tombo_helper as th
@@ -79,6 +80,40 @@ def main():
         d = np.flatnonzero(tb != tb0)
         ds = np.flatnonzero(st != st0)
         df = np.flatnonzero(fm != fm0)
+        if a.aux == 'times' and d.size:
+            dbg = eng.get(N.GET_DEBUG_COUNTERS)[::4]          # one record per wavefront (its first read)
+            t0, t1, hw, b0, b1 = dbg[:, 0], dbg[:, 1], dbg[:, 2], dbg[:, 4], dbg[:, 5]
+            place = (hw >> 32 & 0xf) << 16 | (hw & 0xffff & ~0xf)     # XCC, SE, SH, CU, pipe, SIMD (wave slot masked out)
+            for wv in sorted(set((read_of(d) // 4).tolist()))[:4]:
+                same = np.flatnonzero(place == place[wv])
+                ov = [int(j) for j in same if j != wv and t0[j] < t1[wv] and t1[j] > t0[wv]]
+                print('   wavefront %d: xcc %d hw_id %04x (slot %d), ran %d..%d (%.1f us); on its SIMD %d wavefronts of the kernel in all, '
+                      'overlapping it in time: %s' % (
+                          wv, hw[wv] >> 32 & 0xf, hw[wv] & 0xffff, hw[wv] & 0xf, t0[wv] - t0.min(), t1[wv] - t0.min(), (t1[wv] - t0[wv]) / 100.0,
+                          same.size, [(j, int(hw[j] & 0xf), int(t0[j] - t0.min()), int(t1[j] - t0.min())) for j in ov]), flush=True)
+                # the largest number of wavefronts alive at once on that SIMD
+                ev = sorted([(int(t0[j]), 1) for j in same] + [(int(t1[j]), -1) for j in same])
+                cur = mx = 0
+                for _, dlt in ev:
+                    cur += dlt
+                    mx = max(mx, cur)
+                print('      most wavefronts of this kernel alive at once on that SIMD: %d; its phase B ran %d..%d; SIMD neighbours ended at %s, '
+                      'started at %s (ticks of 10 ns from the kernel\'s first wavefront)' % (
+                          mx, b0[wv] - t0.min(), b1[wv] - t0.min(), [int(t1[j] - t0.min()) for j in same if j != wv],
+                          [int(t0[j] - t0.min()) for j in same if j != wv]), flush=True)
+            # how common is "a SIMD neighbour ends (or starts) inside my phase B" among ALL wavefronts of this run?
+            order = np.argsort(place, kind='stable')
+            n_end = n_start = 0
+            grp = collections.defaultdict(list)
+            for j in range(place.size):
+                grp[int(place[j])].append(j)
+            for js in grp.values():
+                for j in js:
+                    for q in js:
+                        if q != j:
+                            n_end += int(b0[j] <= t1[q] <= b1[j])
+                            n_start += int(b0[j] <= t0[q] <= b1[j])
+            print('      of the %d wavefronts of this run: %d have a SIMD neighbour ENDING inside their phase B, %d one STARTING' % (place.size, n_end, n_start), flush=True)
         if d.size or ds.size or df.size:
             rd = read_of(d)
             bad_reads.update(rd.tolist())

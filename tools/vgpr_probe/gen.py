@@ -1,5 +1,6 @@
 # generates vgpr_probe_<alloc>.s : every wave fills v0..v(NV-1) with a signature, idles a wave-dependent time while
 # neighbours come and go, then checks every register (all lanes hold the same value: v_readfirstlane + scalar compare)
+import os
 import sys
 NV = int(sys.argv[1]); ALLOC = int(sys.argv[2]); name = sys.argv[3]
 L = []
@@ -18,12 +19,34 @@ for n in range(NV):
     A('\tv_mov_b32_e32 v%d, s8' % n)
     A('\tv_add_u32_e32 v%d, %d, v%d' % (n, n, n))
 A('\ts_waitcnt lgkmcnt(0)')
+if os.environ.get('LOADS'):
+    A('\tv_mbcnt_lo_u32_b32 v159, -1, 0'); A('\tv_mbcnt_hi_u32_b32 v159, -1, v159'); A('\tv_lshlrev_b32_e32 v159, 4, v159')
+    A('\ts_and_b32 s16, s2, 1023'); A('\ts_lshl_b32 s16, s16, 10'); A('\tv_add_u32_e32 v159, s16, v159')
+    A('\ts_add_u32 s14, s4, 0x1000000'); A('\ts_addc_u32 s15, s5, 0')
 # idle: (wg & 7) * base + base iterations of s_sleep
 A('\ts_and_b32 s9, s2, 7'); A('\ts_add_u32 s9, s9, 1'); A('\ts_mul_i32 s9, s9, s6')
-A('\ts_mov_b32 s20, -1'); A('\ts_mov_b32 s21, 0'); A('\ts_mov_b32 s22, 0'); A('\ts_mov_b64 s[24:25], 0')
+A('\ts_mov_b32 s20, -1'); A('\ts_mov_b32 s21, 0'); A('\ts_mov_b32 s22, 0'); A('\ts_mov_b64 s[24:25], 0'); A('\ts_mov_b32 s13, 0')
 A('.Lidle_%s:' % name)
 import os
-if os.environ.get('ACTIVE'):
+if os.environ.get('LOADS'):
+    # sixteen 16-byte loads into v[160:223] per iteration from a buffer of 0x5a5a5a5a words (the out buffer's tail, filled by
+    # the host), the registers zeroed before: a load whose data does not arrive, or arrives elsewhere, shows in the compare
+    A('\ts_add_u32 s13, s13, 1')
+    for n in range(160, 224):
+        A('\tv_mov_b32_e32 v%d, 0' % n)
+    for k in range(16):
+        A('\tglobal_load_dwordx4 v[%d:%d], v159, s[14:15] offset:%d' % (160 + 4 * k, 163 + 4 * k, 0))
+    A('\ts_waitcnt vmcnt(0)')
+    for n in range(160, 224):
+        A('\tv_cmp_ne_u32_e32 vcc, 0x5a5a5a5a, v%d' % n)
+        A('\ts_or_b64 s[24:25], s[24:25], vcc')
+elif os.environ.get('WRITES'):
+    # every register is incremented in every iteration (a write that is lost shows at the end: the active form only
+    # rewrites a register with itself); s13 counts the iterations this wave really did
+    A('\ts_add_u32 s13, s13, 1')
+    for n in range(NV):
+        A('\tv_add_u32_e32 v%d, 1, v%d' % (n, n))
+elif os.environ.get('ACTIVE'):
     for n in range(NV):
         A('\ts_add_u32 s11, s8, %d' % n)
         A('\tv_cmp_ne_u32_e32 vcc, s11, v%d' % n)
@@ -33,9 +56,11 @@ else:
     A('\ts_sleep 20')
 A('\ts_sub_u32 s9, s9, 1'); A('\ts_cmp_lg_u32 s9, 0'); A('\ts_cbranch_scc1 .Lidle_%s' % name)
 A('\ts_cmp_eq_u64 s[24:25], 0'); A('\ts_cbranch_scc1 .Lclean_%s' % name); A('\ts_mov_b32 s22, 0x10000'); A('.Lclean_%s:' % name)
-for n in range(NV):
+for n in range(NV if not os.environ.get('LOADS') else 159):
     A('\tv_readfirstlane_b32 s10, v%d' % n)
     A('\ts_add_u32 s11, s8, %d' % n)
+    if os.environ.get('WRITES'):
+        A('\ts_add_u32 s11, s11, s13')
     A('\ts_cmp_eq_u32 s10, s11')
     A('\ts_cbranch_scc1 .Lok_%s_%d' % (name, n))
     A('\ts_add_u32 s22, s22, 1')

@@ -12,7 +12,9 @@ int main(int argc, char **argv)
     hipModule_t mod; hipFunction_t fn;
     CK(hipModuleLoad(&mod, path));
     CK(hipModuleGetFunction(&fn, mod, name));
-    unsigned *d_out; CK(hipMalloc((void **)&d_out, (size_t)n_wg * 16));
+    unsigned *d_out; CK(hipMalloc((void **)&d_out, (size_t)(1 << 24) + (2 << 20)));   // results (<= 16 MiB) + 2 MiB of 0x5a5a5a5a for the LOADS kernels
+    if ((size_t)n_wg * 16 > (size_t)(1 << 24)) { printf("too many waves\n"); return 1; }
+    CK(hipMemset((char *)d_out + (1 << 24), 0x5a, 2 << 20));
     std::vector<unsigned> out((size_t)n_wg * 4);
     long bad_total = 0;
     for (int r = 0; r < reps; r++) {
