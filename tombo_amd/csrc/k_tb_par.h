@@ -115,13 +115,28 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
     const bool use_strip = strip_s0 >= 0 && r0 - (TBR - 1) > n_static && bp_guess >= strip_s0 + 24 &&
                            bp_guess < strip_s0 + 60;
     if (use_strip) wb = strip_s0 >> 4;
+    // band starts (and, phase B / verifier, the recorded path) of two rows per 16-byte access: the lanes of a wavefront
+    // walk 64 different parts of the reads, so every memory instruction is 64 separate requests whatever its width --
+    // the kernel is bound by their number (48 per block of 16 rows with one row per access)
+#pragma unroll
+    for (int k = 0; k < TBR; k += 2) {
+        const i64 rb = r0 - k - 1;                      // the lower row of the pair (rows r0 - k and r0 - k - 1)
+        const i64 rbc = rb >= 1 ? rb : 1;
+        union { f64x2_u d; i64 q[2]; } u;
+        u.d = *(const f64x2_u *)(st + rbc - 1);         // (st[rb - 1], st[rb]) = the entries of rows rb and rb + 1
+        stv[k + 1] = u.q[0];
+        stv[k] = rb >= 1 ? u.q[1] : u.q[0];             // (below row 1 both clamp to row 1's entry, as one row per access did)
+        if (EXT) {
+            u.d = *(const f64x2_u *)(tb + rbc - 1);
+            oldv[k + 1] = u.q[0];
+            oldv[k] = rb >= 1 ? u.q[1] : u.q[0];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < TBR; k++) {
         const i64 rr = r0 - k;
         const i64 rc_ = rr >= 1 ? rr : 1;
-        stv[k] = st[rc_ - 1];
         win[k] = use_strip ? *(const uint4 *)(strip + rc_ * MV_STRIP_BYTES) : *(const uint4 *)(mv + rc_ * rowb + 4 * wb);
-        if (EXT) oldv[k] = tb[rc_ - 1];
     }
     u64 nzl[TBR], nzh[TBR], d2l[TBR], d2h[TBR];
     int fl_full[TBR], m2_full[TBR];
@@ -135,9 +150,15 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
         fl_full[k] = nzl[k] ? 31 - (cf >> 1) : -1;
         m2_full[k] = (int)((d2l[k] >> (2 * (fl_full[k] & 31))) & 1ull);
     }
+    static_assert(TBR % 2 == 0, "rows are loaded and stored in pairs");
+    bool pend_a = false;                            // (phase A: the even row's value, waiting for its pair)
+    i64 pend_v = 0;
 #pragma unroll
     for (int k = 0; k < TBR; k++) {
         const i64 rr = r0 - k;
+        bool sa = false;                            // phase A: this row has a value to record (sv), stored with its pair row
+        i64 sv = 0;
+        {
         const bool act = rr > stop && rr >= 1 && rc == TBA_OK && (!EXT || VER || merged_row == TBP_NONE);
         const i64 bp64 = cur_ev - stv[k];
         int bp = (int)bp64;
@@ -157,7 +178,7 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
         if (fast) bp = 16 * wb + f;
         if (__builtin_expect(act && !fast, 0)) {
             // outside the window, or nothing but stays down to its start
-            if (bp64 >= Wi || bp64 < -Wi) { rc = TBA_INTERNAL; continue; }
+            if (bp64 >= Wi || bp64 < -Wi) { rc = TBA_INTERNAL; goto row_end; }
             if (in_win) bp = wb > 0 ? 16 * wb - 1 : -1; // everything in the window was a stay
             const unsigned char *row = mv + rr * rowb;
             // the highest non-stay cell at or below bp, 32 cells (one aligned 8-byte load) at a time
@@ -185,7 +206,7 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
                     m = MVG(bp);
                 }
 #undef MVG
-                if (rc != TBA_OK) continue;
+                if (rc != TBA_OK) goto row_end;
             }
         }
         if (m == 2) bp--;
@@ -200,9 +221,23 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
                 if (VER) { if (oldv[k] != cur_ev + 1) ++*dbg_stores; }
                 else if (EXT && rr - 1 >= cmp_lo && oldv[k] == cur_ev + 1) merged_row = rr - 1;
                 else {
-                    if (EXT) TBP_B_STORE(tb, rr - 1, cur_ev + 1); else tb[rr - 1] = cur_ev + 1;
+                    if (EXT) TBP_B_STORE(tb, rr - 1, cur_ev + 1); else { sa = true; sv = cur_ev + 1; }
                     if (EXT && dbg_stores) ++*dbg_stores;
                 }
+            }
+        }
+        }
+row_end:
+        if (MODE == TBP_A) {
+            // rows r0 - k (even k) and r0 - k - 1 are neighbours in read_tb: one 16-byte store for the pair
+            if ((k & 1) == 0) { pend_a = sa; pend_v = sv; }
+            else if (pend_a && sa) {
+                union { f64x2_u d; i64 q[2]; } u;
+                u.q[0] = sv; u.q[1] = pend_v;
+                *(f64x2_u *)(tb + rr - 1) = u.d;
+            } else {
+                if (pend_a) tb[rr] = pend_v;
+                if (sa) tb[rr - 1] = sv;
             }
         }
     }
@@ -369,6 +404,11 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     // the read to the serial kernels (tb_done stays 0, top_pos untouched); a finished chain goes to
     // k_tb_par_verify (tb_done = 2), which trims.  An error of a phase A on the true path is the
     // serial walk's own error at that row.
+#ifdef TBA_TB_DRAIN
+    // (experiment: no load of this wavefront is still in flight when it terminates -- the rows a phase B prefetched and
+    // never looked at are otherwise pending at s_endpgm)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 #ifdef TBA_TB_TIMES
     if (have && c == 0) {
         r.dbg[0] = tt0; r.dbg[1] = (i64)__builtin_amdgcn_s_memrealtime();

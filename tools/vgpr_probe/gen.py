@@ -28,7 +28,31 @@ A('\ts_and_b32 s9, s2, 7'); A('\ts_add_u32 s9, s9, 1'); A('\ts_mul_i32 s9, s9, s
 A('\ts_mov_b32 s20, -1'); A('\ts_mov_b32 s21, 0'); A('\ts_mov_b32 s22, 0'); A('\ts_mov_b64 s[24:25], 0'); A('\ts_mov_b32 s13, 0')
 A('.Lidle_%s:' % name)
 import os
-if os.environ.get('LOADS'):
+if os.environ.get('MASKS'):
+    # the failing decision's shape (k_tb_par.h: m = m2 ? 2 : 1 through an SGPR-pair mask a VALU compare has just written,
+    # the result in one of the allocation's top registers, read a few instructions later): compare -> mask -> select -> check,
+    # alternately all-true and all-false, results in v216..v223
+    for n in range(0, 200, 2):
+        t = 216 + (n // 2) % 8
+        A('\tv_cmp_eq_u32_e64 s[26:27], v%d, v%d' % (n, n))          # all ones
+        A('\tv_mov_b32_e32 v215, v%d' % (n + 1))
+        A('\ts_mov_b32 s28, -1')
+        A('\tv_cndmask_b32_e64 v%d, 1, 2, s[26:27]' % t)              # -> 2
+        A('\ts_and_b64 s[26:27], s[26:27], exec')
+        A('\tv_cmp_eq_u32_e32 vcc, 2, v%d' % t)
+        A('\ts_xor_b64 s[30:31], s[28:29], -1')
+        A('\tv_mov_b32_e32 v214, 11')
+        A('\tv_subbrev_co_u32_e32 v213, vcc, 0, v215, vcc')           # v215 - 1 when the select gave 2
+        A('\tv_sub_u32_e32 v213, v215, v213')                         # must be 1
+        A('\tv_cmp_ne_u32_e32 vcc, 1, v213')
+        A('\ts_or_b64 s[24:25], s[24:25], vcc')
+        A('\tv_cmp_ne_u32_e64 s[26:27], v%d, v%d' % (n, n))          # all zeros
+        A('\tv_mov_b32_e32 v215, v%d' % (n + 1))
+        A('\ts_mov_b32 s28, -1')
+        A('\tv_cndmask_b32_e64 v%d, 1, 2, s[26:27]' % t)              # -> 1
+        A('\tv_cmp_ne_u32_e32 vcc, 1, v%d' % t)
+        A('\ts_or_b64 s[24:25], s[24:25], vcc')
+elif os.environ.get('LOADS'):
     # sixteen 16-byte loads into v[160:223] per iteration from a buffer of 0x5a5a5a5a words (the out buffer's tail, filled by
     # the host), the registers zeroed before: a load whose data does not arrive, or arrives elsewhere, shows in the compare
     A('\ts_add_u32 s13, s13, 1')
@@ -56,7 +80,7 @@ else:
     A('\ts_sleep 20')
 A('\ts_sub_u32 s9, s9, 1'); A('\ts_cmp_lg_u32 s9, 0'); A('\ts_cbranch_scc1 .Lidle_%s' % name)
 A('\ts_cmp_eq_u64 s[24:25], 0'); A('\ts_cbranch_scc1 .Lclean_%s' % name); A('\ts_mov_b32 s22, 0x10000'); A('.Lclean_%s:' % name)
-for n in range(NV if not os.environ.get('LOADS') else 159):
+for n in range(NV if not (os.environ.get('LOADS') or os.environ.get('MASKS')) else (159 if os.environ.get('LOADS') else 200)):
     A('\tv_readfirstlane_b32 s10, v%d' % n)
     A('\ts_add_u32 s11, s8, %d' % n)
     if os.environ.get('WRITES'):
