@@ -967,52 +967,7 @@ __device__ inline int dev_banded_traceback(const unsigned char *mv, i64 stride, 
     return TBA_OK;
 }
 
-// start discovery epilogue: traceback, score_valid_bases (tombo_stats.py:2340-2362), events per
-// base (resquiggle.py:740-752) and the retry / fallback decision (resquiggle.py:992-1006).
-// One thread per read.
-__global__ __launch_bounds__(64) void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int mode,
-    const double *event_means, const double *ref_means, const double *ref_sds,
-    const unsigned char *moves, i64 start_moves_stride, i64 *read_tb, double *start_vals)
-{
-    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ri >= n_reads) return;
-    ReadState &r = rs[ri];
-    if (r.status != TBA_OK) return;
-    if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
-    const tba_params &P = dp->p;
-    const i64 nb = P.start_n_bases;
-    const i64 bw = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
-    i64 *tb = read_tb + r.seg_off;
-    int rc = dev_banded_traceback(moves + ri * start_moves_stride, 0, cpl_class(bw), nb, bw,
-                                  nullptr, true, r.top_pos, -1, tb);
-    const double *ev = event_means + r.ev_off;
-    if (rc == TBA_OK && mode == DP_START_TRY && dp->o.check_start_score) {
-        const double *mu = ref_means + r.ref_off, *sd = ref_sds + r.ref_off;
-        double *vals = start_vals + ri * nb;
-        i64 nv = 0;
-        for (i64 i = 0; i < nb; i++) {
-            if (tb[i] == tb[i + 1]) continue;
-            double m = np_sum(ev + tb[i], tb[i + 1] - tb[i]) / (double)(tb[i + 1] - tb[i]);
-            vals[nv++] = fabs((m - mu[i]) / sd[i]);
-        }
-        if (nv == 0) rc = TBA_INVALID_START_PATH;
-        else if (np_sum(vals, nv) / (double)nv > dp->o.sig_match_thresh) rc = TBA_POOR_START;
-    }
-    if (rc == TBA_OK) {
-        r.epb = (double)(tb[nb] - tb[0]) / (double)(nb + 1);
-        r.mapped_start = tb[0];
-        r.start_state = ST_OK;
-        r.start_res[2 * mode] = (double)tb[0];
-        r.start_res[2 * mode + 1] = r.epb;
-        r.n_start_calls = mode + 1;
-    } else if (mode == DP_START_TRY && rc != TBA_INTERNAL) {
-        // except th.TomboError: retry with the save bandwidth or fall back to the static DP
-        r.pad0 = rc; // why the first try failed (stand-alone find_seq_start_in_events reports it)
-        r.start_state = r.n_ev < P.start_save_bw + nb ? ST_STATIC : ST_RETRY;
-    } else {
-        r.status = rc;
-    }
-}
+// (k_start_tb, the start discovery's epilogue, lives in k_tb_par.h: it walks with that file's row blocks)
 
 // the branch of find_adaptive_base_assignment before start discovery (resquiggle.py:984-989)
 __global__ __launch_bounds__(64) void k_path0(ReadState *rs, i64 n_reads, const DevParams *dp)

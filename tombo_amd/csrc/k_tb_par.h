@@ -95,7 +95,9 @@ enum { TBP_A = 0, TBP_B = 1, TBP_V = 2 };
 //   TBP_V (the verifier): nothing is written; every row is compared with what tb holds and the
 //     rows that differ are counted in *dbg_stores (a band-edge violation is not its business: phase B
 //     has seen the same row).
-template <int MODE>
+//   IDENT: the band of row r starts at event r - 1 (the static band of start discovery, resquiggle.py:710-716):
+//     no band-start array to read.
+template <int MODE, bool IDENT = false>
 __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int roww, const i64 *st,
     int Wi, int thresh, i64 r0, i64 stop, i64 &cur_ev, int &bp_guess, int &rc, i64 *tb,
     i64 &viol_lo, i64 cmp_lo, i64 &merged_row, const unsigned char *strip, int strip_s0, i64 n_static,
@@ -123,7 +125,8 @@ __device__ __forceinline__ void tbp_block(const unsigned char *mv, int rowb, int
         const i64 rb = r0 - k - 1;                      // the lower row of the pair (rows r0 - k and r0 - k - 1)
         const i64 rbc = rb >= 1 ? rb : 1;
         union { f64x2_u d; i64 q[2]; } u;
-        u.d = *(const f64x2_u *)(st + rbc - 1);         // (st[rb - 1], st[rb]) = the entries of rows rb and rb + 1
+        if (IDENT) { u.q[0] = rbc - 1; u.q[1] = rbc; }
+        else u.d = *(const f64x2_u *)(st + rbc - 1);    // (st[rb - 1], st[rb]) = the entries of rows rb and rb + 1
         stv[k + 1] = u.q[0];
         stv[k] = rb >= 1 ? u.q[1] : u.q[0];             // (below row 1 both clamp to row 1's entry, as one row per access did)
         if (EXT) {
@@ -427,6 +430,64 @@ __global__ __launch_bounds__(64) void k_main_tb_par(ReadState *rs, i64 n_reads, 
     r.tb_done = 1;
     tbp_trim(r, tb, B);
 #endif
+}
+
+// start discovery epilogue: traceback, score_valid_bases (tombo_stats.py:2340-2362), events per
+// base (resquiggle.py:740-752) and the retry / fallback decision (resquiggle.py:992-1006).
+// One thread per read.
+__global__ __launch_bounds__(64) void k_start_tb(ReadState *rs, i64 n_reads, const DevParams *dp, int mode,
+    const double *event_means, const double *ref_means, const double *ref_sds,
+    const unsigned char *moves, i64 start_moves_stride, i64 *read_tb, double *start_vals)
+{
+    i64 ri = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= n_reads) return;
+    ReadState &r = rs[ri];
+    if (r.status != TBA_OK) return;
+    if (r.start_state != (mode == DP_START_TRY ? ST_TRY : ST_RETRY)) return;
+    const tba_params &P = dp->p;
+    const i64 nb = P.start_n_bases;
+    const i64 bw = mode == DP_START_TRY ? P.start_bw : P.start_save_bw;
+    i64 *tb = read_tb + r.seg_off;
+    // c_banded_traceback over the start band (identity band starts, no band-edge test) in blocks of TBR rows: their
+    // 64-cell windows fetched together (tbp_block; a cell-by-cell walk is a dependent memory round trip per cell --
+    // 0.5 ms per launch for 250 rows, whatever the batch)
+    int rc = TBA_OK;
+    {
+        const unsigned char *mv = moves + ri * start_moves_stride;
+        const int rowb = (int)mv_row_bytes(bw), roww = rowb / 4;
+        i64 cur = r.top_pos + (nb - 1), viol = TBP_NONE, none = TBP_NONE;
+        int guess = (int)r.top_pos;
+        tb[nb] = cur + 1;
+        for (i64 r0 = nb; r0 >= 1 && rc == TBA_OK; r0 -= TBR)
+            tbp_block<TBP_A, true>(mv, rowb, roww, nullptr, (int)bw, -1, r0, 0, cur, guess, rc, tb, viol, 0, none, nullptr, -1, 0);
+    }
+    const double *ev = event_means + r.ev_off;
+    if (rc == TBA_OK && mode == DP_START_TRY && dp->o.check_start_score) {
+        const double *mu = ref_means + r.ref_off, *sd = ref_sds + r.ref_off;
+        double *vals = start_vals + ri * nb;
+        i64 nv = 0;
+        for (i64 i = 0; i < nb; i++) {
+            if (tb[i] == tb[i + 1]) continue;
+            double m = np_sum(ev + tb[i], tb[i + 1] - tb[i]) / (double)(tb[i + 1] - tb[i]);
+            vals[nv++] = fabs((m - mu[i]) / sd[i]);
+        }
+        if (nv == 0) rc = TBA_INVALID_START_PATH;
+        else if (np_sum(vals, nv) / (double)nv > dp->o.sig_match_thresh) rc = TBA_POOR_START;
+    }
+    if (rc == TBA_OK) {
+        r.epb = (double)(tb[nb] - tb[0]) / (double)(nb + 1);
+        r.mapped_start = tb[0];
+        r.start_state = ST_OK;
+        r.start_res[2 * mode] = (double)tb[0];
+        r.start_res[2 * mode + 1] = r.epb;
+        r.n_start_calls = mode + 1;
+    } else if (mode == DP_START_TRY && rc != TBA_INTERNAL) {
+        // except th.TomboError: retry with the save bandwidth or fall back to the static DP
+        r.pad0 = rc; // why the first try failed (stand-alone find_seq_start_in_events reports it)
+        r.start_state = r.n_ev < P.start_save_bw + nb ? ST_STATIC : ST_RETRY;
+    } else {
+        r.status = rc;
+    }
 }
 
 // The verifier, behind the kernel boundary (what the result rests on: top of this file).  Same lanes,
