@@ -261,6 +261,7 @@ __device__ __forceinline__ double shift_cells(double (&Q)[CPL])
 //   prev row : registers + DPP (above); cells >= W hold -inf so out-of-band candidates need no guards
 //   mu/sd    : prefetched one row ahead
 template <bool B> struct BoolTag { static constexpr bool value = B; };
+template <int I> struct IntTag { static constexpr int value = I; };
 
 template <int CPL, bool DIRECT>
 // Waves per SIMD the register allocation of the classes up to 8 cells per lane is held to: 4 (128

@@ -935,12 +935,17 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
 // intercept.  One workgroup per read; the (<= 1000) points sit in LDS, the n(n-1)/2 slopes are
 // recomputed inside every radix-select pass instead of being stored (4 MB per read otherwise).
 // Pair enumeration by circular distance: (i, (i+d) mod n); slope(i,j) == slope(j,i) bitwise.
+#ifndef TSW_SAMPLE_DIST
 #define TSW_SAMPLE_DIST 128 // distances in the window sample: at most ...
+#endif
 #ifndef TSW_SAMPLE_MIN
-#define TSW_SAMPLE_MIN 96   // ... and at least (scratch permitting: see the sample size below)
+#define TSW_SAMPLE_MIN 48   // ... and at least (scratch permitting: see the sample size below)
 #endif
 #define TSW_MIN_POINTS 256  // below this the generic two-pass select is cheap anyway
 #define TSW_REL 1e-5        // guard band of the approximate classification (see below)
+#ifndef TSW_STEP
+#define TSW_STEP 8          // partners per step of the pass over the pairs (their LDS loads go out together)
+#endif
 // The per-base means the fit needs (ts.compute_base_means = c_new_means, _c_helper.pyx:59-71,
 // over the resolved boundaries) are computed here, for the <= 1000 sampled bases only: a thread
 // sums its base's samples in order and divides once -- a read of 10 000 bases touches a tenth of
@@ -949,7 +954,7 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
     const double *norm, const i64 *segs, const double *ref_means, i64 *samp_ind, double *scratch,
     double *scratch2)
 {
-    __shared__ BucketSmem sm;
+    __shared__ alignas(16) BucketSmem sm; // (16: the sorted points of the pair pass are read as double2)
     __shared__ u32 s_ncand;
     __shared__ double s_win[2];
     __shared__ int s_win_ok;
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
     // all n(n-1)/2 pairs by circular distance d: (i, (i+d) mod n) for d = 1..(n-1)/2, plus
     // (i, i + n/2) for i < n/2 when n is even; slope(i,j) == slope(j,i) bitwise.  The loops have
     // workgroup-uniform trip counts (the visitor ballots).
-    auto slopes = [&](auto visit) {
+    auto slopes = [=](auto visit) {   // (closures by value: nothing here may pin a local to scratch)
         // a thread keeps point i and walks the distances four at a time (their LDS loads go out
         // together); dtop = dmax, plus the antipodal distance n/2 for even n (first half of the
         // points only)
@@ -1039,29 +1044,32 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
     //  1. a sample (TSW_SAMPLE_DIST evenly spread circular distances, approximate slopes) is
     //     histogrammed; the buckets at the sample quantiles 0.5 -/+ 4 sigma give a window
     //     [t1, t2) that holds the two middle ranks of ALL slopes with near certainty;
-    //  2. every pair is classified against the window without a division (a sign(b) against
-    //     t |b|, the edges moved outwards by the relative guard band TSW_REL >> 2^-53):
-    //     safely below t1 -> counted; safely above t2 -> nothing; inside the window or within
-    //     the guard band of an edge -> (a, b) is appended to a list in global scratch;
-    //  3. the list (a few thousand pairs) is divided exactly, classified exactly, and the middle
-    //     ranks are selected among the exact in-window slopes.
+    //  2. every pair is classified against the window without a division (the points sorted by
+    //     level, two compares per pair against the edges moved outwards by the relative guard
+    //     band TSW_REL >> 2^-53: see the pass itself): safely below t1 -> counted; safely above
+    //     t2 -> nothing; inside the window or within the guard band of an edge -> WHICH pair it
+    //     is goes to a list in global scratch;
+    //  3. the listed pairs (several thousand) are divided exactly, classified exactly, and the
+    //     middle ranks are selected among the exact in-window slopes.
     // The count below t1 and the in-window multiset are exact, so the result is the reference's
     // np.median; whenever the window misses the middle ranks or the list overflows, the generic
     // form runs instead.
     double slope = 0;
     bool fast_done = false;
-    // (a, b) pairs in this read's slices of the csum and score buffers (n_raw doubles each)
-    const i64 cap1 = r.n_raw / 2, cap2 = scratch2 != nullptr ? r.n_raw / 2 : 0;
+    // the listed pairs (8 bytes each: which pair, then its exact slope) in this read's slices of the csum and
+    // score buffers (n_raw doubles each)
+    const i64 cap1 = r.n_raw, cap2 = scratch2 != nullptr ? r.n_raw : 0;
     const i64 cap = cap1 + cap2 < 65536 ? cap1 + cap2 : 65536;
     if (n >= TSW_MIN_POINTS && scratch != nullptr && cap >= 4096) {
         double *cl1 = scratch + r.raw_off + blockIdx.x, *cl2 = scratch2 + r.raw_off;
-        auto pair_at = [&](i64 k) { return k < cap1 ? cl1 + 2 * k : cl2 + 2 * (k - cap1); };
+        auto pair_at = [=](i64 k) { return k < cap1 ? cl1 + k : cl2 + (k - cap1); };
+        const u32 cap_u = (u32)cap, cap1_u = (u32)(cap1 < 65536 ? cap1 : 65536);
         const int nn = (int)n, dmax = (nn - 1) / 2;
         // Sample size.  The window spans +-4 sigma of a sample quantile, so the list holds about
         // 4 ns / sqrt(sample) pairs.  Measured per workgroup: ~1.3 cycles per sample element,
-        // ~20 per listed pair (scattered append, exact division, select) -- a flat optimum
-        // around 64-128 k samples for 1000 points; more when the scratch is small (the list
-        // should stay under 60 % of it).
+        // ~15 per listed pair since round 6 (append, exact division, select; ~40 before) -- a flat
+        // optimum around 48 k samples for 1000 points (profiles/r06_theil_sen_phases.txt); more
+        // when the scratch is small (the list should stay under 60 % of it).
         int ds;
         {
             const double want = 4.0 * (double)ns / (0.6 * (double)cap);
@@ -1130,126 +1138,150 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
                 A1 = t1 - t1 * TSW_REL; B2 = t2 + t2 * TSW_REL;
             }
             i64 c_lo = 0;
-            const int dtop = dmax + ((nn & 1) ? 0 : 1);
-            auto classify = [&](double a, double b) {
-                if (b == 0) return; // max_slope = 1000: above the window
-                // a / b against the guarded edges without dividing: the sign of b is folded
-                // into a, then a' < A1 |b|  =>  a / b < A1 (1 + 2^-53) < t1
-                const double ab = fabs(b), as = b < 0 ? -a : a;
-                if (as < A1 * ab) { c_lo++; return; }  // safely below the window
-                if (as >= B2 * ab) return;             // safely above
-                // inside, or too close to an edge to tell (NaNs land here too)
-                const u32 pos = atomicAdd(&s_ncand, 1u);
-                if (pos < cap) { double *pr = pair_at(pos); pr[0] = a; pr[1] = b; }
-            };
-            if (!(nn & 1)) {
-                // Even n (the 1000-point sample): a thread keeps TWO points and walks the distances four
-                // at a time: the 8 pairs need 5 partner points instead of 8 (the pass was bound by LDS
-                // bandwidth).  The circle is walked in the order slot 0, nh, 1, nh + 1, ... (any order of
-                // the point set gives every unordered pair once): thread t holds positions 2t and 2t + 1 =
-                // slots t and nh + t, the partner at position 2t + c sits in slot (c & 1) nh + (t + c / 2)
-                // mod nh -- consecutive threads, consecutive slots.
-                // Round 5: no branch per pair.  A pair is two subtractions, the sign fold as a bit
-                // operation, two products and three compares whose lane masks are combined and counted on
-                // the scalar unit (the count below the window lives in an SGPR per wavefront); the pairs
-                // that go to the list -- 1-2 % -- are appended once per step of eight pairs, behind ONE
-                // wave-uniform branch and one LDS counter bump.  (Before: four nested exec-mask regions
-                // per pair, a per-lane 64-bit counter, a counter bump per pair instruction that had a
-                // listed lane -- ~20 instructions per pair against ~9; profiles/r05_theil_sen_phases.txt.)
-                const int nh = nn / 2;
-                const bool okr = tid < nh;
-                const int tc = okr ? tid : 0;
-                const int lane = tid & 63;
-                const double eA = s_ev[tc], mA = s_md[tc], eB = s_ev[nh + tc], mB = s_md[nh + tc];
-                // the antipodal distance nh only from the first half of the circle
-                const int dlimA = okr ? (2 * tc < nh ? nh : nh - 1) : 0;
-                const int dlimB = okr ? (2 * tc + 1 < nh ? nh : nh - 1) : 0;
-                const u64 okm = __ballot(okr);
-                i64 wave_lo = 0;
-                auto step = [&](const int d0, auto tail_tag) __attribute__((always_inline)) {
-                    constexpr bool TAIL = decltype(tail_tag)::value;
-                    double ep[5], mp[5];
-#pragma unroll
-                    for (int u = 0; u < 5; u++) {
-                        const int c = d0 + u;
-                        int h = tc + (c >> 1);
-                        h = h >= nh ? h - nh : h;
-                        const int slot = (c & 1) ? nh + h : h;
-                        ep[u] = s_ev[slot]; mp[u] = s_md[slot];
+            // Round 6: a pair costs two single-precision compares.  The points are sorted by (level, model
+            // mean) into the histogram's LDS (free once the window is known; s_ev / s_md stay as they were),
+            // and every point k gets u1[k] = m_k - A1 e_k and u2[k] = m_k - B2 e_k, rounded to float.  For
+            // i < j in that order e_j >= e_i, so
+            //    u1[j] < u1[i] - tau  =>  (m_j - m_i) - A1 (e_j - e_i) < 0  =>  e_j > e_i (equal levels come
+            //                             in ascending m) and the pair's slope is below A1: counted;
+            //    u2[j] > u2[i] + tau  =>  the slope is above B2, or e_j == e_i (the reference's max_slope =
+            //                             1000): nothing;
+            //    neither              =>  in the window or too close to tell: listed (a, b) from the double
+            //                             points, divided exactly in step 3.
+            // tau = 2^-20 (max |m| + 3 max |e|) is sixteen times the rounding of a float u (the double
+            // arithmetic behind it is 2^-29 of that) -- against it twice plus the rounding of u[i] -/+ tau;
+            // the computed slope is within 3 2^-53 of the real one and TSW_REL = 1e-5 covers that as before.
+            // What tau adds to the list is the pairs within ~1e-5 / (e_j - e_i) of a window edge: a few.
+            // A wavefront takes blocks of 64 rows i (a lane each) against chunks of 64 later points j: the
+            // chunk is loaded once (a lane each), u[j] comes to the compares through v_readlane (an SGPR
+            // operand: as 64-lane LDS broadcasts the loads alone took as long as the old pass), the lane
+            // masks are combined and counted on the scalar unit.  Row blocks are handed out in mirrored
+            // pairs (block b and the last-but-b share the chunks: n + 64 partners together, every
+            // wavefront the same).  Before: two differences, a sign fold, two products, three double
+            // compares per pair and 1.25 LDS loads of 16 bytes -- 52 % of this kernel
+            // (profiles/r05_theil_sen_phases.txt).
+            double2 *sp = (double2 *)sm.raw8;                       // sorted (e, m) ...
+            float2 *sf = (float2 *)(sp + 1024);                     // ... and their (u1, u2)
+            int np2 = 256;
+            while (np2 < nn) np2 <<= 1;
+            for (int k = tid; k < np2; k += SEL_NT) {
+                double2 v;
+                v.x = k < nn ? s_ev[k] : INFINITY; v.y = k < nn ? s_md[k] : INFINITY;
+                sp[k] = v;
+            }
+            __syncthreads();
+            for (int kk = 2; kk <= np2; kk <<= 1)
+                for (int jj = kk >> 1; jj >= 1; jj >>= 1) {
+                    for (int t = tid; t < np2 / 2; t += SEL_NT) {
+                        const int i = 2 * t - (t & (jj - 1)), p = i + jj;
+                        const double2 x = sp[i], y = sp[p];
+                        const bool gt = x.x > y.x || (x.x == y.x && x.y > y.y);
+                        if (gt == ((i & kk) == 0)) { sp[i] = y; sp[p] = x; }
                     }
-                    u64 cm[8];
-                    u32 n_list = 0;
+                    // thread t's pair lies in the 128 points [128 (t / 64), +128) while jj <= 64: a wavefront
+                    // works on its own points then, and its LDS operations complete in order -- the
+                    // workgroup meets only around the steps that reach further (14 of the 55 for 1024 points)
+                    const int jnext = jj > 1 ? jj >> 1 : (kk < np2 ? kk : 1 << 30);
+                    if (jj > 64 || jnext > 64 || np2 / 2 > SEL_NT) __syncthreads();
+                    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+                }
+            double mx = 0;
+            const int nblk = (nn + 63) / 64;
+            for (int k = tid; k < 64 * nblk; k += SEL_NT) {
+                float2 u;
+                u.x = u.y = INFINITY;                                // past the end: never below, never listed
+                if (k < nn) {
+                    const double2 v = sp[k];
+                    u.x = (float)(v.y - A1 * v.x); u.y = (float)(v.y - B2 * v.x);
+                    mx = fmax(mx, fabs(v.y) + 3.0 * fabs(v.x));
+                }
+                sf[k] = u;
+            }
+            for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, shfl_f64(mx, (tid & 63) ^ m));
+            if ((tid & 63) == 0) sm.redd[tid >> 6] = mx;
+            __syncthreads();
+            for (int w = 0; w < SEL_NT / 64; w++) mx = fmax(mx, sm.redd[w]);
+            const float tau = (float)(0x1p-20 * mx);
+            TBA_PHASE(3, 6);
+            const int lane = tid & 63, wv = tid >> 6;
+            i64 wave_lo = 0;
+            for (int bk = wv; bk < (nblk + 1) / 2; bk += SEL_NT / 64) {
+                const int bA = bk, bB = nblk - 1 - bk;              // bA <= bB; every row of bA exists
+                const int rowA = 64 * bA + lane, rowB = 64 * bB + lane, rcB = rowB < nn ? rowB : nn - 1;
+                const u64 okmB = __ballot(rowB < nn);
+                const float2 fa = sf[rowA], fb = sf[rcB];
+                const float cA1 = fa.x - tau, cA2 = fa.y + tau, cB1 = fb.x - tau, cB2 = fb.y + tau;
+                // one chunk of 64 partners.  MODE 0: the rows of bA against their own block (j > i only);
+                // 1: bA against a later chunk; 2: bA against bB's chunk, and bB against its own; 3: both
+                auto chunk = [&](const int jc, auto mode_tag) __attribute__((always_inline)) {
+                    constexpr int MODE = decltype(mode_tag)::value;
+                    constexpr int NS = MODE >= 2 ? 2 : 1;
+                    const float2 pv = sf[jc + lane];
+                    // The listed pairs -- 1-2 % -- are not appended where they are found (a wave-uniform branch
+                    // for one lane's store: ~100 issue cycles each, 3/4 of this pass when it was done so): a
+                    // lane shifts the listed bit of every partner into a mask of its own (v_addc: one
+                    // instruction), and after 32 partners all lanes append what they have together.
+                    for (int h = 0; h < 64; h += 32) {
+                        u32 lm[NS];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int u = q >> 1;
-                        const double a = (q & 1) ? mB - mp[u + 1] : mA - mp[u];
-                        const double b = (q & 1) ? eB - ep[u + 1] : eA - ep[u];
-                        // a / b against the guarded edges without dividing: the sign of b is folded
-                        // into a, then a' < A1 |b|  =>  a / b < A1 (1 + 2^-53) < t1.  b == 0: the
-                        // reference's slope is max_slope = 1000, above the window (both products are 0
-                        // then and one of the two compares holds: never listed, never counted).
-                        const double ab = fabs(b);
-                        const double as = __hiloint2double(__double2hiint(a) ^ (__double2hiint(b) & (int)0x80000000), __double2loint(a));
-                        u64 lo = __ballot(as < A1 * ab), hi = __ballot(as >= B2 * ab);
-                        const u64 zero = __ballot(ab == 0.0);
-                        u64 ok = okm;
-                        if (TAIL) ok = __ballot(d0 + u <= ((q & 1) ? dlimB : dlimA));
-                        wave_lo += __popcll(lo & ~zero & ok);          // safely below the window
-                        cm[q] = ok & ~(lo | hi);                       // inside, too close to an edge, NaN
-                        n_list += (u32)__popcll(cm[q]);
-                    }
-                    if (n_list) {                                      // (wave-uniform)
-                        u32 base = 0;
-                        if (lane == 0) base = atomicAdd(&s_ncand, n_list);
-                        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                        for (int q = 0; q < NS; q++) lm[q] = 0;
+                        for (int g = h; g < h + 32; g += TSW_STEP) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            if (cm[q] == 0) continue;
-                            const int u = q >> 1;
-                            if ((cm[q] >> lane) & 1ull) {
-                                const u32 pos = base + (u32)__popcll(cm[q] & ((1ull << lane) - 1ull));
-                                if (pos < cap) {
-                                    // (the partner is read from LDS again: keeping the step's eight
-                                    // differences alive for this rare lane cost the kernel its 80-register
-                                    // step -- tests/test_kernel_resources.py)
-                                    const int c = d0 + u + (q & 1);
-                                    int h = tc + (c >> 1);
-                                    h = h >= nh ? h - nh : h;
-                                    const int slot = (c & 1) ? nh + h : h;
-                                    double *pr = pair_at(pos);
-                                    pr[0] = ((q & 1) ? mB : mA) - s_md[slot];
-                                    pr[1] = ((q & 1) ? eB : eA) - s_ev[slot];
+                            for (int u = 0; u < TSW_STEP; u++) {
+                                const int jj = g + u;
+                                const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.x), jj));
+                                const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv.y), jj));
+                                const u64 tri = (1ull << jj) - 1ull;  // the rows of the chunk's own block before j
+#pragma unroll
+                                for (int q = 0; q < NS; q++) {
+                                    const u64 lo = __ballot(s1 < (q ? cB1 : cA1)), hi = __ballot(s2 > (q ? cB2 : cA2));
+                                    u64 ok = q ? okmB : ~0ull;
+                                    if (MODE == (q ? 2 : 0)) ok &= tri;
+                                    wave_lo += __popcll(lo & ok);      // safely below the window
+                                    const u64 cm = ok & ~(lo | hi);    // inside, too close to an edge, NaN
+                                    u64 carry_out;
+                                    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(lm[q]), "=s"(carry_out) : "s"(cm));
                                 }
                             }
-                            base += (u32)__popcll(cm[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < NS; q++) {
+                            u32 m = lm[q];                             // bit 31 - k: partner jc + h + k
+                            if (__ballot(m != 0) == 0) continue;
+                            // where a lane's pairs go: the counts before it (bit plane by bit plane: a count is
+                            // small), one counter bump per wavefront
+                            const u32 cnt = (u32)__popc(m);
+                            const u64 before = (1ull << lane) - 1ull;
+                            u32 pos = 0, tot = 0;
+                            for (int bp = 0; bp < 6; bp++) {
+                                const u64 pl = __ballot((cnt >> bp) & 1u);
+                                pos += (u32)__popcll(pl & before) << bp;
+                                tot += (u32)__popcll(pl) << bp;
+                                if (__ballot(cnt >> (bp + 1)) == 0) break;
+                            }
+                            u32 base = 0;
+                            if (lane == 0) base = atomicAdd(&s_ncand, tot);
+                            pos += (u32)__builtin_amdgcn_readfirstlane((int)base);
+                            const i64 hi16 = (i64)((q ? rcB : rowA) << 16) | (jc + h);
+                            while (m) {
+                                const int k = __clz((int)m);
+                                m &= ~(0x80000000u >> k);
+                                // only WHICH pair (step 3 takes the points out of LDS again)
+                                if (pos < cap_u) *(i64 *)(pos < cap1_u ? cl1 + pos : cl2 + (pos - cap1_u)) = hi16 + k;
+                                pos++;
+                            }
                         }
                     }
                 };
-                int d0 = 1;
-                for (; d0 + 3 <= nh - 1; d0 += 4) step(d0, BoolTag<false>{});   // every distance valid for every thread
-                for (; d0 <= nh; d0 += 4) step(d0, BoolTag<true>{});
-                c_lo = lane == 0 ? wave_lo : 0;
-            } else
-            for (int i0 = 0; i0 < nn; i0 += SEL_NT) {
-                const int i = i0 + tid;
-                const bool okr = i < nn;
-                const int ic = okr ? i : 0;
-                const double ei = s_ev[ic], mi = s_md[ic];
-                const int dlim = okr ? dmax : 0;
-                for (int d0 = 1; d0 <= dtop; d0 += 4) {
-                    double ej[4], mj[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        int j = ic + d0 + u;
-                        j = j >= nn ? j - nn : j;
-                        j = j >= nn ? 0 : j;
-                        ej[u] = s_ev[j]; mj[u] = s_md[j];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (d0 + u <= dlim) classify(mi - mj[u], ei - ej[u]);
-                }
+                chunk(64 * bA, IntTag<0>{});
+                for (int c = bA + 1; c < bB; c++) chunk(64 * c, IntTag<1>{});
+                if (bB != bA) {
+                    chunk(64 * bB, IntTag<2>{});
+                    for (int c = bB + 1; c < nblk; c++) chunk(64 * c, IntTag<3>{});
+                } else                                                // (the middle block of an odd number)
+                    for (int c = bA + 1; c < nblk; c++) chunk(64 * c, IntTag<1>{});
             }
+            c_lo = lane == 0 ? wave_lo : 0;
             c_lo = block_sum_i64(c_lo, &sm.rad);
             __threadfence_block();
             __syncthreads();
@@ -1264,7 +1296,10 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
                 i64 lo_more = 0, inw = 0;
                 for (i64 k = tid; k < n_c; k += SEL_NT) {
                     double *pr = pair_at(k);
-                    const double sl = pr[0] / pr[1];
+                    const i64 ij = *(const i64 *)pr;
+                    const double2 pi = sp[ij >> 16], pj = sp[ij & 0xffff];
+                    const double a = pi.y - pj.y, b = pi.x - pj.x;
+                    const double sl = b == 0.0 ? 1000.0 : a / b;               // (max_slope: _c_helper.pyx:371)
                     const bool below = sl < t1, in = sl >= t1 && sl < t2;
                     lo_more += below; inw += in;
                     pr[0] = in ? sl : INFINITY;
@@ -1273,16 +1308,22 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
                 inw = block_sum_i64(inw, &sm.rad);
                 __threadfence_block();
                 __syncthreads();
-                const i64 k_lo = (ns - 1) / 2 - c_lo, k_hi = ns / 2 - c_lo;
+                // (workgroup-uniform: held in SGPRs across the selection -- as vector registers they were the kernel's one spill)
+                auto uni = [](i64 v) {
+                    return (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)v >> 32)) << 32) |
+                                 (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u64)v));
+                };
+                const i64 k_lo = uni((ns - 1) / 2 - c_lo), k_hi = uni(ns / 2 - c_lo);
                 if (k_lo >= 0 && k_hi < inw) {
-                    const double a = block_kth([&](i64 k) { return pair_at(k)[0]; }, n_c, k_lo, t1, t2, &sm);
+                    double a;                                              // (inlined by request, as the medians below)
+                    [[clang::always_inline]] a = block_kth([=](i64 k) { return pair_at(k)[0]; }, n_c, k_lo, t1, t2, &sm);
                     const int found = sm.found;
                     const double nxt = sm.next;
                     __syncthreads();
                     double b = a;
                     if (k_hi != k_lo) {
                         if (found & 2) b = nxt; // the next order statistic came with the first one
-                        else { b = block_kth([&](i64 k) { return pair_at(k)[0]; }, n_c, k_hi, t1, t2, &sm); __syncthreads(); }
+                        else { [[clang::always_inline]] b = block_kth([=](i64 k) { return pair_at(k)[0]; }, n_c, k_hi, t1, t2, &sm); __syncthreads(); }
                     }
                     slope = (ns & 1) ? a : (a + b) / 2.0;
                     fast_done = true;
@@ -1291,11 +1332,13 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
         }
     }
     TBA_PHASE(3, 3);
-    if (!fast_done) slope = block_median_fe(slopes, ns, 0.5, 1.5, &sm);
+    if (!fast_done) { [[clang::always_inline]] slope = block_median_fe(slopes, ns, 0.5, 1.5, &sm); } // (inlined by request, as the intercepts below)
     TBA_PHASE(3, 4);
     // intercepts of a normalised read sit within a unit or so of 0 (first bucket range only)
-    double inter = block_median_fast([&](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, -2.0,
-                                     2.0, &sm);
+    // (inlined by request: past the kernel's present size the compiler made it a call, with the closure in scratch)
+    double inter;
+    [[clang::always_inline]] inter = block_median_fast([=](i64 i) { return s_md[i] - (slope * s_ev[i]); }, n, -2.0,
+                                                       2.0, &sm);
     TBA_PHASE(3, 5);
     TBA_PHASE_END(3);
     if (tid == 0) {
