@@ -851,7 +851,7 @@ def pack_reads(raws, seqs, reverse=False, pinned=False, n_threads=None, stage=No
     rp = (C.c_void_p * n)(*[_addr(r) for r in raws])
     sp = (C.c_void_p * n)(*seq_ptr)
     if n_threads is None:
-        n_threads = min(16, os.cpu_count() or 1)
+        n_threads = min(int(os.environ.get('TBA_PACK_THREADS', '16')), os.cpu_count() or 1)
     rc = L.tba_pack_reads(i64(n), rp, C.c_int(RAW_DTYPES[dt]), C.c_int(int(bool(reverse))),
                           _p(raw_off, i64), C.c_void_p(_addr(raw)), sp, _p(seq_off, i64),
                           C.cast(C.c_void_p(_addr(seq)), C.POINTER(C.c_uint8)), C.c_int(int(n_threads)))

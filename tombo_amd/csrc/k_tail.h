@@ -943,6 +943,9 @@ __global__ __launch_bounds__(64) void k_skip_dp(ReadState *rs, const DevParams *
 #endif
 #define TSW_MIN_POINTS 256  // below this the generic two-pass select is cheap anyway
 #define TSW_REL 1e-5        // guard band of the approximate classification (see below)
+#ifndef TSW_BM_U
+#define TSW_BM_U 12        // samples of a base in flight per thread (base means; RNA's 40-sample bases: 8 -> 12 = -13 % of the phase, 16 spills)
+#endif
 #ifndef TSW_STEP
 #define TSW_STEP 8          // partners per step of the pass over the pairs (their LDS loads go out together)
 #endif
@@ -970,14 +973,14 @@ __global__ __launch_bounds__(SEL_NT, 6) void k_theil_sen(ReadState *rs, const De
     auto base_mean = [&](i64 k) { // c_new_means: sequential sum, one divide
         const i64 a = sg[k], b = sg[k + 1];
         double acc = 0;
-        // the adds are sequential (the reference's order), the loads are not: eight in flight (a
+        // the adds are sequential (the reference's order), the loads are not: TSW_BM_U in flight (a
         // `load -> add` loop pays a memory round trip per sample of the base: 13 % of this kernel)
-        for (i64 j = a; j < b; j += 8) {
-            double t[8];
+        for (i64 j = a; j < b; j += TSW_BM_U) {
+            double t[TSW_BM_U];
 #pragma unroll
-            for (int u = 0; u < 8; u++) t[u] = x[j + u < b ? j + u : b - 1];
+            for (int u = 0; u < TSW_BM_U; u++) t[u] = x[j + u < b ? j + u : b - 1];
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (j + u < b) acc += t[u];
+            for (int u = 0; u < TSW_BM_U; u++) if (j + u < b) acc += t[u];
         }
         return acc / (double)(b - a);
     };
