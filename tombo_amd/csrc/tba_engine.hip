@@ -102,7 +102,7 @@ struct tba_engine {
     // first consumer (k_remove_stalls; start discovery).  Both groups wait on memory most of their time
     // (SQ_WAIT_ANY 60-80 % of their wave cycles): together they fill what each leaves idle.
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_stalls = nullptr, ev_levels = nullptr, ev_st0 = nullptr, ev_st1 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_stalls = nullptr, ev_levels = nullptr, ev_st0 = nullptr, ev_st1 = nullptr, ev_skip0 = nullptr, ev_skip1 = nullptr;
     hipEvent_t ev[N_STAGE + 1] = {};
     float stage_ms[32] = {};
     bool have_model = false, have_batch = false, ran = false;
@@ -187,7 +187,7 @@ extern "C" int tba_engine_create(int device, tba_engine **out)
     if (const char *v = getenv("TBA_TB_WAVE_BELOW")) e->tb_wave_below = std::max<i64>(atoll(v), 0);
     HIP_TRY(hipStreamCreate(&e->stream));
     if (device < TBA_MAX_DEVICES) g_live_engines[device]++;
-    for (hipEvent_t *x : {&e->ev_fork, &e->ev_stalls, &e->ev_levels, &e->ev_st0, &e->ev_st1}) HIP_TRY(hipEventCreate(x));
+    for (hipEvent_t *x : {&e->ev_fork, &e->ev_stalls, &e->ev_levels, &e->ev_st0, &e->ev_st1, &e->ev_skip0, &e->ev_skip1}) HIP_TRY(hipEventCreate(x));
     for (int i = 0; i <= N_STAGE; i++) HIP_TRY(hipEventCreate(&e->ev[i]));
     *out = e;
     return 0;
@@ -201,7 +201,7 @@ extern "C" void tba_engine_destroy(tba_engine *e)
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     e->release_all();
     for (int i = 0; i <= N_STAGE; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
-    for (hipEvent_t x : {e->ev_fork, e->ev_stalls, e->ev_levels, e->ev_st0, e->ev_st1}) if (x) (void)hipEventDestroy(x);
+    for (hipEvent_t x : {e->ev_fork, e->ev_stalls, e->ev_levels, e->ev_st0, e->ev_st1, e->ev_skip0, e->ev_skip1}) if (x) (void)hipEventDestroy(x);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->device < TBA_MAX_DEVICES) g_live_engines[e->device]--;
@@ -842,9 +842,26 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         k_scan_arena<1><<<1, 256, 0, s>>>(rs, n, e->skip_arena);
 #define SKIP_WAVE_ARGS(c_) rs, dp, e->d_norm.as<double>(), e->d_refm.as<double>(), e->d_refs.as<double>(), e->d_dpsegs.as<i64>(), e->d_segs.as<i64>(), e->d_win.as<i64>(), skipq, lists + 2 * qcap * (c_), qcap
         if (P.raw_min_obs_per_base > 1) { // (k_skip_plan queues nothing otherwise)
-            k_skip_dp_wave<SKIP_LEN_S, SKIP_BITS_S, 0><<<2048, 64, 0, s>>>(SKIP_WAVE_ARGS(0));
-            k_skip_dp_wave<SKIP_LEN_M, SKIP_BITS_M, 1><<<1024, 64, 0, s>>>(SKIP_WAVE_ARGS(1));
+            // The three classes own disjoint windows and each is a queue drained by lone wavefronts whose time is
+            // one lane's stay recurrence: a kernel is as long as its slowest chain of windows, not as its work.
+            // With the side stream the middle class runs beside the big one (142 KB of LDS: one workgroup per
+            // CU, few windows) instead of behind it: 7.46 -> 5.7 ms for the three on cfg4 (tools/skip_timeline.sh;
+            // the small class beside the big one and the other two behind each other: 6.9 for the stage against
+            // 6.5).  TBA_SKIP_FORK=0: one after the other, as before round 6.
+            static const bool fork_off = getenv("TBA_SKIP_FORK") != nullptr && getenv("TBA_SKIP_FORK")[0] == '0';
+            const bool fork = side && !fork_off;
+            hipStream_t sw = fork ? s2 : s;
+            if (fork) {
+                HIP_TRY(hipEventRecord(e->ev_skip0, s));
+                HIP_TRY(hipStreamWaitEvent(s2, e->ev_skip0, 0));
+            }
             k_skip_dp_wave<SKIP_LEN_B, SKIP_BITS_B, 2><<<512, 64, 0, s>>>(SKIP_WAVE_ARGS(2));
+            k_skip_dp_wave<SKIP_LEN_M, SKIP_BITS_M, 1><<<1024, 64, 0, sw>>>(SKIP_WAVE_ARGS(1));
+            k_skip_dp_wave<SKIP_LEN_S, SKIP_BITS_S, 0><<<2048, 64, 0, s>>>(SKIP_WAVE_ARGS(0));
+            if (fork) {
+                HIP_TRY(hipEventRecord(e->ev_skip1, s2));
+                HIP_TRY(hipStreamWaitEvent(s, e->ev_skip1, 0));
+            }
         }
 #undef SKIP_WAVE_ARGS
         // (raw_min_obs_per_base == 1, DNA: the small windows out of LDS -- k_tail.h)
