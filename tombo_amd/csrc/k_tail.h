@@ -570,23 +570,29 @@ __global__ __launch_bounds__(64) void k_skip_plan(ReadState *rs, i64 n_reads, co
 // the stay recurrence) run on lane 0 out of registers, eight positions per LDS round trip.  Only
 // two forward rows are live: the traceback's test "previous base's score > this base's score"
 // (pyx:176-180) is evaluated for every position when a row is finished and kept as one bit.
-template <int LEN, int BITS>
+// LDS is what limits the wavefronts in flight, and the wavefronts in flight are the kernel's speed (each is one lane's
+// recurrence most of the time), so a position costs 36 bytes, not 72 (round 6): the diagonal sources are dropped
+// into the row they are about to become (read a batch ahead of the write), a base's z-scores become their cumulative sums in
+// place (the next base needs exactly those, and the array of the base before is free by then), the counters are 16-bit
+// (<= LEN), and the largest class reads its signal from global memory (SIG_LDS = false: one coalesced pass per base).
+// Workgroups per CU: 5 / 2 / 1 -> 6 / 4 / 2.
+template <int LEN, int BITS, bool SIG_LDS>
 struct SkipWaveSmem {
     double row[2][LEN];            // forward scores of the previous / current base
-    double za[LEN], zb[LEN], cuma[LEN], cumb[LEN], dg[LEN];
-    i32 la[LEN], lb[LEN];          // last-diagonal counters
+    double z[2][LEN];              // z-scores, then cumulative z-scores, of the current base; the previous base's
+    short l[2][LEN];               // last-diagonal counters
     u64 bits[BITS];                // row b, word w: bits[b * words + w]
-    double sg[LEN + 512];          // the window's signal (L = len + (n - 1) m)
     double mu[256], sd[256];       // expected level / sd of the window's bases
+    double sg[SIG_LDS ? LEN + 512 : 1]; // the window's signal (L = len + (n - 1) m)
 };
 #ifdef TBA_SKIP_STATS
 #define SKP(i_) do { const i64 t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) skp[i_] += t_ - tl_; tl_ = __builtin_readcyclecounter(); } while (0)
 #else
 #define SKP(i_) do { } while (0)
 #endif
-template <int LEN, int BITS>
+template <int LEN, int BITS, bool SIG_LDS>
 __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double *means,
-    const double *sds, i64 n, i64 m, bool winsor, double mh, SkipWaveSmem<LEN, BITS> &S, i64 *new_segs
+    const double *sds, i64 n, i64 m, bool winsor, double mh, SkipWaveSmem<LEN, BITS, SIG_LDS> &S, i64 *new_segs
 #ifdef TBA_SKIP_STATS
     , i64 *skp
 #endif
@@ -601,17 +607,17 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
     if (len <= m || len > LEN) return TBA_INTERNAL; // (the planner's windows always have len > 2 m)
     const i64 words = (len + 63) / 64;
     if (n * words > BITS) return TBA_INTERNAL;
-    double *zp = S.za, *zc = S.zb, *cum = S.cuma, *cumn = S.cumb;
-    i32 *pl = S.la, *bl = S.lb;
+    double *cum = S.z[0], *zc = S.z[1]; // cum: np.cumsum of the previous base's scores; zc: this base's, in the making
+    short *pl = S.l[0], *bl = S.l[1];
     if (L > LEN + 512 || n > 256) return TBA_INTERNAL;
     // the whole window's signal and levels come into LDS in one go (all loads in flight together:
     // one global round trip per window instead of one per base)
-    for (i64 k = lane; k < L; k += 64) S.sg[k] = sig[k];
+    if (SIG_LDS) for (i64 k = lane; k < L; k += 64) S.sg[k] = sig[k];
     for (i64 k = lane; k < n; k += 64) { S.mu[k] = means[k]; S.sd[k] = sds[k]; }
-    for (i64 k = lane; k < len; k += 64) pl[k] = (i32)m;
+    for (i64 k = lane; k < len; k += 64) pl[k] = (short)m;
     __syncthreads();
     auto zrow = [&](i64 base, double *z) { // c_base_z_scores, pyx:17-32
-        const double *x = S.sg + base * m;
+        const double *x = (SIG_LDS ? S.sg : sig) + base * m;
         const double mu = S.mu[base], sd = S.sd[base];
         for (i64 k = lane; k < len; k += 64) {
             double v = (x[k] - mu) / sd;
@@ -620,14 +626,14 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
             z[k] = v;
         }
     };
-    zrow(0, zp);
+    zrow(0, cum);
     __syncthreads();
-    if (lane == 0) { // first row: np.cumsum (resquiggle.py:352-361) = the cumulative z-scores too
+    if (lane == 0) { // first row: np.cumsum (resquiggle.py:352-361) = the cumulative z-scores too (in place)
         double acc = 0;
         for (i64 k0 = 0; k0 < len; k0 += 8) {
             double t[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) t[u] = zp[k0 + u < len ? k0 + u : len - 1];
+            for (int u = 0; u < 8; u++) t[u] = cum[k0 + u < len ? k0 + u : len - 1];
 #pragma unroll
             for (int u = 0; u < 8; u++) { acc = k0 + u == 0 ? t[u] : acc + t[u]; t[u] = acc; }
 #pragma unroll
@@ -656,7 +662,7 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
             const i64 di = k + m - lag;
             double diag = pf[di];
             if (lag > 1) diag += cum[k + m - 1] - cum[di];
-            S.dg[k] = diag;
+            bf[k] = diag;                        // (the row two bases back is dead; lane 0 reads a batch, then writes it)
         }
         __syncthreads();
         SKP(5);
@@ -664,7 +670,7 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
             double stay_run = zc[0] + pf[m - 1];
             double csum = zc[0];
             i32 bl_run = 1;
-            bf[0] = stay_run; bl[0] = 1; cumn[0] = csum;
+            bf[0] = stay_run; bl[0] = 1;         // (zc[0] is its own cumulative sum)
             // A lone lane pays for every dependent instruction (~10 cycles each) and dearly for
             // every exec-mask branch, so a step is kept to: best = max(diag, stay) (the selected
             // value of "diag > stay ? diag : stay"; the strict compare only feeds the counter,
@@ -679,7 +685,7 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const i64 k = k0 + u;
-                    dv[u] = S.dg[k <= k_last ? k : k_last]; zv[u] = zc[k];
+                    dv[u] = bf[k <= k_last ? k : k_last]; zv[u] = zc[k]; // (past k_last: whatever is there, not used)
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
@@ -691,15 +697,15 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
                     dv[u] = stay_run; lv[u] = bl_run; cv[u] = csum;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) { bf[k0 + u] = dv[u]; bl[k0 + u] = lv[u]; cumn[k0 + u] = cv[u]; }
+                for (int u = 0; u < 8; u++) { bf[k0 + u] = dv[u]; bl[k0 + u] = (short)lv[u]; zc[k0 + u] = cv[u]; }
             }
             for (i64 k = k0; k < len; k++) {
-                const double d = k <= k_last ? S.dg[k] : -INFINITY, zv = zc[k];
+                const double d = k <= k_last ? bf[k] : -INFINITY, zv = zc[k];
                 const bool take = d > stay_run;
                 stay_run = zv + max_f64_raw(d, stay_run);
                 bl_run = take ? 1 : bl_run + 1;
                 csum = csum + zv;
-                bf[k] = stay_run; bl[k] = bl_run; cumn[k] = csum;
+                bf[k] = stay_run; bl[k] = (short)bl_run; zc[k] = csum;
             }
         }
         if (__syncthreads_or(bad)) return TBA_INTERNAL;
@@ -713,9 +719,8 @@ __device__ inline int raw_window_dp_wave(const double *sig, i64 L, const double 
             if (lane == 0) S.bits[i * words + w0] = mk;
         }
         __syncthreads();
-        i32 *t = pl; pl = bl; bl = t;
-        double *tz = zp; zp = zc; zc = tz;
-        tz = cum; cum = cumn; cumn = tz;
+        short *t = pl; pl = bl; bl = t;
+        double *tz = cum; cum = zc; zc = tz;     // this base's cumulative scores are the next one's `cum`
         SKP(7);
     }
     int rc = TBA_OK;
@@ -757,7 +762,8 @@ __global__ __launch_bounds__(64) void k_skip_dp_wave(ReadState *rs, const DevPar
     const double *norm, const double *ref_means, const double *ref_sds, const i64 *dp_segs,
     i64 *segs, const i64 *win_scratch, i64 *skipq, const i32 *list, i64 list_cap)
 {
-    __shared__ SkipWaveSmem<LEN, BITS> S;
+    constexpr bool SIG_LDS = CLS != 2;           // (the largest class: see SkipWaveSmem)
+    __shared__ SkipWaveSmem<LEN, BITS, SIG_LDS> S;
     __shared__ i64 s_id;
     const tba_params &P = dp->p;
     const i64 m = P.raw_min_obs_per_base;
@@ -778,12 +784,15 @@ __global__ __launch_bounds__(64) void k_skip_dp_wave(ReadState *rs, const DevPar
         const i64 s = w3[3 * i], e = w3[3 * i + 1], n = e - s;
         const i64 sig_start = ds[s], sig_end = ds[e];
         int rc = TBA_OK;
+#ifdef TBA_SKIP_CLASS_STATS
+        const i64 tcs_ = __builtin_readcyclecounter();
+#endif
 #ifdef TBA_SKIP_STATS
         const i64 t0_ = __builtin_readcyclecounter();
 #endif
         if (sig_start < 0 || sig_end > r.norm_len) rc = TBA_INTERNAL;
         else {
-            rc = raw_window_dp_wave<LEN, BITS>(sig + sig_start, sig_end - sig_start,
+            rc = raw_window_dp_wave<LEN, BITS, SIG_LDS>(sig + sig_start, sig_end - sig_start,
                                                ref_means + r.ref_off + s, ref_sds + r.ref_off + s, n, m,
                                                P.do_winsorize_z != 0, P.max_half_z_score, S, out + s + 1
 #ifdef TBA_SKIP_STATS
@@ -796,6 +805,12 @@ __global__ __launch_bounds__(64) void k_skip_dp_wave(ReadState *rs, const DevPar
         }
         // (every failure of the window DP is the same "unexpected error" status)
         if (rc != TBA_OK && threadIdx.x == 0) r.status = rc;
+#ifdef TBA_SKIP_CLASS_STATS   // per read: windows and cycles of every class (tools/stage_times.py, TBA_DBG_PHASES=1: the sums)
+        if (threadIdx.x == 0) {
+            atomicAdd((unsigned long long *)&r.dbg[CLS], 1ull);
+            atomicAdd((unsigned long long *)&r.dbg[3 + CLS], (unsigned long long)(__builtin_readcyclecounter() - tcs_));
+        }
+#endif
 #ifdef TBA_SKIP_STATS
         if (threadIdx.x == 0) {
             atomicAdd((unsigned long long *)&r.dbg[0], 1ull);

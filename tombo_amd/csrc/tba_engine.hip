@@ -844,10 +844,10 @@ static int enqueue_stages(tba_engine *e, int first, int last)
         if (P.raw_min_obs_per_base > 1) { // (k_skip_plan queues nothing otherwise)
             // The three classes own disjoint windows and each is a queue drained by lone wavefronts whose time is
             // one lane's stay recurrence: a kernel is as long as its slowest chain of windows, not as its work.
-            // With the side stream the middle class runs beside the big one (142 KB of LDS: one workgroup per
-            // CU, few windows) instead of behind it: 7.46 -> 5.7 ms for the three on cfg4 (tools/skip_timeline.sh;
-            // the small class beside the big one and the other two behind each other: 6.9 for the stage against
-            // 6.5).  TBA_SKIP_FORK=0: one after the other, as before round 6.
+            // With the side stream the middle class runs beside the big one instead of behind it: 5.0 -> 4.1 ms for
+            // the three on cfg4 (tools/skip_timeline.sh; before the kernels' LDS diet 7.5 -> 5.7; all three at once
+            // on three streams: 3.7-4.1, no better for the stage).  TBA_SKIP_FORK=0: one after the other, as before
+            // round 6.
             static const bool fork_off = getenv("TBA_SKIP_FORK") != nullptr && getenv("TBA_SKIP_FORK")[0] == '0';
             const bool fork = side && !fork_off;
             hipStream_t sw = fork ? s2 : s;
