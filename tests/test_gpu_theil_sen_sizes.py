@@ -1,0 +1,43 @@
+"""k_theil_sen's one-pass median (round 6: sorted points, blocks of 64 rows against chunks of 64 partners, mirrored pairs of
+row blocks) at point counts that exercise every shape of its enumeration: fewer than TSW_MIN_POINTS (the generic two-pass
+select), an odd number of row blocks (the middle block has no mirror), a last block of one row, exactly 1000 and the
+subsampled case -- every read against the oracle (status, boundaries, scale values)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('samp_name,n_bases', [
+    ('DNA', 200), ('DNA', 256), ('DNA', 257), ('DNA', 300), ('DNA', 320), ('DNA', 321), ('DNA', 449), ('DNA', 512),
+    ('DNA', 577), ('DNA', 640), ('DNA', 705), ('DNA', 961), ('DNA', 999), ('DNA', 1000), ('DNA', 1001), ('RNA', 385), ('RNA', 833)])
+def test_reads_of_n_bases_equal_the_oracle(samp_name, n_bases):
+    import oracle
+    from tombo_amd import _native as N
+    from tombo_amd._default_parameters import SIG_MATCH_THRESH
+    from test_gpu_determinism import _device_batch
+    n = 6
+    eng, gen, model, params, raw_off, seq_off = _device_batch(samp_name, n, n_bases, 1000 + n_bases)
+    eng.run()
+    out = eng.download(want_norm=False)
+    si = eng.get(N.GET_SAMP_IND)
+    h_raw, h_seq = gen.download()
+    segs, seg_off = out['segs'], np.asarray(eng.seg_off)
+    checked = 0
+    for i in range(n):
+        raw = h_raw[raw_off[i]:raw_off[i + 1]].astype(np.float64)
+        want = oracle.resquiggle_read(
+            raw, h_seq[seq_off[i]:seq_off[i + 1]], model.level_means, model.level_sds, oracle.make_params(params),
+            oracle.make_opts(model.kmer_width, model.central_pos, outlier_thresh=5.0, sig_match_thresh=SIG_MATCH_THRESH[samp_name]),
+            stall_ints=oracle.identify_stalls(raw) if samp_name == 'RNA' else None, samp_ind=si[i] if n_bases > 1000 else None)
+        assert want['status'] == int(out['status'][i]), (i, want['status'], int(out['status'][i]))
+        if want['status'] == 0:
+            np.testing.assert_array_equal(segs[seg_off[i]:seg_off[i + 1]], want['segs'], err_msg='read %d' % i)
+            # shift, scale (the Theil-Sen fit's output), lower / upper limit: the same bits
+            np.testing.assert_array_equal(np.asarray(out['sv'][i], np.float64).view(np.int64),
+                                          np.asarray(want['scale_values'], np.float64).view(np.int64), err_msg='read %d' % i)
+            assert int(out['read_start'][i]) == want['read_start_rel_to_raw']
+            assert float(out['score'][i]) == want['sig_match_score']
+            checked += 1
+    eng.close(), gen.close()
+    assert checked >= 1
