@@ -48,9 +48,13 @@ def test_reads_of_n_bases_equal_the_oracle(samp_name, n_bases):
     assert checked >= 1
 
 
-@pytest.mark.parametrize('samp_name,n,n_bases', [('RNA', 4096, 3000), ('DNA', 2048, 10000)])
-def test_every_read_of_a_batch_equals_the_oracle(samp_name, n, n_bases):
-    """4 096 RNA reads of 3 kb / 2 048 DNA reads of 10 kb, EVERY one against the oracle (status, boundaries, scale values).
+@pytest.mark.parametrize('samp_name,n,n_bases,bandwidth', [
+    ('RNA', 4096, 3000, 500), ('DNA', 2048, 10000, 500),
+    ('DNA', 1024, 10000, 300),      # Tombo's default band: k_dp<5>
+    ('DNA', 4096, 2000, 100)])      # BASELINE config 1's shape: k_dp_multi<4, 2>, two reads per wavefront
+def test_every_read_of_a_batch_equals_the_oracle(samp_name, n, n_bases, bandwidth):
+    """4 096 RNA reads of 3 kb / 2 048 DNA reads of 10 kb (and the benchmark's two narrower bands), EVERY one against the oracle
+    (status, boundaries, scale values).
     About 6 % of such RNA reads have a skip window of the largest wave class (k_skip_dp_wave<1792>: its signal from global
     memory, round 6), a quarter one of the middle class -- the handful of reads of the other RNA parity tests may have none"""
     import oracle
@@ -59,7 +63,7 @@ def test_every_read_of_a_batch_equals_the_oracle(samp_name, n, n_bases):
     from tombo_amd._default_parameters import SIG_MATCH_THRESH
     from test_gpu_determinism import _device_batch
     rna = samp_name == 'RNA'
-    eng, gen, model, params, raw_off, seq_off = _device_batch(samp_name, n, n_bases, 4242)
+    eng, gen, model, params, raw_off, seq_off = _device_batch(samp_name, n, n_bases, 4242, bandwidth)
     eng.run()
     out = eng.download(want_norm=False)
     si = eng.get(N.GET_SAMP_IND)
@@ -84,4 +88,4 @@ def test_every_read_of_a_batch_equals_the_oracle(samp_name, n, n_bases):
             bad.append('read %d: scale values differ' % i)
     eng.close(), gen.close()
     assert not bad, '\n'.join(bad[:20])
-    assert sum(w['status'] == 0 for w in wants) > 0.9 * n
+    assert sum(w['status'] == 0 for w in wants) > 0.9 * n, sum(w['status'] == 0 for w in wants)
